@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py — GS-ICP-SLAM hot path on MI355X.
+
+One "step" = one SLAM frame's worth of the hot path on synthetic Replica-shaped input:
+  tracker : pygicp.FastGICP  set_input_source + set_source_filter + align + get_source_correspondence
+            on S-pair (8 280 points/frame, max_correspondence_distance 0.02)          [REF mp_Tracker.py:191-231]
+  mapper  : one optimisation iteration's rasteriser work — GaussianRasterizer forward (+ an L1 colour/depth loss to
+            produce image gradients) + backward, P = 300 000 surfels, 1200x680          [REF mp_Mapper.py:219-242]
+With N > 1 GPUs the mapper's tiles are sharded across ranks (strong scaling; gs_icp_slam_amd/sharded.py) and the
+tracker runs as a replica on every rank (it does not shard — DESIGN.md).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, algorithmic bytes
+over HIP-event kernel time) and `cpu_baseline` (the OpenMP GICP oracle timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=300_000)
+    ap.add_argument("--res", choices=["replica", "tum"], default="replica")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gs_icp_slam_amd import _lib, synth
+    from gs_icp_slam_amd.sharded import ShardedGaussianRasterizer
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    import pygicp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = synth.REPLICA if args.res == "replica" else synth.TUM
+    W, H = cfg["W"], cfg["H"]
+    P = args.gaussians
+    # ---------------- mapper inputs (S-map) ----------------
+    cam = synth.make_camera(W, H, cfg["fx"], cfg["fy"], synth.DEFAULT_POSE_A)
+    g = synth.s_map(P, seed=2)
+    params = {k: torch.from_numpy(g[k]).to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+        viewmatrix=torch.from_numpy(cam["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(cam["projmatrix"]).to(dev), sh_degree=0,
+        campos=torch.from_numpy(cam["campos"]).to(dev), prefiltered=False, debug=False)
+    rast = ShardedGaussianRasterizer(rs)
+    with torch.no_grad():   # target images: render of a perturbed copy, so gradients are non-zero
+        g2 = synth.s_map(P, seed=2, perturb_seed=3)
+        t2 = {k: torch.from_numpy(g2[k]).to(dev) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+        gt_depth, gt_color, _, _ = rast(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"],
+                                        opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
+        gt_depth, gt_color = gt_depth.clone(), gt_color.clone()
+        del t2
+
+    # ---------------- tracker inputs (S-pair) ----------------
+    sp = synth.s_pair(cfg, noise=(args.res == "tum"))
+    pw = sp["points_a"].astype(np.float64) @ sp["pose_a"][:3, :3].T + sp["pose_a"][:3, 3]
+
+    def filt(n, tr):
+        f = np.zeros(n, np.int32)
+        f[tr] = np.arange(1, len(tr) + 1)
+        return f
+    f_src = filt(len(sp["points_b"]), sp["trackable_b"])
+
+    def setup_tracker(reg):
+        reg.set_max_correspondence_distance(cfg["max_corr"])
+        reg.set_max_knn_distance(99999.0)
+        reg.set_input_target(pw)
+        reg.set_target_filter(len(sp["trackable_a"]), filt(len(pw), sp["trackable_a"]))
+        reg.calculate_target_covariance_with_filter()
+
+    reg = pygicp.FastGICP()
+    setup_tracker(reg)
+
+    def tracker_step(r):
+        r.set_input_source(sp["points_b"])
+        r.set_source_filter(len(sp["trackable_b"]), f_src)
+        T = r.align(sp["pose_a"])
+        idx, d2 = r.get_source_correspondence()
+        return T, idx, d2
+
+    last = {}
+
+    def step():
+        T, idx, d2 = tracker_step(reg)
+        means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+        depth, color, radii, used = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
+                                         scales=params["scales"], rotations=params["rotations"])
+        loss = (color - gt_color).abs().mean() + 0.1 * ((depth - gt_depth) / 10.0).abs().mean()
+        loss.backward()
+        for p in params.values():
+            p.grad = None
+        last.update(T=T, loss=loss, radii=radii)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    _lib.profile_enable(True)
+    _lib.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---------------- roofline of the dominant kernel ----------------
+    per_launch_us = {k: (1e3 * ms / max(c, 1)) for k, (ms, c) in prof.items() if c > 0}
+    raster_stages = ["preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "tile_ranges", "blend_forward", "blend_backward",
+                     "preprocess_backward", "memset"]
+    dominant = max((k for k in raster_stages if k in per_launch_us), key=lambda k: per_launch_us[k])
+    num_rendered = 0
+    fn_probe = None
+    with torch.no_grad():
+        pass
+    # D (duplicates) and P_vis from one extra forward
+    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
+    depth, color, radii, used = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
+                                     scales=params["scales"], rotations=params["rotations"])
+    node = depth.grad_fn
+    while node is not None and not hasattr(node, "num_rendered"):
+        node = node.next_functions[0][0] if node.next_functions else None
+    D_local = int(getattr(node, "num_rendered", 0))
+    P_vis = int((radii > 0).sum())
+    T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    n_pass = 2  # tile sort: 8 B (key+value) read + written per pass, ceil(bits/8) = 2 passes for T <= 65 536 tiles
+    bytes_fwd_blend = 52.0 * D_local + 24.0 * W * H / world + 8.0 * T_tiles / world        # list + gather 48 B, pixel writes
+    bytes_bwd_blend = 52.0 * D_local + 40.0 * W * H / world + 44.0 * P_vis                  # SURVEY §8d backward formula
+    alg_bytes = {"blend_forward": bytes_fwd_blend, "blend_backward": bytes_bwd_blend,
+                 "preprocess": 128.0 * P, "preprocess_backward": 184.0 * P, "tile_sort": 16.0 * n_pass * D_local,
+                 "depth_sort": 16.0 * 4 * P, "duplicate": 8.0 * D_local + 56.0 * P_vis, "tile_ranges": 4.0 * D_local,
+                 "scan": 12.0 * P, "memset": 44.0 * P}
+    ach = alg_bytes[dominant] / (per_launch_us[dominant] * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "kernel_us": round(per_launch_us[dominant], 2),
+                "algorithmic_bytes": int(alg_bytes[dominant]),
+                "note": "working set < 256 MiB Infinity Cache; stage is latency/issue bound, not HBM bound (DESIGN.md)"}
+
+    # ---------------- CPU baseline: OpenMP GICP oracle (port), rank 0 only ----------------
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle
+        oreg = oracle.OracleGICP()
+        setup_tracker(oreg)
+        tracker_step(oreg)  # warm-up (thread pool, first touch)
+        n, t_cpu0 = 0, time.perf_counter()
+        while time.perf_counter() - t_cpu0 < args.cpu_seconds:
+            To, _, _ = tracker_step(oreg)
+            n += 1
+        t_cpu = time.perf_counter() - t_cpu0
+        cpu = {"value": round(n / t_cpu, 2), "unit": "tracker frames/s (GICP align only; the reference has no CPU rasteriser)",
+               "cores": oreg.num_threads(), "kind": "port",
+               "sample": f"{n} x (set_input_source + align + get_source_correspondence) on S-pair {args.res}, {len(sp['points_b'])} points, "
+                         f"{t_cpu:.1f} s wall",
+               "pose_agrees_with_gpu": bool(np.allclose(To, last["T"], atol=1e-5))}
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        stage_us = {k: round(v, 2) for k, v in per_launch_us.items()}
+        out = {
+            "metric": "SLAM hot-path FPS (GICP tracker align + mapper render fwd+bwd per frame), Replica room0-shaped synthetic",
+            "value": round(args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2] shape: S-pair {args.res} tracker ({len(sp['points_b'])} pts, gate {cfg['max_corr']} m) + "
+                                   f"S-map mapper iteration (P={P}, {W}x{H}, sh_degree 0)", "gaussians": P, "width": W, "height": H,
+                       "duplicates_per_rank": D_local, "visible_gaussians": P_vis,
+                       "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-reduce image + grads), tracker replicated"},
+            "render_bwd_ms_per_iter": round(sum(per_launch_us.get(k, 0.0) for k in raster_stages) / 1e3, 4),
+            "tracker_align_kernel_us": stage_us.get("gicp_align"),
+            "stage_us_per_launch": stage_us,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""ctypes binding of libgsicp_hip.so (the C ABI declared in include/gsicp_hip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing any product module raises.
+PyTorch is used by the callers only for device memory and streams; no torch type crosses this boundary.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsicp_hip.so")
+
+c_void_p, c_int, c_float, c_double, c_size_t, c_char_p = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double,
+                                                          ctypes.c_size_t, ctypes.c_char_p)
+RESIZE_FN = ctypes.CFUNCTYPE(c_void_p, c_void_p, c_size_t)
+
+# Every symbol include/gsicp_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "gsicp_abi_version": (c_int, []),
+    "gsicp_last_error": (c_char_p, []),
+    "gsicp_device_count": (c_int, []),
+    "gsicp_profile_enable": (c_int, [c_int]),
+    "gsicp_profile_num_stages": (c_int, []),
+    "gsicp_profile_stage_name": (c_char_p, [c_int]),
+    "gsicp_profile_read": (c_int, [c_void_p, c_void_p, c_int]),
+    "gsicp_raster_forward": (c_int, [RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, c_int, c_int, c_int, c_void_p,
+                                     c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_void_p]),
+    "gsicp_raster_backward": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gsicp_raster_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsicp_raster_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "gsicp_knn_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
+    "gsicp_gicp_create": (c_void_p, []),
+    "gsicp_gicp_destroy": (None, [c_void_p]),
+    "gsicp_gicp_set_max_correspondence_distance": (c_int, [c_void_p, c_double]),
+    "gsicp_gicp_set_max_knn_distance": (c_int, [c_void_p, c_double]),
+    "gsicp_gicp_set_correspondence_randomness": (c_int, [c_void_p, c_int]),
+    "gsicp_gicp_set_max_iterations": (c_int, [c_void_p, c_int]),
+    "gsicp_gicp_set_num_threads": (c_int, [c_void_p, c_int]),
+    "gsicp_gicp_set_regularization_method": (c_int, [c_void_p, c_int]),
+    "gsicp_gicp_set_rotation_epsilon": (c_int, [c_void_p, c_double]),
+    "gsicp_gicp_set_transformation_epsilon": (c_int, [c_void_p, c_double]),
+    "gsicp_gicp_set_input_target": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "gsicp_gicp_set_input_source": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "gsicp_gicp_set_target_filter": (c_int, [c_void_p, c_int, c_void_p, c_int]),
+    "gsicp_gicp_set_source_filter": (c_int, [c_void_p, c_int, c_void_p, c_int]),
+    "gsicp_gicp_calculate_target_covariance_with_filter": (c_int, [c_void_p]),
+    "gsicp_gicp_calculate_source_covariance": (c_int, [c_void_p]),
+    "gsicp_gicp_get_target_rotationsq": (c_int, [c_void_p, c_void_p, c_int]),
+    "gsicp_gicp_get_target_scales": (c_int, [c_void_p, c_void_p, c_int]),
+    "gsicp_gicp_get_source_rotationsq": (c_int, [c_void_p, c_void_p, c_int]),
+    "gsicp_gicp_get_source_scales": (c_int, [c_void_p, c_void_p, c_int]),
+    "gsicp_gicp_set_target_covariances_fromqs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    "gsicp_gicp_align": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "gsicp_gicp_get_source_correspondence": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "gsicp_gicp_num_source": (c_int, [c_void_p]),
+    "gsicp_gicp_num_target": (c_int, [c_void_p]),
+    "gsicp_gicp_last_align_stats": (c_int, [c_void_p, c_void_p]),
+    "gsicp_gicp_get_final_hessian": (c_int, [c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises ImportError if it is not built — there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -m gs_icp_slam_amd.build` "
+                "(hipcc --offload-arch=gfx950).  gs_icp_slam_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gsicp_abi_version() != 1:
+            raise ImportError("libgsicp_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().gsicp_last_error().decode(errors="replace")
+
+
+def check(rc, what):
+    if rc < 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {last_error()}")
+    return rc
+
+
+def profile_enable(on=True):
+    load().gsicp_profile_enable(int(bool(on)))
+
+
+def profile_read():
+    """-> {stage_name: (total_ms, launches)} accumulated since the last read (synchronises the recorded events)."""
+    lib = load()
+    n = lib.gsicp_profile_num_stages()
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int * n)()
+    lib.gsicp_profile_read(ms, cnt, n)
+    return {lib.gsicp_profile_stage_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}

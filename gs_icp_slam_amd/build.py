@@ -1,0 +1,65 @@
+"""Builds libgsicp_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU.
+
+    python -m gs_icp_slam_amd.build [--force]
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libgsicp_hip.so")
+ARCH = "gfx950"
+
+# (source, extra flags).  raster_preprocess is built without FMA contraction so that the floats feeding integer
+# outputs (sort keys, tile rectangles) are reproducible against the CPU oracle; see the file header.
+SOURCES = [
+    ("raster_preprocess.hip", ["-ffp-contract=off"]),
+    ("raster.hip", []),
+    ("knn.hip", []),
+    ("gicp.hip", ["-ffp-contract=off"]),
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(HERE, "..", "include", "gsicp_hip.h"))
+    objs = []
+    for src, extra in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if force or _newer(obj, [sp] + headers):
+            cmd = [hipcc] + COMMON + extra + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _newer(OUT, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,441 @@
+// Per-Gaussian kernels of the gfx950 rasteriser: forward preprocess (R1), its backward (R8+R9) and mark_visible (R10).
+//
+// Replaces the per-Gaussian stage of diff_gaussian_rasterization reached from
+// GaussianRasterizer.forward [REF gaussian_renderer/__init__.py:294-302] / loss.backward() [REF mp_Mapper.py:242].
+// Quaternions are (x,y,z,w) [REF utils/general_utils.py:89-99]; matrices are row-vector form
+// [REF scene/shared_objs.py:163-166].
+//
+// This translation unit is compiled with -ffp-contract=off: view-space depth (the sort key), the pixel centre,
+// the radius and the tile rectangle feed INTEGER outputs that the parity tests compare bit-exactly, so every
+// float expression here is evaluated left-to-right without FMA fusion.  One thread per Gaussian, 256-thread
+// blocks (4 waves); the work is 56 B read + ~66 B written per Gaussian and embarrassingly parallel, so the
+// kernel is HBM/launch bound.  Camera matrices are wave-uniform and live in SGPRs.
+#include "raster_common.hpp"
+
+namespace gsicp {
+
+namespace {
+
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct Cam {
+    float v[16];
+    float p[16];
+};
+
+__device__ inline void load_cam(const float* view, const float* proj, Cam& c) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c.v[i] = view[i]; c.p[i] = proj[i]; }
+}
+
+__device__ inline void quat_to_R(const float* q, float* Rm) {
+    const float x = q[0], y = q[1], z = q[2], r = q[3];
+    Rm[0] = 1.f - 2.f * (y * y + z * z);
+    Rm[1] = 2.f * (x * y - r * z);
+    Rm[2] = 2.f * (x * z + r * y);
+    Rm[3] = 2.f * (x * y + r * z);
+    Rm[4] = 1.f - 2.f * (x * x + z * z);
+    Rm[5] = 2.f * (y * z - r * x);
+    Rm[6] = 2.f * (x * z - r * y);
+    Rm[7] = 2.f * (y * z + r * x);
+    Rm[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+__device__ inline void cov3_from_scale_rot(const float* s, float mod, const float* q, float* c6) {
+    float Rm[9];
+    quat_to_R(q, Rm);
+    const float s0 = mod * s[0], s1 = mod * s[1], s2 = mod * s[2];
+    float L[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        L[3 * i + 0] = Rm[3 * i + 0] * s0;
+        L[3 * i + 1] = Rm[3 * i + 1] * s1;
+        L[3 * i + 2] = Rm[3 * i + 2] * s2;
+    }
+#define GS_DOT(i, j) (L[3 * (i)] * L[3 * (j)] + L[3 * (i) + 1] * L[3 * (j) + 1] + L[3 * (i) + 2] * L[3 * (j) + 2])
+    c6[0] = GS_DOT(0, 0); c6[1] = GS_DOT(0, 1); c6[2] = GS_DOT(0, 2);
+    c6[3] = GS_DOT(1, 1); c6[4] = GS_DOT(1, 2); c6[5] = GS_DOT(2, 2);
+#undef GS_DOT
+}
+
+// 2x3 matrix M = J * Rw2c with J the perspective Jacobian at the (frustum-clamped) view-space point.
+__device__ inline void ewa_M(const float* t_in, float fx, float fy, float tanx, float tany, const float* view, float* Mm,
+                             float* tcl, bool* clx, bool* cly) {
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    const float txtz = t_in[0] / t_in[2], tytz = t_in[1] / t_in[2];
+    const float cx = fminf(limx, fmaxf(-limx, txtz));
+    const float cy = fminf(limy, fmaxf(-limy, tytz));
+    if (clx) *clx = (txtz < -limx || txtz > limx);
+    if (cly) *cly = (tytz < -limy || tytz > limy);
+    const float tx = cx * t_in[2], ty = cy * t_in[2], tz = t_in[2];
+    if (tcl) { tcl[0] = tx; tcl[1] = ty; tcl[2] = tz; }
+    const float j00 = fx / tz, j02 = -(fx * tx) / (tz * tz);
+    const float j11 = fy / tz, j12 = -(fy * ty) / (tz * tz);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Mm[k] = j00 * view[4 * k + 0] + j02 * view[4 * k + 2];
+        Mm[3 + k] = j11 * view[4 * k + 1] + j12 * view[4 * k + 2];
+    }
+}
+
+__device__ inline void cov2_from_M(const float* Mm, const float* c6, float* abc) {
+    const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+    float v0[3], v1[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v0[i] = S[3 * i] * Mm[0] + S[3 * i + 1] * Mm[1] + S[3 * i + 2] * Mm[2];
+        v1[i] = S[3 * i] * Mm[3] + S[3 * i + 1] * Mm[4] + S[3 * i + 2] * Mm[5];
+    }
+    abc[0] = (Mm[0] * v0[0] + Mm[1] * v0[1] + Mm[2] * v0[2]) + 0.3f;
+    abc[1] = Mm[0] * v1[0] + Mm[1] * v1[1] + Mm[2] * v1[2];
+    abc[2] = (Mm[3] * v1[0] + Mm[4] * v1[1] + Mm[5] * v1[2]) + 0.3f;
+}
+
+__device__ inline void sh_to_rgb(int deg, const float* mean, const float* campos, const float* sh, float* rgb, unsigned* clampmask) {
+    float res[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) res[c] = SH_C0 * sh[c];
+    if (deg > 0) {
+        const float dx = mean[0] - campos[0], dy = mean[1] - campos[1], dz = mean[2] - campos[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx / len, y = dy / len, z = dz / len;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            res[c] = res[c] - SH_C1 * y * sh[3 + c] + SH_C1 * z * sh[6 + c] - SH_C1 * x * sh[9 + c];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                res[c] = res[c] + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] +
+                         SH_C2[2] * (2.f * zz - xx - yy) * sh[18 + c] + SH_C2[3] * xz * sh[21 + c] +
+                         SH_C2[4] * (xx - yy) * sh[24 + c];
+            if (deg > 2) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    res[c] = res[c] + SH_C3[0] * y * (3.f * xx - yy) * sh[27 + c] + SH_C3[1] * xy * z * sh[30 + c] +
+                             SH_C3[2] * y * (4.f * zz - xx - yy) * sh[33 + c] +
+                             SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + c] +
+                             SH_C3[4] * x * (4.f * zz - xx - yy) * sh[39 + c] + SH_C3[5] * z * (xx - yy) * sh[42 + c] +
+                             SH_C3[6] * x * (xx - 3.f * yy) * sh[45 + c];
+            }
+        }
+    }
+    unsigned m = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        res[c] = res[c] + 0.5f;
+        if (res[c] < 0.f) m |= (1u << c);
+        rgb[c] = fmaxf(res[c], 0.f);
+    }
+    *clampmask = m;
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    Cam cam;
+    load_cam(a.view, a.proj, cam);
+    const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
+    const float fx = (float)a.W / (2.f * a.tanfovx), fy = (float)a.H / (2.f * a.tanfovy);
+
+    // defaults for a culled Gaussian
+    a.radii[idx] = 0;
+    a.tiles_touched[idx] = 0;
+    a.depth_keys[idx] = 0xFFFFFFFFu;
+    a.ids[idx] = (uint32_t)idx;
+    a.clamped[idx] = 0;
+    SplatRec rec = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const float p[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    float pv[3];
+    pv[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+    pv[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+    pv[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+    bool ok = pv[2] > 0.2f;
+    if (ok) {
+        const float ph0 = cam.p[0] * p[0] + cam.p[4] * p[1] + cam.p[8] * p[2] + cam.p[12];
+        const float ph1 = cam.p[1] * p[0] + cam.p[5] * p[1] + cam.p[9] * p[2] + cam.p[13];
+        const float ph3 = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
+        const float pw = 1.f / (ph3 + 0.0000001f);
+        const float ndcx = ph0 * pw, ndcy = ph1 * pw;
+        float c6[6];
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = a.cov3D_precomp[6 * idx + k];
+        } else {
+            const float s[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+            const float q[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]};
+            cov3_from_scale_rot(s, a.scale_modifier, q, c6);
+        }
+        float Mm[6], abc[3];
+        ewa_M(pv, fx, fy, a.tanfovx, a.tanfovy, cam.v, Mm, nullptr, nullptr, nullptr);
+        cov2_from_M(Mm, c6, abc);
+        const float det = abc[0] * abc[2] - abc[1] * abc[1];
+        ok = det != 0.f;
+        if (ok) {
+            const float det_inv = 1.f / det;
+            rec.ca = abc[2] * det_inv; rec.cb = -abc[1] * det_inv; rec.cc = abc[0] * det_inv;
+            const float mid = 0.5f * (abc[0] + abc[2]);
+            const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float l1 = mid + disc, l2 = mid - disc;
+            const float radf = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+            rec.px = ((ndcx + 1.f) * (float)a.W - 1.f) * 0.5f;
+            rec.py = ((ndcy + 1.f) * (float)a.H - 1.f) * 0.5f;
+            const int rad = (int)radf;
+            int x0, y0, x1, y1;
+            tile_rect(rec.px, rec.py, rad, gx, gy, x0, y0, x1, y1);
+            const int ntiles = (x1 - x0) * (y1 - y0);
+            ok = ntiles != 0;
+            if (ok) {
+                unsigned cm = 0;
+                float rgb[3];
+                if (a.colors_precomp) {
+                    rgb[0] = a.colors_precomp[3 * idx]; rgb[1] = a.colors_precomp[3 * idx + 1]; rgb[2] = a.colors_precomp[3 * idx + 2];
+                } else {
+                    sh_to_rgb(a.D, p, a.campos, a.shs + (size_t)3 * a.M * idx, rgb, &cm);
+                }
+                rec.r = rgb[0]; rec.g = rgb[1]; rec.b = rgb[2];
+                rec.depth = pv[2];
+                rec.radius = (float)rad;
+                rec.opacity = a.opacities[idx];
+                uint32_t mine = (uint32_t)ntiles;
+                if (a.tile_mod > 1) {  // multi-GPU tile sharding: count only this rank's tiles
+                    mine = 0;
+                    for (int y = y0; y < y1; ++y)
+                        for (int x = x0; x < x1; ++x) mine += ((y * gx + x) % a.tile_mod) == a.tile_rem;
+                }
+                a.radii[idx] = rad;
+                a.tiles_touched[idx] = mine;
+                a.depth_keys[idx] = __float_as_uint(pv[2]);
+                a.clamped[idx] = (unsigned char)cm;
+            }
+        }
+    }
+    if (!ok) rec = SplatRec{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    a.rec[idx] = rec;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+__device__ inline void sh_backward(int deg, int M, const float* mean, const float* campos, const float* sh, unsigned cm,
+                                   const float* dcol, float* dL_dsh, float* dm) {
+    float dRGB[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dRGB[c] = (cm >> c) & 1u ? 0.f : dcol[c];
+    for (int k = 3; k < 3 * M; ++k) dL_dsh[k] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dL_dsh[c] = SH_C0 * dRGB[c];
+    if (deg == 0) return;
+    const float dir[3] = {mean[0] - campos[0], mean[1] - campos[1], mean[2] - campos[2]};
+    const float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    const float x = dir[0] / len, y = dir[1] / len, z = dir[2] / len;
+    float dx[3], dy[3], dz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dL_dsh[3 + c] = -SH_C1 * y * dRGB[c];
+        dL_dsh[6 + c] = SH_C1 * z * dRGB[c];
+        dL_dsh[9 + c] = -SH_C1 * x * dRGB[c];
+        dx[c] = -SH_C1 * sh[9 + c];
+        dy[c] = -SH_C1 * sh[3 + c];
+        dz[c] = SH_C1 * sh[6 + c];
+    }
+    if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dL_dsh[12 + c] = SH_C2[0] * xy * dRGB[c];
+            dL_dsh[15 + c] = SH_C2[1] * yz * dRGB[c];
+            dL_dsh[18 + c] = SH_C2[2] * (2.f * zz - xx - yy) * dRGB[c];
+            dL_dsh[21 + c] = SH_C2[3] * xz * dRGB[c];
+            dL_dsh[24 + c] = SH_C2[4] * (xx - yy) * dRGB[c];
+            dx[c] += SH_C2[0] * y * sh[12 + c] + SH_C2[2] * 2.f * -x * sh[18 + c] + SH_C2[3] * z * sh[21 + c] + SH_C2[4] * 2.f * x * sh[24 + c];
+            dy[c] += SH_C2[0] * x * sh[12 + c] + SH_C2[1] * z * sh[15 + c] + SH_C2[2] * 2.f * -y * sh[18 + c] + SH_C2[4] * 2.f * -y * sh[24 + c];
+            dz[c] += SH_C2[1] * y * sh[15 + c] + SH_C2[2] * 2.f * 2.f * z * sh[18 + c] + SH_C2[3] * x * sh[21 + c];
+        }
+        if (deg > 2) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dL_dsh[27 + c] = SH_C3[0] * y * (3.f * xx - yy) * dRGB[c];
+                dL_dsh[30 + c] = SH_C3[1] * xy * z * dRGB[c];
+                dL_dsh[33 + c] = SH_C3[2] * y * (4.f * zz - xx - yy) * dRGB[c];
+                dL_dsh[36 + c] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * dRGB[c];
+                dL_dsh[39 + c] = SH_C3[4] * x * (4.f * zz - xx - yy) * dRGB[c];
+                dL_dsh[42 + c] = SH_C3[5] * z * (xx - yy) * dRGB[c];
+                dL_dsh[45 + c] = SH_C3[6] * x * (xx - 3.f * yy) * dRGB[c];
+                dx[c] += SH_C3[0] * sh[27 + c] * 3.f * 2.f * xy + SH_C3[1] * sh[30 + c] * yz + SH_C3[2] * sh[33 + c] * -2.f * xy +
+                         SH_C3[3] * sh[36 + c] * -3.f * 2.f * xz + SH_C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
+                         SH_C3[5] * sh[42 + c] * 2.f * xz + SH_C3[6] * sh[45 + c] * 3.f * (xx - yy);
+                dy[c] += SH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + SH_C3[1] * sh[30 + c] * xz +
+                         SH_C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * sh[36 + c] * -3.f * 2.f * yz +
+                         SH_C3[4] * sh[39 + c] * -2.f * xy + SH_C3[5] * sh[42 + c] * -2.f * yz + SH_C3[6] * sh[45 + c] * -3.f * 2.f * xy;
+                dz[c] += SH_C3[1] * sh[30 + c] * xy + SH_C3[2] * sh[33 + c] * 4.f * 2.f * yz +
+                         SH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * sh[39 + c] * 4.f * 2.f * xz +
+                         SH_C3[5] * sh[42 + c] * (xx - yy);
+            }
+        }
+    }
+    float dd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { dd[0] += dx[c] * dRGB[c]; dd[1] += dy[c] * dRGB[c]; dd[2] += dz[c] * dRGB[c]; }
+    const float sum2 = dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2];
+    const float inv = 1.f / sqrtf(sum2 * sum2 * sum2);
+    dm[0] += ((sum2 - dir[0] * dir[0]) * dd[0] - dir[1] * dir[0] * dd[1] - dir[2] * dir[0] * dd[2]) * inv;
+    dm[1] += (-dir[0] * dir[1] * dd[0] + (sum2 - dir[1] * dir[1]) * dd[1] - dir[2] * dir[1] * dd[2]) * inv;
+    dm[2] += (-dir[0] * dir[2] * dd[0] - dir[1] * dir[2] * dd[1] + (sum2 - dir[2] * dir[2]) * dd[2]) * inv;
+}
+
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    float dm[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool visible = a.radii[i] > 0;
+    const bool use_sh = (a.colors_precomp == nullptr) && (a.dL_dsh != nullptr);
+    if (visible) {
+        Cam cam;
+        load_cam(a.view, a.proj, cam);
+        const float fx = (float)a.W / (2.f * a.tanfovx), fy = (float)a.H / (2.f * a.tanfovy);
+        const float p[3] = {a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]};
+        float c6[6];
+        float q[4] = {0.f, 0.f, 0.f, 1.f}, sc[3] = {1.f, 1.f, 1.f};
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = a.cov3D_precomp[6 * i + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sc[k] = a.scales[3 * i + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = a.rotations[4 * i + k];
+            cov3_from_scale_rot(sc, a.scale_modifier, q, c6);
+        }
+        float pv[3], Mm[6], tcl[3], abc[3];
+        bool clx, cly;
+        pv[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+        pv[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+        pv[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+        ewa_M(pv, fx, fy, a.tanfovx, a.tanfovy, cam.v, Mm, tcl, &clx, &cly);
+        cov2_from_M(Mm, c6, abc);
+        const float A = abc[0], B = abc[1], C = abc[2];
+        const float det = A * C - B * B;
+        const float gA = a.dL_dconic[4 * i], gB = a.dL_dconic[4 * i + 1], gC = a.dL_dconic[4 * i + 2];
+        const float d2inv = 1.f / (det * det + 0.0000001f);
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (d2inv != 0.f) {
+            dL_da = d2inv * (-C * C * gA + B * C * gB + (det - A * C) * gC);
+            dL_dc = d2inv * (-A * A * gC + A * B * gB + (det - A * C) * gA);
+            dL_db = d2inv * (2.f * B * C * gA - (det + 2.f * B * B) * gB + 2.f * A * B * gC);
+        }
+        const float h = 0.5f * dL_db;
+        float GM[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { GM[k] = dL_da * Mm[k] + h * Mm[3 + k]; GM[3 + k] = h * Mm[k] + dL_dc * Mm[3 + k]; }
+#define GS_FULL(r, qq) (Mm[r] * GM[qq] + Mm[3 + (r)] * GM[3 + (qq)])
+        dcov[0] = GS_FULL(0, 0); dcov[3] = GS_FULL(1, 1); dcov[5] = GS_FULL(2, 2);
+        dcov[1] = 2.f * GS_FULL(0, 1); dcov[2] = 2.f * GS_FULL(0, 2); dcov[4] = 2.f * GS_FULL(1, 2);
+#undef GS_FULL
+        const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+        float dM[6];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dM[3 * r + k] = 2.f * (GM[3 * r] * S[k] + GM[3 * r + 1] * S[3 + k] + GM[3 * r + 2] * S[6 + k]);
+#define GS_DJ(r, col) (dM[3 * (r)] * cam.v[col] + dM[3 * (r) + 1] * cam.v[4 + (col)] + dM[3 * (r) + 2] * cam.v[8 + (col)])
+        const float dJ00 = GS_DJ(0, 0), dJ02 = GS_DJ(0, 2), dJ11 = GS_DJ(1, 1), dJ12 = GS_DJ(1, 2);
+#undef GS_DJ
+        const float tz = 1.f / tcl[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float xm = clx ? 0.f : 1.f, ym = cly ? 0.f : 1.f;
+        const float dtx = xm * (-fx * tz2 * dJ02);
+        const float dty = ym * (-fy * tz2 * dJ12);
+        const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * tcl[0]) * tz3 * dJ02 + (2.f * fy * tcl[1]) * tz3 * dJ12;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dm[k] += cam.v[4 * k] * dtx + cam.v[4 * k + 1] * dty + cam.v[4 * k + 2] * dtz;
+        const float gd = a.dL_ddepths[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dm[k] += cam.v[4 * k + 2] * gd;
+        {
+            const float ph0 = cam.p[0] * p[0] + cam.p[4] * p[1] + cam.p[8] * p[2] + cam.p[12];
+            const float ph1 = cam.p[1] * p[0] + cam.p[5] * p[1] + cam.p[9] * p[2] + cam.p[13];
+            const float ph3 = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
+            const float mw = 1.f / (ph3 + 0.0000001f);
+            const float mul1 = ph0 * mw * mw, mul2 = ph1 * mw * mw;
+            const float g0 = a.dL_dmean2D[3 * i], g1 = a.dL_dmean2D[3 * i + 1];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dm[k] += (cam.p[4 * k] * mw - cam.p[4 * k + 3] * mul1) * g0 + (cam.p[4 * k + 1] * mw - cam.p[4 * k + 3] * mul2) * g1;
+        }
+        if (use_sh) {
+            const float dcol[3] = {a.dL_dcolors[3 * i], a.dL_dcolors[3 * i + 1], a.dL_dcolors[3 * i + 2]};
+            sh_backward(a.D, a.M, p, a.campos, a.shs + (size_t)3 * a.M * i, a.clamped[i], dcol, a.dL_dsh + (size_t)3 * a.M * i, dm);
+        }
+        if (!a.cov3D_precomp) {
+            float Rm[9];
+            quat_to_R(q, Rm);
+            const float sv[3] = {a.scale_modifier * sc[0], a.scale_modifier * sc[1], a.scale_modifier * sc[2]};
+            const float G3[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
+                                 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+            float dLm[9], dR[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    dLm[3 * r + k] = 2.f * (G3[3 * r] * Rm[k] + G3[3 * r + 1] * Rm[3 + k] + G3[3 * r + 2] * Rm[6 + k]) * sv[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float acc = 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { acc += dLm[3 * r + k] * Rm[3 * r + k]; dR[3 * r + k] = dLm[3 * r + k] * sv[k]; }
+                dsc[k] = a.scale_modifier * acc;
+            }
+            const float x = q[0], y = q[1], z = q[2], r = q[3];
+            const float d00 = dR[0], d01 = dR[1], d02 = dR[2], d10 = dR[3], d11 = dR[4], d12 = dR[5], d20 = dR[6], d21 = dR[7], d22 = dR[8];
+            drot[0] = 2.f * (y * (d01 + d10) + z * (d02 + d20) + r * (d21 - d12)) - 4.f * x * (d11 + d22);
+            drot[1] = 2.f * (x * (d01 + d10) + z * (d12 + d21) + r * (d02 - d20)) - 4.f * y * (d00 + d22);
+            drot[2] = 2.f * (x * (d02 + d20) + y * (d12 + d21) + r * (d10 - d01)) - 4.f * z * (d00 + d11);
+            drot[3] = 2.f * (x * (d21 - d12) + y * (d02 - d20) + z * (d10 - d01));
+        }
+    } else if (use_sh) {
+        for (int k = 0; k < 3 * a.M; ++k) a.dL_dsh[(size_t)3 * a.M * i + k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.dL_dmeans3D[3 * i + k] = dm[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = dcov[k];
+    if (a.dL_dscales) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.dL_dscales[3 * i + k] = dsc[k];
+    }
+    if (a.dL_drots) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.dL_drots[4 * i + k] = drot[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* means3D, const float* view, unsigned char* present) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float z = view[2] * means3D[3 * i] + view[6] * means3D[3 * i + 1] + view[10] * means3D[3 * i + 2] + view[14];
+    present[i] = z > 0.2f ? 1 : 0;
+}
+
+}  // namespace
+
+void launch_preprocess(const PreprocessArgs& a, hipStream_t s) {
+    if (a.P <= 0) return;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_preprocess_backward(const PreprocessBwdArgs& a, hipStream_t s) {
+    if (a.P <= 0) return;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+}
+
+}  // namespace gsicp

@@ -1,0 +1,266 @@
+"""Deterministic synthetic inputs shaped like the reference's datasets (S-pair, S-tum, S-map).
+
+No dataset ships with the reference tree and there is no network, so every test and benchmark in this repo
+runs on these analytic scenes.  Camera conventions restate the reference's helpers:
+  * world->view and projection matrices, row-vector (pre-transposed) form: scene/shared_objs.py:8-43, 157-172
+  * depth -> point back-projection with a strided pixel pick: mp_Tracker.py:394-431
+Pure numpy; nothing here touches the GPU or the oracle.
+"""
+import math
+
+import numpy as np
+
+REPLICA = dict(W=1200, H=680, fx=600.0, fy=600.0, cx=599.5, cy=339.5, depth_scale=6553.5, depth_trunc=12.0,
+               stride=10, max_corr=0.02)  # configs/Replica/caminfo.txt:3 ; replica.sh:135-142
+TUM = dict(W=640, H=480, fx=517.3, fy=516.5, cx=318.6, cy=255.3, depth_scale=5000.0, depth_trunc=3.0,
+           stride=5, max_corr=0.03)       # configs/TUM/rgbd_dataset_freiburg1_desk.txt:3 ; tum.sh:135-142
+
+ROOM_LO = np.array([-3.0, -1.5, -2.0])
+ROOM_HI = np.array([3.0, 1.5, 2.0])
+CUBOIDS = [  # (lo, hi) interior boxes
+    (np.array([-2.2, 0.3, 0.9]), np.array([-1.0, 1.5, 1.7])),
+    (np.array([0.6, 0.7, 1.1]), np.array([1.9, 1.5, 1.9])),
+    (np.array([-0.5, -0.4, 1.2]), np.array([0.3, 0.2, 1.6])),
+]
+
+
+# ------------------------------------------------------------------------------------------ cameras
+def focal2fov(focal, pixels):
+    return 2.0 * math.atan(pixels / (2.0 * focal))
+
+
+def world2view(Rc2w, t_w2c):
+    """4x4 world->camera matrix from a camera-to-world rotation and world->camera translation
+    (the (R, t) pair the tracker hands to SharedCam.setup_cam, mp_Tracker.py:224-226, 277)."""
+    Rt = np.zeros((4, 4))
+    Rt[:3, :3] = Rc2w.T
+    Rt[:3, 3] = t_w2c
+    Rt[3, 3] = 1.0
+    return Rt
+
+
+def projection_matrix(znear, zfar, fovX, fovY):
+    tY, tX = math.tan(fovY / 2), math.tan(fovX / 2)
+    top, right = tY * znear, tX * znear
+    P = np.zeros((4, 4))
+    P[0, 0] = 2.0 * znear / (2 * right)
+    P[1, 1] = 2.0 * znear / (2 * top)
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    return P
+
+
+def make_camera(W, H, fx, fy, pose_c2w=None, znear=0.01, zfar=100.0):
+    """Returns the raster-settings camera block: viewmatrix/projmatrix in row-vector form (float32),
+    campos, tanfovx, tanfovy."""
+    if pose_c2w is None:
+        pose_c2w = np.eye(4)
+    w2c = np.linalg.inv(pose_c2w)
+    fovx, fovy = focal2fov(fx, W), focal2fov(fy, H)
+    view = np.float32(w2c).T.copy()                     # world_view_transform = (W2C)^T
+    proj = np.float32(projection_matrix(znear, zfar, fovx, fovy)).T
+    full = (view @ proj).astype(np.float32)             # full_proj_transform = view^T-form @ proj^T-form
+    campos = np.linalg.inv(view.astype(np.float64))[3, :3].astype(np.float32)
+    return dict(viewmatrix=view, projmatrix=full, campos=campos, tanfovx=math.tan(fovx * 0.5), tanfovy=math.tan(fovy * 0.5),
+                W=W, H=H)
+
+
+def se3(rot_axis_angle_deg=(0.0, 0.0, 0.0), trans=(0.0, 0.0, 0.0)):
+    rx, ry, rz = [math.radians(a) for a in rot_axis_angle_deg]
+    cx, sx, cy, sy, cz, sz = math.cos(rx), math.sin(rx), math.cos(ry), math.sin(ry), math.cos(rz), math.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = trans
+    return T
+
+
+DEFAULT_POSE_A = None  # set below, after se3()
+
+
+# ------------------------------------------------------------------------------------------ ray-cast room
+def _slab(o, d, lo, hi):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0 = (lo - o) / d
+        t1 = (hi - o) / d
+    tmin = np.minimum(t0, t1)
+    tmax = np.maximum(t0, t1)
+    return tmin.max(axis=-1), tmax.min(axis=-1)
+
+
+def raycast_depth(cfg, pose_c2w):
+    """Exact z-depth image (float64 metres) of the analytic room from a camera-to-world pose."""
+    W, H = cfg["W"], cfg["H"]
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    dc = np.stack([(u - cfg["cx"]) / cfg["fx"], (v - cfg["cy"]) / cfg["fy"], np.ones_like(u)], -1)
+    d = dc @ pose_c2w[:3, :3].T
+    o = pose_c2w[:3, 3]
+    _, t_exit = _slab(o, d, ROOM_LO, ROOM_HI)
+    depth = t_exit
+    for lo, hi in CUBOIDS:
+        te, tx = _slab(o, d, lo, hi)
+        hit = (te < tx) & (te > 0)
+        depth = np.where(hit & (te < depth), te, depth)
+    return depth
+
+
+DEFAULT_POSE_A = se3((12.0, 28.0, 0.0), (-0.9, -0.2, -1.1))
+
+
+def checker_colors(points_w):
+    c = (np.floor(points_w * 4.0).astype(np.int64).sum(-1) & 1).astype(np.float32)
+    base = 0.25 + 0.5 * c[:, None]
+    tint = 0.5 + 0.5 * np.sin(points_w * np.array([1.3, 2.1, 0.7]))
+    return np.clip(base * 0.6 + 0.4 * tint, 0, 1).astype(np.float32)
+
+
+def downsample_indices(W, H, stride):
+    """Pixel pick of mp_Tracker.py:394-413: rows stride*k-1 (row 0 for k=0), every stride-th column."""
+    h_val = stride * np.arange(0, int(H / stride) + 1) - 1
+    h_val[0] = 0
+    cols = np.arange(0, W, stride)
+    idx = (h_val[:, None] * W + cols[None, :]).flatten()
+    return idx[idx < W * H]
+
+
+def frame_points(cfg, pose_c2w, noise_seed=None, holes=0.0):
+    """Depth image -> quantised uint16 -> strided camera-frame points, like
+    Tracker.downsample_and_make_pointcloud2 (mp_Tracker.py:415-431).
+    Returns points (M,3) f32, z (M,), trackable indices, and the metric depth image."""
+    W, H = cfg["W"], cfg["H"]
+    depth = raycast_depth(cfg, pose_c2w)
+    if noise_seed is not None:
+        rng = np.random.default_rng(noise_seed)
+        sigma = 0.0012 + 0.0019 * (depth - 0.4) ** 2
+        depth = depth + rng.normal(size=depth.shape) * sigma
+        if holes > 0:
+            depth = np.where(rng.random(depth.shape) < holes, 0.0, depth)
+    d16 = np.clip(np.round(depth * cfg["depth_scale"]), 0, 65535).astype(np.uint16)
+    idx = downsample_indices(W, H, cfg["stride"])
+    u = (idx % W).astype(np.float32)
+    v = (idx // W).astype(np.float32)
+    x_pre = (u - np.float32(cfg["cx"])) / np.float32(cfg["fx"])
+    y_pre = (v - np.float32(cfg["cy"])) / np.float32(cfg["fy"])
+    z = d16.flatten()[idx].astype(np.float32) / np.float32(cfg["depth_scale"])
+    nz = z != 0
+    z = z[nz]
+    pts = np.stack([x_pre[nz] * z, y_pre[nz] * z, z], -1).astype(np.float32)
+    trackable = np.where(z <= cfg["depth_trunc"])[0]
+    depth_m = d16.astype(np.float32) / np.float32(cfg["depth_scale"])
+    return pts, z, trackable, depth_m
+
+
+def s_pair(cfg=REPLICA, noise=False, motion=None):
+    """Two frames with known relative motion: frame B = frame A o motion.  TUM-shaped default: 1 deg about y and
+    2 cm along x.  Replica-shaped default: (0.2 deg x, 0.3 deg y, 8 mm x, 3 mm z) — with Replica's 2 cm
+    correspondence gate and stride-10 sampling (3-7 cm point spacing) the 1 deg / 2 cm motion of SURVEY.md §8d lies
+    outside GICP's convergence basin (the CPU oracle slides by 69 mm); real Replica inter-frame motion is ~1 cm.
+    Frame A looks into a room corner (floor + two walls + cuboids in view) so that all six degrees of freedom are
+    observable; from the room centre looking +z only one flat wall is visible and GICP slides along it."""
+    pose_a = DEFAULT_POSE_A.copy()
+    if motion is None:
+        motion = se3((0.2, 0.3, 0.0), (0.008, 0.0, 0.003)) if cfg["max_corr"] < 0.025 else se3((0.0, 1.0, 0.0), (0.02, 0.0, 0.0))
+    pose_b = pose_a @ motion
+    kw = dict(noise_seed=1, holes=0.15) if noise else {}
+    pa = frame_points(cfg, pose_a, **({"noise_seed": 11, "holes": 0.15} if noise else {}))
+    pb = frame_points(cfg, pose_b, **kw)
+    return dict(cfg=cfg, pose_a=pose_a, pose_b=pose_b, points_a=pa[0], z_a=pa[1], trackable_a=pa[2],
+                points_b=pb[0], z_b=pb[1], trackable_b=pb[2], depth_a=pa[3], depth_b=pb[3])
+
+
+# ------------------------------------------------------------------------------------------ surfel map
+def _faces():
+    """(origin, edge_u, edge_v, inward/outward normal) rectangles of the room (facing in) and cuboids (facing out)."""
+    faces = []
+
+    def box(lo, hi, inward):
+        sgn = -1.0 if inward else 1.0
+        for ax in range(3):
+            a1, a2 = (ax + 1) % 3, (ax + 2) % 3
+            for side, val in ((0, lo[ax]), (1, hi[ax])):
+                o = lo.copy()
+                o[ax] = val
+                eu = np.zeros(3); eu[a1] = hi[a1] - lo[a1]
+                ev = np.zeros(3); ev[a2] = hi[a2] - lo[a2]
+                n = np.zeros(3); n[ax] = (1.0 if side else -1.0) * sgn
+                faces.append((o, eu, ev, n))
+    box(ROOM_LO, ROOM_HI, True)
+    for lo, hi in CUBOIDS:
+        box(lo, hi, False)
+    return faces
+
+
+def quat_from_R_batch(Rm):
+    """Vectorised (N,3,3) -> (N,4) xyzw, w >= 0 branch-free variant (Shepperd via max component)."""
+    m = Rm
+    t = np.stack([1 + m[:, 0, 0] - m[:, 1, 1] - m[:, 2, 2], 1 - m[:, 0, 0] + m[:, 1, 1] - m[:, 2, 2],
+                  1 - m[:, 0, 0] - m[:, 1, 1] + m[:, 2, 2], 1 + m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2]], -1)
+    k = t.argmax(-1)
+    q = np.zeros((m.shape[0], 4))
+    for c in range(4):
+        sel = k == c
+        if not sel.any():
+            continue
+        ms, s = m[sel], 2 * np.sqrt(t[sel, c])
+        if c == 0:
+            q[sel] = np.stack([0.25 * s, (ms[:, 0, 1] + ms[:, 1, 0]) / s, (ms[:, 0, 2] + ms[:, 2, 0]) / s, (ms[:, 2, 1] - ms[:, 1, 2]) / s], -1)
+        elif c == 1:
+            q[sel] = np.stack([(ms[:, 0, 1] + ms[:, 1, 0]) / s, 0.25 * s, (ms[:, 1, 2] + ms[:, 2, 1]) / s, (ms[:, 0, 2] - ms[:, 2, 0]) / s], -1)
+        elif c == 2:
+            q[sel] = np.stack([(ms[:, 0, 2] + ms[:, 2, 0]) / s, (ms[:, 1, 2] + ms[:, 2, 1]) / s, 0.25 * s, (ms[:, 1, 0] - ms[:, 0, 1]) / s], -1)
+        else:
+            q[sel] = np.stack([(ms[:, 2, 1] - ms[:, 1, 2]) / s, (ms[:, 0, 2] - ms[:, 2, 0]) / s, (ms[:, 1, 0] - ms[:, 0, 1]) / s, 0.25 * s], -1)
+    return q
+
+
+def s_map(P=300_000, seed=2, perturb_seed=None):
+    """P surfels on the room surfaces: activated parameters as the mapper would hand them to the rasteriser
+    (means, scales = std-devs, normalised xyzw quaternions, opacity in (0,1), SH DC)."""
+    rng = np.random.default_rng(seed)
+    faces = _faces()
+    areas = np.array([np.linalg.norm(np.cross(f[1], f[2])) for f in faces])
+    counts = rng.multinomial(P, areas / areas.sum())
+    means, Rs = [], []
+    for (o, eu, ev, n), c in zip(faces, counts):
+        a, b = rng.random(c), rng.random(c)
+        means.append(o[None] + a[:, None] * eu[None] + b[:, None] * ev[None])
+        u = eu / np.linalg.norm(eu)
+        v = np.cross(n, u)
+        th = rng.random(c) * 2 * np.pi
+        ex = np.cos(th)[:, None] * u[None] + np.sin(th)[:, None] * v[None]
+        ey = np.cross(np.broadcast_to(n, ex.shape), ex)
+        Rs.append(np.stack([ex, ey, np.broadcast_to(n, ex.shape)], -1))  # columns = local axes, z = normal
+    means = np.concatenate(means).astype(np.float32)
+    Rm = np.concatenate(Rs)
+    quats = quat_from_R_batch(Rm).astype(np.float32)
+    tang = np.exp(rng.normal(math.log(0.01), 0.5, size=(P, 2)))
+    scales = np.concatenate([tang, 0.1 * tang.min(-1, keepdims=True)], -1).astype(np.float32)
+    opac = (1.0 / (1.0 + np.exp(-rng.normal(1.0, 2.0, size=P)))).astype(np.float32)
+    rgb = rng.random((P, 3)).astype(np.float32)
+    sh_dc = ((rgb - 0.5) / 0.28209479177387814).astype(np.float32)
+    out = dict(means3D=means, scales=scales, rotations=quats, opacities=opac[:, None], shs=sh_dc[:, None, :], rgb=rgb)
+    if perturb_seed is not None:
+        pr = np.random.default_rng(perturb_seed)
+        out["means3D"] = (means + pr.normal(0, 0.002, means.shape)).astype(np.float32)
+        out["shs"] = (out["shs"] + pr.normal(0, 0.2, out["shs"].shape)).astype(np.float32)
+        out["opacities"] = np.clip(out["opacities"] * np.exp(pr.normal(0, 0.2, (P, 1))), 1e-3, 0.999).astype(np.float32)
+        out["scales"] = (out["scales"] * np.exp(pr.normal(0, 0.1, (P, 3)))).astype(np.float32)
+    return out
+
+
+def random_gaussians(P, seed=0, sh_degree=0, spread=1.0, zmin=1.0, zmax=6.0):
+    """Small random cloud in front of an identity camera — unit-test input."""
+    rng = np.random.default_rng(seed)
+    means = np.stack([rng.uniform(-spread, spread, P), rng.uniform(-spread * 0.6, spread * 0.6, P), rng.uniform(zmin, zmax, P)], -1)
+    q = rng.normal(size=(P, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    scales = np.exp(rng.normal(math.log(0.05), 0.6, size=(P, 3)))
+    opac = rng.uniform(0.05, 0.95, size=(P, 1))
+    M = (sh_degree + 1) ** 2
+    shs = rng.normal(0, 0.5, size=(P, M, 3))
+    shs[:, 0] += 0.5
+    f32 = np.float32
+    return dict(means3D=means.astype(f32), rotations=q.astype(f32), scales=scales.astype(f32), opacities=opac.astype(f32),
+                shs=shs.astype(f32))

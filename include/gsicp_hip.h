@@ -1,0 +1,154 @@
+/* gsicp_hip.h — C ABI of libgsicp_hip.so, the MI355X (gfx950) implementation of GS-ICP-SLAM's per-frame hot path.
+ *
+ * Plain pointers and sizes only: no torch / pybind / Eigen types cross this boundary.  Every DEVICE pointer is a
+ * HIP device address valid on the current device; `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  All work is enqueued on `stream`; functions documented "synchronous" wait for it before returning.
+ * Return value: >= 0 on success (meaning given per function), < 0 on failure; gsicp_last_error() then returns
+ * a thread-local message.  The reference side of each entry point (what a maintainer binds it to) is cited as
+ * [REF file:line] relative to /root/reference; INTEGRATION.md shows the Python (ctypes) bindings shipped in
+ * gs_icp_slam_amd/ and the pybind11 stub equivalent.
+ *
+ * The reference's own native sources for this path are absent from its tree (empty submodules,
+ * [REF .gitmodules:1-10]); the interfaces replaced are therefore identified by their Python call sites.
+ */
+#ifndef GSICP_HIP_H
+#define GSICP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSICP_ABI_VERSION 1
+
+int gsicp_abi_version(void);
+const char* gsicp_last_error(void);
+/* Number of visible HIP devices (<0: runtime error). */
+int gsicp_device_count(void);
+
+/* Per-stage hipEvent timers (off by default).  While enabled, every kernel / library call of the rasteriser and the
+ * GICP align kernel is bracketed by an event pair on the stream it is launched on.  gsicp_profile_read() synchronises
+ * the recorded events, writes the accumulated milliseconds and launch counts per stage (order = stage index) and
+ * clears the log; it returns the number of stages.  This is what bench.py's `roofline` block is measured with. */
+int gsicp_profile_enable(int on);
+int gsicp_profile_num_stages(void);
+const char* gsicp_profile_stage_name(int stage);
+int gsicp_profile_read(double* ms_out, int* count_out, int capacity);
+
+/* --------------------------------------------------------------------------------------------------------
+ * 1. Rasteriser — replaces diff_gaussian_rasterization._C.{rasterize_gaussians, rasterize_gaussians_backward,
+ *    mark_visible}, reached from GaussianRasterizer.forward at [REF gaussian_renderer/__init__.py:294-302] and
+ *    from loss.backward() at [REF mp_Mapper.py:242].
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* Scratch-buffer resize callback (same convention the viewer's C++ caller uses for the upstream rasteriser,
+ * [REF SIBR_viewers/src/projects/gaussianviewer/renderer/GaussianView.cpp:304,432-434]): must return a DEVICE
+ * pointer to at least `bytes` bytes, 256-byte aligned, that stays alive until the matching backward call. */
+typedef char* (*gsicp_resize_fn)(void* user, size_t bytes);
+
+/* Forward: preprocess -> depth sort -> tile binning -> tile sort -> front-to-back blend.
+ *   P Gaussians; D = active SH degree (0..3); M = SH coefficients per Gaussian in `shs` (>= (D+1)^2).
+ *   All float inputs are contiguous f32 on the device.  Exactly one of shs / colors_precomp and one of
+ *   (scales, rotations) / cov3D_precomp must be non-NULL.  rotations are quaternions in (x,y,z,w) order
+ *   [REF utils/general_utils.py:89-99]; viewmatrix / projmatrix are the row-vector (pre-transposed) 4x4s of
+ *   [REF scene/shared_objs.py:163-166].
+ *   Outputs: out_color (3,H,W), out_depth (1,H,W) = sum z*alpha*T, radii (P) int32, is_used (P) int32.
+ *   tile_mod / tile_rem: this call blends only tiles with (tile_id % tile_mod) == tile_rem and leaves the other
+ *   tiles' pixels untouched (multi-GPU tile sharding; pass 1, 0 for the whole image).
+ * Returns the number of (Gaussian, tile) duplicates binned for this call (the reference's `num_rendered`).
+ * Synchronises `stream` once (to size the binning buffer), like the reference implementation. */
+int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
+                         gsicp_resize_fn img_alloc, void* img_user, int P, int D, int M, const float* background,
+                         int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                         const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                         float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug, void* stream);
+
+/* Backward of the call above.  geom/binning/img buffers are the ones the forward call filled; num_rendered its
+ * return value.  dL_dpix (3,H,W) and dL_ddepth (1,H,W; may be NULL) are the incoming image gradients.
+ * Gradient outputs (all DEVICE, all fully overwritten): dL_dmeans2D (P,3) [x,y in NDC-scaled units, z = 0],
+ * dL_dconic (P,4) scratch, dL_dopacity (P), dL_dcolors (P,3), dL_ddepths (P) scratch, dL_dmeans3D (P,3),
+ * dL_dcov3D (P,6), dL_dsh (P,M,3; may be NULL when colors_precomp is used), dL_dscales (P,3), dL_drots (P,4).
+ * Asynchronous on `stream`. */
+int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* background, int width, int height,
+                          const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                          float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                          const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                          float tan_fovy, const int* radii, const char* geom_buffer, const char* binning_buffer,
+                          const char* img_buffer, const float* dL_dpix, const float* dL_ddepth, float* dL_dmeans2D,
+                          float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_ddepths, float* dL_dmeans3D,
+                          float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, int tile_mod, int tile_rem,
+                          int debug, void* stream);
+
+/* present[i] = 1 iff Gaussian i passes the frustum test (view-space z > 0.2).  Asynchronous. */
+int gsicp_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                              unsigned char* present, void* stream);
+
+/* Introspection used by the parity tests: byte offsets of the sections inside the three scratch buffers
+ * (so tests can read the sorted (tile, Gaussian) lists and tile ranges bit-exactly).  out[] receives
+ * {geom_bytes, binning_bytes, img_bytes, off_records, off_point_list, off_tile_keys, off_ranges, off_final_T,
+ *  off_n_contrib, off_clamped}. */
+int gsicp_raster_layout(int P, int num_rendered, int width, int height, size_t out[10]);
+
+/* --------------------------------------------------------------------------------------------------------
+ * 2. simple_knn — replaces simple_knn._C.distCUDA2 [REF scene/gaussian_model.py:20 (import site)].
+ *    out[i] = mean squared distance from point i to its 3 nearest other points (f32).  Asynchronous.
+ * ------------------------------------------------------------------------------------------------------ */
+int gsicp_knn_dist2(int P, const float* points, float* out, void* stream);
+
+/* --------------------------------------------------------------------------------------------------------
+ * 3. GICP tracker — replaces pygicp.FastGICP [REF mp_Tracker.py:53].  One opaque object per tracker; all
+ *    functions below are synchronous with respect to their HOST arguments (host numpy in, host numpy out, as at
+ *    the reference's call sites) and run their kernels on the object's own stream.
+ * ------------------------------------------------------------------------------------------------------ */
+typedef struct gsicp_gicp gsicp_gicp;
+
+gsicp_gicp* gsicp_gicp_create(void);                       /* pygicp.FastGICP()            [REF mp_Tracker.py:53]  */
+void gsicp_gicp_destroy(gsicp_gicp*);
+int gsicp_gicp_set_max_correspondence_distance(gsicp_gicp*, double d);     /* [REF mp_Tracker.py:109] */
+int gsicp_gicp_set_max_knn_distance(gsicp_gicp*, double d);                /* [REF mp_Tracker.py:110] */
+int gsicp_gicp_set_correspondence_randomness(gsicp_gicp*, int k);          /* upstream API; k-NN size, default 20 */
+int gsicp_gicp_set_max_iterations(gsicp_gicp*, int n);                     /* upstream API; default 64 */
+int gsicp_gicp_set_num_threads(gsicp_gicp*, int n);                        /* upstream API; accepted, ignored */
+/* method: 0 NONE, 1 MIN_EIG, 2 NORMALIZED_MIN_EIG, 3 PLANE (default), 4 FROBENIUS */
+int gsicp_gicp_set_regularization_method(gsicp_gicp*, int method);
+int gsicp_gicp_set_rotation_epsilon(gsicp_gicp*, double eps);
+int gsicp_gicp_set_transformation_epsilon(gsicp_gicp*, double eps);
+
+/* points: HOST (n,3) row-major, f32 (is_f64 = 0) or f64 (is_f64 = 1)  [REF mp_Tracker.py:157,191,287] */
+int gsicp_gicp_set_input_target(gsicp_gicp*, const void* points, int n, int is_f64);
+int gsicp_gicp_set_input_source(gsicp_gicp*, const void* points, int n, int is_f64);
+/* filter: HOST int32 (n_points); 0 = not trackable, r>0 = r-th trackable point  [REF mp_Tracker.py:159-163,192-195] */
+int gsicp_gicp_set_target_filter(gsicp_gicp*, int n_trackable, const int32_t* filter, int n_points);
+int gsicp_gicp_set_source_filter(gsicp_gicp*, int n_trackable, const int32_t* filter, int n_points);
+int gsicp_gicp_calculate_target_covariance_with_filter(gsicp_gicp*);       /* [REF mp_Tracker.py:164] */
+int gsicp_gicp_calculate_source_covariance(gsicp_gicp*);                   /* implicit inside align() upstream */
+/* out: HOST f32; rotations 4 per point (x,y,z,w), scales 3 per point (std-devs, descending)
+ * [REF mp_Tracker.py:166-169,256-264].  Returns the number of points written. */
+int gsicp_gicp_get_target_rotationsq(gsicp_gicp*, float* out, int capacity_points);
+int gsicp_gicp_get_target_scales(gsicp_gicp*, float* out, int capacity_points);
+int gsicp_gicp_get_source_rotationsq(gsicp_gicp*, float* out, int capacity_points);
+int gsicp_gicp_get_source_scales(gsicp_gicp*, float* out, int capacity_points);
+/* Sigma_i = R(q_i) diag(s_i^2) R(q_i)^T for the K current target points  [REF mp_Tracker.py:288] */
+int gsicp_gicp_set_target_covariances_fromqs(gsicp_gicp*, const float* rots_flat, int n_rots, const float* scales_flat,
+                                             int n_scales);
+/* initial/final: HOST 4x4 row-major f64 camera-to-world.  Returns the number of outer iterations (>= 0)
+ * [REF mp_Tracker.py:199] */
+int gsicp_gicp_align(gsicp_gicp*, const double* initial_pose, double* final_pose);
+/* One entry per trackable source point: nearest-target index (-1 when farther than the correspondence gate) and
+ * the squared distance to the nearest target point, as of the last linearisation  [REF mp_Tracker.py:231].
+ * Returns the number of entries. */
+int gsicp_gicp_get_source_correspondence(gsicp_gicp*, int32_t* target_index, float* sq_distance, int capacity);
+int gsicp_gicp_num_source(gsicp_gicp*);
+int gsicp_gicp_num_target(gsicp_gicp*);
+/* out[0..5]: kernel launches of the last align, LM trials, final cost, converged flag, device microseconds, reserved */
+int gsicp_gicp_last_align_stats(gsicp_gicp*, double out[6]);
+int gsicp_gicp_get_final_hessian(gsicp_gicp*, double out[36]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSICP_HIP_H */

@@ -1,0 +1,150 @@
+"""GPU parity: HIP GICP tracker (through the drop-in pygicp API / C ABI) vs the CPU oracle, plus known-answer tests.
+
+Bars: nearest-neighbour indices bit-exact (fp32 search with a fixed evaluation order on both sides); squared
+distances bit-exact; covariances / scales / poses to fp64-reduction-order tolerance (1e-9 relative on covariances,
+1e-6 on the float-rounded 4x4)."""
+import numpy as np
+import pytest
+
+from gs_icp_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def world(points, pose):
+    return points.astype(np.float64) @ pose[:3, :3].T + pose[:3, 3]
+
+
+def filt(n, trackable):
+    f = np.zeros(n, np.int32)
+    f[trackable] = np.arange(1, len(trackable) + 1)
+    return f
+
+
+def drive(reg, sp, cfg, use_fromqs=False):
+    """The reference tracker's call sequence for frame 0 + one tracked frame (mp_Tracker.py:109-110,157-169,191-200,231)."""
+    reg.set_max_correspondence_distance(cfg["max_corr"])
+    reg.set_max_knn_distance(99999.0)
+    pw = world(sp["points_a"], sp["pose_a"])
+    reg.set_input_target(pw)
+    reg.set_target_filter(len(sp["trackable_a"]), filt(len(pw), sp["trackable_a"]))
+    reg.calculate_target_covariance_with_filter()
+    rots = np.reshape(reg.get_target_rotationsq(), (-1, 4))
+    scales = np.reshape(reg.get_target_scales(), (-1, 3))
+    if use_fromqs:
+        reg.set_input_target(pw.astype(np.float32))
+        reg.set_target_covariances_fromqs(rots.flatten(), scales.flatten())
+    reg.set_input_source(sp["points_b"])
+    reg.set_source_filter(len(sp["trackable_b"]), filt(len(sp["points_b"]), sp["trackable_b"]))
+    T = reg.align(sp["pose_a"])
+    idx, d2 = reg.get_source_correspondence()
+    srots = np.reshape(np.array(reg.get_source_rotationsq()), (-1, 4))
+    sscales = np.reshape(np.array(reg.get_source_scales()), (-1, 3))
+    return dict(T=T, idx=idx, d2=d2, rots=rots, scales=scales, srots=srots, sscales=sscales)
+
+
+def quat_cov(q, s):
+    x, y, z, r = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                  2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    return R @ (s[:, :, None] ** 2 * np.swapaxes(R, 1, 2))
+
+
+def pose_err(T, gt):
+    dR = T[:3, :3].astype(np.float64) @ gt[:3, :3].T
+    ang = np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
+    return ang, 1e3 * np.linalg.norm(T[:3, 3] - gt[:3, 3])
+
+
+@pytest.mark.parametrize("name", ["replica", "tum"])
+@pytest.mark.parametrize("fromqs", [False, True])
+def test_align_matches_oracle(name, fromqs):
+    import oracle
+    import pygicp
+    cfg = synth.REPLICA if name == "replica" else synth.TUM
+    sp = synth.s_pair(cfg, noise=(name == "tum"))
+    po = drive(oracle.OracleGICP(), sp, cfg, fromqs)
+    reg = pygicp.FastGICP()
+    pp = drive(reg, sp, cfg, fromqs)
+    print(name, "fromqs", fromqs, reg.last_align_stats(), "pose err (deg, mm)", pose_err(pp["T"], sp["pose_b"]))
+    # exported Gaussians: sign-invariant comparison through the reconstructed covariance
+    np.testing.assert_allclose(pp["scales"], po["scales"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(quat_cov(pp["rots"], pp["scales"]), quat_cov(po["rots"], po["scales"]), rtol=0, atol=2e-7)
+    np.testing.assert_allclose(pp["sscales"], po["sscales"], rtol=2e-5, atol=1e-7)
+    assert np.allclose(np.linalg.norm(pp["rots"], axis=1), 1.0, atol=1e-5)
+    # correspondences (as of the last linearisation): bit-exact indices and distances
+    assert pp["idx"].shape == po["idx"].shape == (len(sp["trackable_b"]),)
+    assert np.array_equal(pp["idx"], po["idx"]), f"{(pp['idx'] != po['idx']).sum()} correspondence indices differ"
+    assert np.array_equal(pp["d2"], po["d2"]), f"max |d2 diff| {np.abs(pp['d2'] - po['d2']).max()}"
+    np.testing.assert_allclose(pp["T"], po["T"], rtol=0, atol=1e-6)
+    ang, mm = pose_err(pp["T"], sp["pose_b"])
+    assert ang < 0.05 and mm < (1.0 if name == "replica" else 5.0)
+
+
+def test_known_answer_rigid_motion():
+    """Source = target moved by a known SE(3): GICP must recover it (no sampling difference, wide gate)."""
+    import pygicp
+    sp = synth.s_pair(synth.TUM)
+    pw = world(sp["points_a"], sp["pose_a"])
+    motion = synth.se3((0.4, -0.7, 0.3), (0.012, -0.008, 0.015))
+    src = (pw - motion[:3, 3]) @ motion[:3, :3]          # motion^-1 applied
+    reg = pygicp.FastGICP()
+    reg.set_max_correspondence_distance(0.1)
+    reg.set_input_target(pw)
+    reg.set_input_source(src.astype(np.float32))
+    T = reg.align(np.eye(4))
+    ang, mm = pose_err(T, motion)
+    assert ang < 0.01 and mm < 0.2, (ang, mm)
+
+
+def test_default_gate_bruteforce_path_and_float64_input():
+    import oracle
+    import pygicp
+    rng = np.random.default_rng(0)
+    tgt = rng.uniform(-1, 1, size=(700, 3))
+    motion = synth.se3((1.0, 2.0, -1.0), (0.01, 0.02, -0.01))
+    src = ((tgt - motion[:3, 3]) @ motion[:3, :3])[:500]
+    res = []
+    for reg in (oracle.OracleGICP(), pygicp.FastGICP()):
+        reg.set_input_target(tgt)            # float64 in, as at mp_Tracker.py:157
+        reg.set_input_source(src.astype(np.float32))
+        T = reg.align(np.eye(4))
+        idx, d2 = reg.get_source_correspondence()
+        res.append((T, idx, d2))
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    np.testing.assert_allclose(res[0][0], res[1][0], atol=1e-6)
+    assert pose_err(res[1][0], motion)[1] < 0.5
+
+
+def test_filters_and_errors():
+    import pygicp
+    reg = pygicp.FastGICP()
+    with pytest.raises(RuntimeError):
+        reg.align(np.eye(4))                           # nothing set
+    pts = np.random.default_rng(1).uniform(-1, 1, (100, 3)).astype(np.float32)
+    reg.set_input_target(pts)
+    with pytest.raises(RuntimeError):
+        reg.set_target_covariances_fromqs(np.zeros(8, np.float32), np.zeros(6, np.float32))   # wrong sizes
+    with pytest.raises(RuntimeError):
+        reg.set_input_source(np.zeros((5, 2), np.float32))
+    reg.set_input_source(pts[:40])
+    f = np.zeros(40, np.int32); f[[3, 7, 9]] = [1, 2, 3]
+    reg.set_source_filter(3, f)
+    reg.set_max_correspondence_distance(0.05)
+    reg.align(np.eye(4))
+    idx, d2 = reg.get_source_correspondence()
+    assert idx.tolist() == [3, 7, 9] and np.all(d2 == 0.0)
+
+
+def test_distances_beyond_gate_are_exact():
+    """The reference exports the raw nearest-neighbour distance even when it exceeds the gate (thresholds at
+    mp_Tracker.py:235 sit above max_corr^2)."""
+    import oracle
+    import pygicp
+    sp = synth.s_pair(synth.REPLICA, motion=synth.se3((0.0, 1.0, 0.0), (0.02, 0.0, 0.0)))
+    out = []
+    for reg in (oracle.OracleGICP(), pygicp.FastGICP()):
+        r = drive(reg, sp, synth.REPLICA)
+        out.append(r)
+    assert (out[0]["idx"] < 0).mean() > 0.2
+    assert np.array_equal(out[0]["d2"], out[1]["d2"]) and np.array_equal(out[0]["idx"], out[1]["idx"])
