@@ -73,6 +73,10 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -m gs_icp_slam_amd.build` "
                 "(hipcc --offload-arch=gfx950).  gs_icp_slam_amd has no CPU fallback.")
+        try:
+            import torch  # noqa: F401  (loads the HIP runtime this library is linked against; see build.py)
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -30,6 +30,17 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _torch_lib_dir():
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            return os.path.join(os.path.dirname(spec.origin), "lib")
+    except Exception:
+        pass
+    return None
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -54,7 +65,14 @@ def build(force=False, verbose=True):
             subprocess.check_call(cmd)
         objs.append(obj)
     if force or _newer(OUT, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+        # Link against the HIP runtime PyTorch already carries (torch/lib/libamdhip64.so, no versioned SONAME) so that
+        # the process holds ONE runtime: device pointers and streams handed over by torch must belong to the runtime
+        # our kernels are launched through.  Falls back to /opt/rocm's runtime when torch is not installed.
+        link = []
+        tl = _torch_lib_dir()
+        if tl and os.path.exists(os.path.join(tl, "libamdhip64.so")):
+            link = [f"-L{tl}", f"-Wl,-rpath,{tl}", "-Wl,--disable-new-dtags"]
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs + link
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

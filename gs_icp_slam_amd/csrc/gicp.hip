@@ -52,7 +52,6 @@ using gsicp::g_last_error;
 namespace {
 
 constexpr unsigned long long EMPTY_KEY = ~0ull;
-constexpr int ALIGN_THREADS = 1024;
 constexpr int NRED = 28;  // 21 (upper H) + 6 (b) + 1 (cost)
 
 struct GridView {
@@ -229,80 +228,91 @@ __device__ inline void regularise(int method, const double* evals, const double*
 }
 
 // ---------------------------------------------------------------------------------------------- k-NN covariances
-// One thread per query; all points streamed through LDS in tiles of 256; sorted top-K (d2, idx) in registers.
-template <int K>
-__global__ __launch_bounds__(256) void knn_cov_kernel(int n, int k, const float4* __restrict__ pts, float max_d2, int reg_method,
+// One WAVE per query point (4 queries per 256-thread workgroup, so ~n/4 workgroups fill the chip even at n = 8 k).
+// The 64 lanes stream the cloud 64 candidates at a time (one coalesced 1 KiB load); the running top-k is a sorted
+// list held ACROSS the lanes (lane r = rank r), so an insertion is a ballot + popcount + one wave_shr DPP move
+// instead of a 20-deep per-thread compare chain.  Ordering is lexicographic (d2, index) like the oracle's.
+__device__ inline bool lex_less(float d, int i, float d2, int i2) { return d < d2 || (d == d2 && i < i2); }
+__device__ inline float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ inline int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }  // lane l <- lane l-1
+
+__global__ __launch_bounds__(256) void knn_cov_kernel(int n, int k, int batch_stride, const float4* __restrict__ pts, float max_d2, int reg_method,
                                                       double* __restrict__ cov, float* __restrict__ rotq, float* __restrict__ scales) {
-    __shared__ float4 tile[256];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool active = i < n;
-    float4 q = active ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float bd[K];
-    int bi[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) { bd[j] = FLT_MAX; bi[j] = 0x7fffffff; }
-    for (int base = 0; base < n; base += 256) {
-        __syncthreads();
-        if (base + (int)threadIdx.x < n) tile[threadIdx.x] = pts[base + threadIdx.x];
-        __syncthreads();
-        const int m = (n - base) < 256 ? (n - base) : 256;
-        if (active) {
-            for (int t = 0; t < m; ++t) {
-                const float4 p = tile[t];
-                const float d = dist2(q.x, q.y, q.z, p.x, p.y, p.z);
-                const int id = base + t;
-                if (d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1])) {
-#pragma unroll
-                    for (int j = K - 1; j > 0; --j) {
-                        const bool before_prev = d < bd[j - 1] || (d == bd[j - 1] && id < bi[j - 1]);
-                        const bool before_cur = d < bd[j] || (d == bd[j] && id < bi[j]);
-                        const float nd = before_prev ? bd[j - 1] : (before_cur ? d : bd[j]);
-                        const int ni = before_prev ? bi[j - 1] : (before_cur ? id : bi[j]);
-                        bd[j] = nd; bi[j] = ni;
-                    }
-                    if (d < bd[0] || (d == bd[0] && id < bi[0])) { bd[0] = d; bi[0] = id; }
-                }
-            }
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= n) return;                       // wave-uniform
+    const int kk = k < n ? k : n;             // <= 64
+    const unsigned long long kmask = kk >= 64 ? ~0ull : ((1ull << kk) - 1ull);
+    const float4 Q = pts[q];
+    float my_d = FLT_MAX;
+    int my_i = 0x7fffffff;
+    float tau_d = FLT_MAX;
+    int tau_i = 0x7fffffff;
+    // Batches are visited in a multiplicative-permutation order: depth-image clouds arrive in raster order, and a
+    // monotone approach towards the query would make almost every candidate an insertion.  The final sorted list
+    // does not depend on the visiting order (the order is a total one).
+    const int nb = (n + 63) / 64;
+    for (int b = 0, pb = 0; b < nb; ++b, pb += batch_stride) {
+        if (pb >= nb) pb -= nb;
+        const int j = pb * 64 + lane;
+        float d = FLT_MAX;
+        int id = 0x7fffffff;
+        if (j < n) {
+            const float4 p = pts[j];
+            d = dist2(Q.x, Q.y, Q.z, p.x, p.y, p.z);
+            id = j;
+        }
+        unsigned long long m = __ballot(lex_less(d, id, tau_d, tau_i));
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float cd = readlane_f(d, b);
+            const int ci = __builtin_amdgcn_readlane(id, b);
+            if (!lex_less(cd, ci, tau_d, tau_i)) continue;   // the list moved on since the ballot
+            const unsigned long long le = __ballot(!lex_less(cd, ci, my_d, my_i)) & kmask;   // entries ranked before the candidate
+            const int pos = __popcll(le);
+            const float up_d = __int_as_float(wave_shr1(__float_as_int(my_d)));
+            const int up_i = wave_shr1(my_i);
+            if (lane > pos) { my_d = up_d; my_i = up_i; }
+            else if (lane == pos) { my_d = cd; my_i = ci; }
+            tau_d = readlane_f(my_d, kk - 1);
+            tau_i = __builtin_amdgcn_readlane(my_i, kk - 1);
         }
     }
-    if (!active) return;
-    const int kk = k < n ? k : n;
+    // neighbours now sit in lanes 0..kk-1, ascending.  Mean / covariance in fp64, summed in rank order (as the oracle).
+    float4 np = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < kk) np = pts[my_i];
     double mu[3] = {0, 0, 0};
     int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < kk && bd[j] <= max_d2) {
-            const float4 p = pts[bi[j]];
-            mu[0] += (double)p.x; mu[1] += (double)p.y; mu[2] += (double)p.z;
-            ++cnt;
-        }
+    for (int j = 0; j < kk; ++j) {
+        if (readlane_f(my_d, j) > max_d2) break;
+        mu[0] += (double)readlane_f(np.x, j); mu[1] += (double)readlane_f(np.y, j); mu[2] += (double)readlane_f(np.z, j);
+        ++cnt;
     }
     mu[0] /= cnt; mu[1] /= cnt; mu[2] /= cnt;
     double raw[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        if (j < kk && bd[j] <= max_d2) {
-            const float4 p = pts[bi[j]];
-            const double dx = (double)p.x - mu[0], dy = (double)p.y - mu[1], dz = (double)p.z - mu[2];
-            raw[0] += dx * dx; raw[1] += dx * dy; raw[2] += dx * dz; raw[3] += dy * dy; raw[4] += dy * dz; raw[5] += dz * dz;
-        }
+    for (int j = 0; j < cnt; ++j) {
+        const double dx = (double)readlane_f(np.x, j) - mu[0], dy = (double)readlane_f(np.y, j) - mu[1], dz = (double)readlane_f(np.z, j) - mu[2];
+        raw[0] += dx * dx; raw[1] += dx * dy; raw[2] += dx * dz; raw[3] += dy * dy; raw[4] += dy * dz; raw[5] += dz * dz;
     }
 #pragma unroll
     for (int d = 0; d < 6; ++d) raw[d] /= cnt;
     double ev[3], V[9], qd[4], out6[6];
-    eig_sym3(raw, ev, V);
+    eig_sym3(raw, ev, V);          // wave-uniform values: executed once per wave, stored by lane 0
     rot_to_quat(V, qd);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) rotq[4 * (size_t)i + d] = (float)qd[d];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) scales[3 * (size_t)i + d] = (float)sqrt(fmax(ev[d], 0.0));
     regularise(reg_method, ev, V, raw, out6);
+    if (lane == 0) {
 #pragma unroll
-    for (int d = 0; d < 6; ++d) cov[6 * (size_t)i + d] = out6[d];
+        for (int d = 0; d < 4; ++d) rotq[4 * (size_t)q + d] = (float)qd[d];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) scales[3 * (size_t)q + d] = (float)sqrt(fmax(ev[d], 0.0));
+#pragma unroll
+        for (int d = 0; d < 6; ++d) cov[6 * (size_t)q + d] = out6[d];
+    }
 }
 
-__global__ __launch_bounds__(256) void cov_fromqs_kernel(int n, const float* __restrict__ rots, const float* __restrict__ scales,
-                                                         double* __restrict__ cov) {
+__global__ __launch_bounds__(256) void cov_fromqs_kernel(int n, int reg_method, const float* __restrict__ rots,
+                                                         const float* __restrict__ scales, double* __restrict__ cov) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double q[4] = {rots[4 * (size_t)i], rots[4 * (size_t)i + 1], rots[4 * (size_t)i + 2], rots[4 * (size_t)i + 3]};
@@ -312,12 +322,29 @@ __global__ __launch_bounds__(256) void cov_fromqs_kernel(int n, const float* __r
     quat_to_rot(q, R);
     const double s0 = scales[3 * (size_t)i], s1 = scales[3 * (size_t)i + 1], s2 = scales[3 * (size_t)i + 2];
     const double v[3] = {s0 * s0, s1 * s1, s2 * s2};
+    double raw[6];
     int k = 0;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = r; c < 3; ++c)
-            cov[6 * (size_t)i + k++] = R[3 * r] * v[0] * R[3 * c] + R[3 * r + 1] * v[1] * R[3 * c + 1] + R[3 * r + 2] * v[2] * R[3 * c + 2];
+            raw[k++] = R[3 * r] * v[0] * R[3 * c] + R[3 * r + 1] * v[1] * R[3 * c + 1] + R[3 * r + 2] * v[2] * R[3 * c + 2];
+    // same regularisation as the k-NN path, on the eigen-structure the Gaussian carries (s^2 descending, columns of R)
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (v[o1] > v[o0]) { const int t = o0; o0 = o1; o1 = t; }
+    if (v[o2] > v[o1]) { const int t = o1; o1 = o2; o2 = t; }
+    if (v[o1] > v[o0]) { const int t = o0; o0 = o1; o1 = t; }
+    const int order[3] = {o0, o1, o2};
+    double ev[3], V[9], out6[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ev[c] = v[order[c]];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) V[3 * r + c] = R[3 * r + order[c]];
+    }
+    regularise(reg_method, ev, V, raw, out6);
+#pragma unroll
+    for (int d = 0; d < 6; ++d) cov[6 * (size_t)i + d] = out6[d];
 }
 
 // ---------------------------------------------------------------------------------------------- hash grid build
@@ -373,6 +400,16 @@ struct AlignResult {
     int iterations, lm_trials, converged, failed;
 };
 
+constexpr int AL_T = 256;        // threads per workgroup
+constexpr int AL_MAX_WG = 240;   // <= one workgroup per CU, so every workgroup is resident and the grid barrier is safe
+
+struct AlignSync {               // zeroed by a hipMemsetAsync before every launch
+    unsigned counter;
+    unsigned abort;
+    unsigned pad[30];
+    double partials[2][AL_MAX_WG][NRED];
+};
+
 struct AlignArgs {
     int n_src;                 // trackable source points
     const int* src_track;
@@ -389,30 +426,13 @@ struct AlignArgs {
     float* sqd;
     double* maha;              // 6 per trackable source point
     AlignResult* result;
+    AlignSync* sync;
 };
 
 __device__ inline double wave_sum_d(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
-}
-
-// block-wide sum of NV doubles per thread into out[] (valid in thread 0); 16 waves
-template <int NV>
-__device__ inline void block_sum(double* vals, double (*scratch)[NRED], double* out, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const double s = wave_sum_d(vals[k]);
-        if (lane == 0) scratch[wave][k] = s;
-    }
-    __syncthreads();
-    if (tid < NV) {
-        double s = 0;
-        for (int w = 0; w < ALIGN_THREADS / 64; ++w) s += scratch[w][tid];
-        out[tid] = s;
-    }
-    __syncthreads();
 }
 
 __device__ inline bool solve6(const double* H, const double* b, double* x) {
@@ -476,26 +496,81 @@ __device__ inline bool is_converged(const double* R, const double* t, double rot
 }
 
 struct AlignShared {
-    double scratch[ALIGN_THREADS / 64][NRED];
+    double scratch[AL_T / 64][NRED];
     double red[NRED];
     double x0[12];      // current pose R,t
     double xi[12];      // trial pose
     double delta[12];
     double H[36], b[6];
-    double y0, lambda, nu;
+    double y0, lambda, nu, denom;
     int state;          // 0 continue LM trials, 1 step accepted / done with this outer iteration, 2 abort
     int converged;
+    int abort;
 };
 
-__global__ __launch_bounds__(ALIGN_THREADS) void gicp_align_kernel(AlignArgs a) {
+// Grid-wide sum of NV doubles per thread.  Workgroup partials go to global memory, one monotonic-counter grid barrier
+// (agent-scope release before the arrive, relaxed polling by ONE lane, agent-scope acquire after — the protocol of
+// cdna_hip_programming.md §6 G16), then every workgroup adds the partials in the same fixed order, so all workgroups
+// hold bit-identical totals and take identical decisions without any further communication.
+template <int NV>
+__device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, unsigned& epoch, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nwg = gridDim.x;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double s = wave_sum_d(vals[k]);
+        if (lane == 0) sh.scratch[wave][k] = s;
+    }
+    __syncthreads();
+    const int buf = epoch & 1;
+    if (tid < NV) {
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < AL_T / 64; ++w) s += sh.scratch[w][tid];
+        sy->partials[buf][blockIdx.x][tid] = s;
+    }
+    ++epoch;
+    if (nwg > 1) {
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&sy->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = epoch * (unsigned)nwg;
+            unsigned spins = 0;
+            int ab = 0;
+            while (__hip_atomic_load(&sy->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > 4000000u || __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ab = 1;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            sh.abort = ab;
+        }
+    }
+    __syncthreads();
+    if (tid < NV) {
+        double s = 0;
+        for (int w = 0; w < nwg; ++w) s += sy->partials[buf][w][tid];
+        sh.red[tid] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
     __shared__ AlignShared sh;
     const int tid = threadIdx.x;
+    const int gtid = blockIdx.x * AL_T + tid, gstride = gridDim.x * AL_T;
+    const bool leader = blockIdx.x == 0 && tid == 0;
+    unsigned epoch = 0;
     if (tid < 12) sh.x0[tid] = a.init[tid];
-    if (tid == 0) { sh.lambda = -1.0; sh.converged = 0; }
+    if (tid == 0) { sh.lambda = -1.0; sh.converged = 0; sh.abort = 0; }
     __syncthreads();
 
     int iterations = 0, lm_trials = 0, failed = 0;
-    double last_cost = 0;
 
     for (int it = 0; it < a.max_iter; ++it) {
         // ---------------- linearize at x0: correspondences + Mahalanobis + H, b, cost
@@ -513,7 +588,7 @@ __global__ __launch_bounds__(ALIGN_THREADS) void gicp_align_kernel(AlignArgs a) 
 #pragma unroll
         for (int k = 0; k < NRED; ++k) acc[k] = 0;
 
-        for (int s = tid; s < a.n_src; s += ALIGN_THREADS) {
+        for (int s = gtid; s < a.n_src; s += gstride) {
             const int i = a.src_track[s];
             const float4 p = a.src_pts[i];
             const float qx = ((Rf[0] * p.x + Rf[1] * p.y) + Rf[2] * p.z) + tf[0];
@@ -572,7 +647,8 @@ __global__ __launch_bounds__(ALIGN_THREADS) void gicp_align_kernel(AlignArgs a) 
             }
             a.corr[s] = c;
         }
-        block_sum<NRED>(acc, sh.scratch, sh.red, tid);
+        grid_sum<NRED>(acc, sh, a.sync, epoch, tid);
+        if (sh.abort) { failed = 2; break; }
         if (tid == 0) {
             int kk = 0;
             for (int r = 0; r < 6; ++r)
@@ -585,11 +661,11 @@ __global__ __launch_bounds__(ALIGN_THREADS) void gicp_align_kernel(AlignArgs a) 
                 sh.lambda = a.lm_init * mx;
             }
             sh.nu = 2.0;
-            for (int i = 0; i < 12; ++i) a.result->lin_pose[i] = sh.x0[i];
+            if (leader) for (int i = 0; i < 12; ++i) a.result->lin_pose[i] = sh.x0[i];
         }
         __syncthreads();
 
-        // ---------------- LM trials
+        // ---------------- LM trials (every workgroup runs the same scalar arithmetic on the same totals)
         bool step_ok = false;
         for (int trial = 0; trial < a.lm_max_iter; ++trial) {
             ++lm_trials;
@@ -609,13 +685,11 @@ __global__ __launch_bounds__(ALIGN_THREADS) void gicp_align_kernel(AlignArgs a) 
                     }
                     double den = 0;
                     for (int i = 0; i < 6; ++i) den += d[i] * (sh.lambda * d[i] - sh.b[i]);
-                    sh.red[0] = den;   // parked until the cost reduction below overwrites red[] (read first)
+                    sh.denom = den;
                 }
             }
             __syncthreads();
             if (sh.state == 2) break;
-            const double denom = sh.red[0];
-            __syncthreads();
             // trial cost with frozen correspondences / Mahalanobis matrices
             double Rx[9], tx[3];
 #pragma unroll
@@ -623,7 +697,7 @@ __global__ __launch_bounds__(ALIGN_THREADS) void gicp_align_kernel(AlignArgs a) 
 #pragma unroll
             for (int i = 0; i < 3; ++i) tx[i] = sh.xi[9 + i];
             double cost[1] = {0};
-            for (int s = tid; s < a.n_src; s += ALIGN_THREADS) {
+            for (int s = gtid; s < a.n_src; s += gstride) {
                 const int c = a.corr[s];
                 if (c < 0) continue;
                 const float4 p = a.src_pts[a.src_track[s]];
@@ -636,10 +710,11 @@ __global__ __launch_bounds__(ALIGN_THREADS) void gicp_align_kernel(AlignArgs a) 
                 cost[0] += e[0] * (m[0] * e[0] + m[1] * e[1] + m[2] * e[2]) + e[1] * (m[1] * e[0] + m[3] * e[1] + m[4] * e[2]) +
                            e[2] * (m[2] * e[0] + m[4] * e[1] + m[5] * e[2]);
             }
-            block_sum<1>(cost, sh.scratch, sh.red, tid);
+            grid_sum<1>(cost, sh, a.sync, epoch, tid);
+            if (sh.abort) { failed = 2; break; }
             if (tid == 0) {
                 const double yi = sh.red[0];
-                const double rho = (sh.y0 - yi) / denom;
+                const double rho = (sh.y0 - yi) / sh.denom;
                 if (rho < 0) {
                     if (is_converged(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps)) {
                         sh.state = 1;       // upstream returns true without accepting the step
@@ -652,22 +727,24 @@ __global__ __launch_bounds__(ALIGN_THREADS) void gicp_align_kernel(AlignArgs a) 
                     for (int i = 0; i < 12; ++i) sh.x0[i] = sh.xi[i];
                     const double f = 2 * rho - 1;
                     sh.lambda = sh.lambda * fmax(1.0 / 3.0, 1 - f * f * f);
-                    for (int i = 0; i < 36; ++i) a.result->H_final[i] = sh.H[i];
-                    a.result->cost = yi;
+                    if (leader) {
+                        for (int i = 0; i < 36; ++i) a.result->H_final[i] = sh.H[i];
+                        a.result->cost = yi;
+                    }
                     sh.state = 1;
                 }
             }
             __syncthreads();
             if (sh.state == 1) { step_ok = true; break; }
         }
+        if (failed) break;
         if (!step_ok) { failed = 1; break; }   // "lm not converged"
         ++iterations;
         if (tid == 0) sh.converged = is_converged(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps) ? 1 : 0;
         __syncthreads();
         if (sh.converged) break;
     }
-    (void)last_cost;
-    if (tid == 0) {
+    if (leader) {
         AlignResult* r = a.result;
         for (int i = 0; i < 16; ++i) r->final_pose[i] = (i == 15) ? 1.0 : 0.0;
         for (int i = 0; i < 3; ++i) {
@@ -682,62 +759,48 @@ __global__ __launch_bounds__(ALIGN_THREADS) void gicp_align_kernel(AlignArgs a) 
 // For trackable source points whose in-gate neighbour was not found on the grid, brute-force the true nearest target
 // (the reference exports the raw kd-tree distance whatever the gate).  packed[s] = float_bits(d2) << 32 | index.
 __global__ __launch_bounds__(256) void miss_list_kernel(int n_src, const float* __restrict__ sqd, const int* __restrict__ corr, float gate,
-                                                        int* __restrict__ miss, int* __restrict__ n_miss,
-                                                        unsigned long long* __restrict__ packed) {
+                                                        int* __restrict__ miss, int* __restrict__ n_miss) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n_src) return;
     const bool found = sqd[s] < gate;   // exact whenever below the gate (grid completeness radius)
     if (!found) {
         const int k = atomicAdd(n_miss, 1);
         miss[k] = s;
-        packed[s] = ~0ull;
     }
     (void)corr;
 }
+// One wave per missed query: lanes stride over the (cell-sorted) trackable targets, lexicographic wave-min at the end.
 __global__ __launch_bounds__(256) void brute_nn_kernel(const int* __restrict__ miss, const int* __restrict__ n_miss_p, const int* __restrict__ src_track,
                                                        const float4* __restrict__ src_pts, const double* __restrict__ lin_pose,
-                                                       const float4* __restrict__ sorted, int n_tgt, int chunk,
-                                                       unsigned long long* __restrict__ packed) {
-    __shared__ float4 tile[256];
-    const int n_miss = *n_miss_p;
-    const int qi = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= n_miss) return;
-    const bool active = qi < n_miss;
-    float qx = 0, qy = 0, qz = 0;
-    int s = 0;
-    if (active) {
-        s = miss[qi];
-        const float4 p = src_pts[src_track[s]];
-        float Rf[9], tf[3];
-        for (int i = 0; i < 9; ++i) Rf[i] = (float)lin_pose[i];
-        for (int i = 0; i < 3; ++i) tf[i] = (float)lin_pose[9 + i];
-        qx = ((Rf[0] * p.x + Rf[1] * p.y) + Rf[2] * p.z) + tf[0];
-        qy = ((Rf[3] * p.x + Rf[4] * p.y) + Rf[5] * p.z) + tf[1];
-        qz = ((Rf[6] * p.x + Rf[7] * p.y) + Rf[8] * p.z) + tf[2];
-    }
-    const int lo = blockIdx.y * chunk, hi = (lo + chunk) < n_tgt ? (lo + chunk) : n_tgt;
-    float bd = FLT_MAX; int bi = 0x7fffffff;
-    for (int base = lo; base < hi; base += 256) {
-        __syncthreads();
-        if (base + (int)threadIdx.x < hi) tile[threadIdx.x] = sorted[base + threadIdx.x];
-        __syncthreads();
-        const int m = (hi - base) < 256 ? (hi - base) : 256;
-        for (int t = 0; t < m; ++t) {
-            const float4 p = tile[t];
-            const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
-            const int id = __float_as_int(p.w);
-            if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
-        }
-    }
-    if (active && bi != 0x7fffffff) atomicMin(&packed[s], ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned)bi);
-}
-__global__ __launch_bounds__(256) void miss_write_kernel(const int* __restrict__ miss, const int* __restrict__ n_miss_p,
-                                                         const unsigned long long* __restrict__ packed, float* __restrict__ sqd) {
-    const int qi = blockIdx.x * 256 + threadIdx.x;
-    if (qi >= *n_miss_p) return;
+                                                       const float4* __restrict__ sorted, int n_tgt, float* __restrict__ sqd) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= *n_miss_p) return;   // wave-uniform
     const int s = miss[qi];
-    const unsigned long long v = packed[s];
-    sqd[s] = v == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(v >> 32));
+    const float4 p = src_pts[src_track[s]];
+    float Rf[9], tf[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)lin_pose[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tf[i] = (float)lin_pose[9 + i];
+    const float qx = ((Rf[0] * p.x + Rf[1] * p.y) + Rf[2] * p.z) + tf[0];
+    const float qy = ((Rf[3] * p.x + Rf[4] * p.y) + Rf[5] * p.z) + tf[1];
+    const float qz = ((Rf[6] * p.x + Rf[7] * p.y) + Rf[8] * p.z) + tf[2];
+    float bd = FLT_MAX;
+    int bi = 0x7fffffff;
+    for (int j = lane; j < n_tgt; j += 64) {
+        const float4 t = sorted[j];
+        const float d = dist2(qx, qy, qz, t.x, t.y, t.z);
+        const int id = __float_as_int(t.w);
+        if (lex_less(d, id, bd, bi)) { bd = d; bi = id; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(bd, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (lex_less(od, oi, bd, bi)) { bd = od; bi = oi; }
+    }
+    if (lane == 0) sqd[s] = bd;
 }
 
 // ---------------------------------------------------------------------------------------------- host object
@@ -785,6 +848,7 @@ struct gsicp_gicp {
     DevBuf<float> sqd;
     DevBuf<double> maha;
     DevBuf<AlignResult> result;
+    DevBuf<AlignSync> sync;
     AlignResult host_result{};
     bool aligned = false, dist_exact = false;
     std::vector<float> h_stage;
@@ -835,12 +899,15 @@ int calc_cov(gsicp_gicp* g, Cloud& c) {
         g_last_error = "hipMalloc failed"; return -1;
     }
     if (n > 0) {
-        if (g->k > 32) { g_last_error = "correspondence randomness (k) > 32 is not supported"; return -2; }
+        if (g->k > 64) { g_last_error = "correspondence randomness (k) > 64 is not supported"; return -2; }
         const float maxd2 = g->max_knn >= (double)FLT_MAX ? FLT_MAX : (float)(g->max_knn * g->max_knn);
         gsicp::ProfileScope ps(gsicp::ST_GICP_COV, g->stream);
-        const dim3 grid((n + 255) / 256), block(256);
-        if (g->k <= 20) hipLaunchKernelGGL(knn_cov_kernel<20>, grid, block, 0, g->stream, n, g->k, c.pts.p, maxd2, g->reg, c.cov.p, c.rotq.p, c.scales.p);
-        else hipLaunchKernelGGL(knn_cov_kernel<32>, grid, block, 0, g->stream, n, g->k, c.pts.p, maxd2, g->reg, c.cov.p, c.rotq.p, c.scales.p);
+        const int nb = (n + 63) / 64;
+        int stride = 1;
+        for (int p : {37, 41, 43, 47, 53, 59, 61, 67, 71, 73})
+            if (p < nb && nb % p != 0) { stride = p; break; }
+        hipLaunchKernelGGL(knn_cov_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, n, g->k, stride, c.pts.p, maxd2, g->reg, c.cov.p,
+                           c.rotq.p, c.scales.p);
         GC(hipGetLastError());
     }
     c.cov_valid = true; c.qs_valid = true;
@@ -905,7 +972,7 @@ gsicp_gicp* gsicp_gicp_create(void) {
         delete g;
         return nullptr;
     }
-    if (g->result.ensure(1) || g->counters.ensure(4)) { g_last_error = "hipMalloc failed"; delete g; return nullptr; }
+    if (g->result.ensure(1) || g->counters.ensure(4) || g->sync.ensure(1)) { g_last_error = "hipMalloc failed"; delete g; return nullptr; }
     return g;
 }
 void gsicp_gicp_destroy(gsicp_gicp* g) {
@@ -916,7 +983,7 @@ void gsicp_gicp_destroy(gsicp_gicp* g) {
 int gsicp_gicp_set_max_correspondence_distance(gsicp_gicp* g, double d) { g->max_corr = d; g->grid_valid = false; return 0; }
 int gsicp_gicp_set_max_knn_distance(gsicp_gicp* g, double d) { g->max_knn = d; g->src.cov_valid = false; return 0; }
 int gsicp_gicp_set_correspondence_randomness(gsicp_gicp* g, int k) {
-    if (k < 1 || k > 32) { g_last_error = "k must be in [1, 32]"; return -2; }
+    if (k < 1 || k > 64) { g_last_error = "k must be in [1, 64]"; return -2; }
     g->k = k; return 0;
 }
 int gsicp_gicp_set_max_iterations(gsicp_gicp* g, int n) { g->max_iter = n; return 0; }
@@ -975,7 +1042,7 @@ int gsicp_gicp_set_target_covariances_fromqs(gsicp_gicp* g, const float* rots, i
     if (t.n > 0) {
         GC(hipMemcpyAsync(t.rotq.p, rots, sizeof(float) * 4 * t.n, hipMemcpyHostToDevice, g->stream));
         GC(hipMemcpyAsync(t.scales.p, scales, sizeof(float) * 3 * t.n, hipMemcpyHostToDevice, g->stream));
-        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, t.rotq.p, t.scales.p, t.cov.p);
+        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, t.rotq.p, t.scales.p, t.cov.p);
         GC(hipGetLastError());
         GC(hipStreamSynchronize(g->stream));
     }
@@ -1007,9 +1074,13 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
         a.init[9 + r] = (double)(float)init[4 * r + 3];
     }
     a.max_iter = g->max_iter; a.lm_max_iter = g->lm_max_iter; a.rot_eps = g->rot_eps; a.trans_eps = g->trans_eps; a.lm_init = g->lm_init;
-    a.corr = g->corr.p; a.sqd = g->sqd.p; a.maha = g->maha.p; a.result = g->result.p;
+    a.corr = g->corr.p; a.sqd = g->sqd.p; a.maha = g->maha.p; a.result = g->result.p; a.sync = g->sync.p;
+    int nwg = (s.n_track + AL_T - 1) / AL_T;
+    if (nwg < 1) nwg = 1;
+    if (nwg > AL_MAX_WG) nwg = AL_MAX_WG;
+    GC(hipMemsetAsync(g->sync.p, 0, 128, g->stream));   // barrier counter + abort flag
     { gsicp::ProfileScope ps(gsicp::ST_GICP_ALIGN, g->stream);
-      hipLaunchKernelGGL(gicp_align_kernel, dim3(1), dim3(ALIGN_THREADS), 0, g->stream, a); }
+      hipLaunchKernelGGL(gicp_align_kernel, dim3(nwg), dim3(AL_T), 0, g->stream, a); }
     ++launches;
     GC(hipGetLastError());
     GC(hipEventRecord(e1, g->stream));
@@ -1034,15 +1105,9 @@ int gsicp_gicp_get_source_correspondence(gsicp_gicp* g, int32_t* idx, float* d2,
         gsicp::ProfileScope ps(gsicp::ST_GICP_MISS, g->stream);
         GC(hipMemsetAsync(g->counters.p, 0, sizeof(int) * 4, g->stream));
         hipLaunchKernelGGL(miss_list_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, g->sqd.p, g->corr.p, gate, g->miss.p,
-                           g->counters.p, g->packed.p);
-        // split the targets so that a few thousand misses still fill the chip
-        int chunks = (t.n_track + 16383) / 16384;
-        if (chunks < 1) chunks = 1;
-        if (chunks > 64) chunks = 64;
-        const int chunk = ((t.n_track + chunks - 1) / chunks + 255) / 256 * 256;
-        hipLaunchKernelGGL(brute_nn_kernel, dim3((n + 255) / 256, chunks), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p,
-                           s.pts.p, g->result.p->lin_pose, g->sorted.p, t.n_track, chunk, g->packed.p);
-        hipLaunchKernelGGL(miss_write_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, g->miss.p, g->counters.p, g->packed.p, g->sqd.p);
+                           g->counters.p);
+        hipLaunchKernelGGL(brute_nn_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
+                           g->result.p->lin_pose, g->sorted.p, t.n_track, g->sqd.p);
         GC(hipGetLastError());
         g->dist_exact = true;
     }

@@ -20,6 +20,7 @@
 //    no lane passes the alpha test skip the reduction entirely (wave-uniform branch).
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -355,6 +356,255 @@ __global__ __launch_bounds__(256) void blend_backward_kernel(BlendArgs a) {
     }
 }
 
+// ================================================================================================================
+// Wave-per-tile variants (default).  One wave64 owns a whole 16x16 tile: lane l handles the pixel column x = l & 15
+// at the four rows y = (l >> 4) + 4k.  Consequences on CDNA4:
+//   * no workgroup barriers at all (a 64-thread workgroup is one wave);
+//   * the per-splat fixed cost (LDS broadcast read of the 48-byte record, loop/branch overhead, dx = px - x which is
+//     shared by a lane's four pixels) is paid once per 256 pixels instead of once per 64;
+//   * four independent pixel chains per lane give the in-order SIMD the ILP it needs to cover exp / LDS latency;
+//   * backward: a lane first adds its four pixels' partial gradients in registers, then ONE DPP reduction per
+//     (tile, splat) replaces four reductions + LDS atomics + two barriers of the 4-wave version.
+// ================================================================================================================
+constexpr int WPIX = 4;   // pixels per lane
+
+__global__ __launch_bounds__(64) void blend_forward_wave_kernel(BlendArgs a) {
+    const int tl = xcd_band_index(blockIdx.x, gridDim.x);
+    if (tl >= a.n_tiles_local) return;
+    const int tile = tl * a.tile_mod + a.tile_rem;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int lane = threadIdx.x;
+    const int px = tx * TILE + (lane & 15);
+    const int py0 = ty * TILE + (lane >> 4);
+    const float pfx = (float)px;
+    const uint2 range = a.ranges[tile];
+
+    __shared__ SplatRec s_rec[64];
+    __shared__ uint32_t s_id[64];
+
+    float T[WPIX], C0[WPIX], C1[WPIX], C2[WPIX], Dz[WPIX], pfy[WPIX];
+    uint32_t last_c[WPIX];
+    bool alive[WPIX], inside[WPIX];
+#pragma unroll
+    for (int k = 0; k < WPIX; ++k) {
+        const int py = py0 + 4 * k;
+        inside[k] = px < a.W && py < a.H;
+        alive[k] = inside[k];
+        pfy[k] = (float)py;
+        T[k] = 1.f; C0[k] = C1[k] = C2[k] = Dz[k] = 0.f; last_c[k] = 0;
+    }
+    uint32_t pos = 0;
+    for (uint32_t base = range.x; base < range.y; base += 64) {
+        const bool any_alive = alive[0] | alive[1] | alive[2] | alive[3];
+        if (__ballot(any_alive) == 0ull) break;
+        __syncthreads();   // single-wave workgroup: orders the LDS reuse, costs ~nothing
+        const uint32_t kk = base + lane;
+        if (kk < range.y) {
+            const uint32_t id = a.point_list[kk];
+            s_id[lane] = id;
+            s_rec[lane] = a.rec[id];
+        }
+        __syncthreads();
+        const int n = (int)(range.y - base) < 64 ? (int)(range.y - base) : 64;
+        for (int j = 0; j < n; ++j) {
+            const SplatRec r = s_rec[j];
+            ++pos;
+            const float dx = r.px - pfx;
+            const float adx2 = r.ca * dx * dx;
+            const float bdx = r.cb * dx;
+            bool contrib = false;
+#pragma unroll
+            for (int k = 0; k < WPIX; ++k) {
+                const float dy = r.py - pfy[k];
+                const float power = -0.5f * (adx2 + r.cc * dy * dy) - bdx * dy;
+                const float alpha = fminf(0.99f, r.opacity * __expf(power));
+                if (alive[k] && power <= 0.f && alpha >= 1.f / 255.f) {   // one (often wave-uniformly false) branch per pixel row
+                    const float test_T = T[k] * (1.f - alpha);
+                    if (test_T < 0.0001f) {
+                        alive[k] = false;
+                    } else {
+                        const float w = alpha * T[k];
+                        C0[k] += r.r * w; C1[k] += r.g * w; C2[k] += r.b * w; Dz[k] += r.depth * w;
+                        T[k] = test_T;
+                        last_c[k] = pos;
+                        contrib = true;
+                    }
+                }
+            }
+            if (a.is_used) {
+                const unsigned long long m = __ballot(contrib);
+                if (m != 0ull && lane == (__ffsll((long long)m) - 1)) a.is_used[s_id[j]] = 1;
+            }
+        }
+    }
+    const size_t HW = (size_t)a.W * a.H;
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+#pragma unroll
+    for (int k = 0; k < WPIX; ++k) {
+        if (inside[k]) {
+            const size_t pix = (size_t)(py0 + 4 * k) * a.W + px;
+            a.final_T[pix] = T[k];
+            a.n_contrib[pix] = last_c[k];
+            a.out_color[pix] = C0[k] + T[k] * bg0;
+            a.out_color[HW + pix] = C1[k] + T[k] * bg1;
+            a.out_color[2 * HW + pix] = C2[k] + T[k] * bg2;
+            a.out_depth[pix] = Dz[k];
+        }
+    }
+}
+
+// Partial wave sum: after the call, lanes 15, 31, 47 and 63 hold the sums of their 16-lane rows (4 fused DPP adds).
+__device__ inline float row_sum_to_lane15(float v) {
+    v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x114, 0xF>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);   // row_shr:8
+    return v;
+}
+
+__global__ __launch_bounds__(64) void blend_backward_wave_kernel(BlendArgs a) {
+    const int tl = xcd_band_index(blockIdx.x, gridDim.x);
+    if (tl >= a.n_tiles_local) return;
+    const int tile = tl * a.tile_mod + a.tile_rem;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    const int lane = threadIdx.x;
+    const int px = tx * TILE + (lane & 15);
+    const int py0 = ty * TILE + (lane >> 4);
+    const float pfx = (float)px;
+    const uint2 range = a.ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const size_t HW = (size_t)a.W * a.H;
+
+    __shared__ SplatRec s_rec[64];
+    __shared__ uint32_t s_id[64];
+    __shared__ float s_acc[64][NGRAD + 1];
+
+    float T[WPIX], T_final[WPIX], pfy[WPIX], dp0[WPIX], dp1[WPIX], dp2[WPIX], dpd[WPIX], bg_dot[WPIX];
+    float acc0[WPIX], acc1[WPIX], acc2[WPIX], accd[WPIX], lc0[WPIX], lc1[WPIX], lc2[WPIX], lcd[WPIX], last_alpha[WPIX];
+    int last_contrib[WPIX];
+    const float bg0 = a.bg[0], bg1 = a.bg[1], bg2 = a.bg[2];
+    int max_contrib = 0;
+#pragma unroll
+    for (int k = 0; k < WPIX; ++k) {
+        const int py = py0 + 4 * k;
+        const bool inside = px < a.W && py < a.H;
+        const size_t pix = (size_t)py * a.W + px;
+        pfy[k] = (float)py;
+        T_final[k] = inside ? a.final_T[pix] : 0.f;
+        T[k] = T_final[k];
+        last_contrib[k] = inside ? (int)a.n_contrib[pix] : 0;
+        max_contrib = last_contrib[k] > max_contrib ? last_contrib[k] : max_contrib;
+        dp0[k] = inside ? a.dL_dpix[pix] : 0.f;
+        dp1[k] = inside ? a.dL_dpix[HW + pix] : 0.f;
+        dp2[k] = inside ? a.dL_dpix[2 * HW + pix] : 0.f;
+        dpd[k] = (inside && a.dL_ddepth) ? a.dL_ddepth[pix] : 0.f;
+        bg_dot[k] = bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k];
+        acc0[k] = acc1[k] = acc2[k] = accd[k] = 0.f;
+        lc0[k] = lc1[k] = lc2[k] = lcd[k] = 0.f;
+        last_alpha[k] = 0.f;
+    }
+    // entries at list positions >= the tile's largest n_contrib contribute to no pixel: start there
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(max_contrib, off, 64);
+        max_contrib = o > max_contrib ? o : max_contrib;
+    }
+    const float ddelx_dx = 0.5f * (float)a.W, ddely_dy = 0.5f * (float)a.H;
+
+    for (int top = max_contrib; top > 0; top -= 64) {   // entries [top-n, top) processed back-to-front
+        const int n = top < 64 ? top : 64;
+        __syncthreads();
+        if (lane < n) {
+            const uint32_t id = a.point_list[range.x + (uint32_t)(top - 1 - lane)];
+            s_id[lane] = id;
+            s_rec[lane] = a.rec[id];
+        }
+#pragma unroll
+        for (int c = 0; c < NGRAD + 1; ++c) s_acc[lane][c] = 0.f;
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const int position = top - 1 - j;   // 0-based position in the tile list
+            const SplatRec r = s_rec[j];
+            const float dx = r.px - pfx;
+            const float adx2 = r.ca * dx * dx;
+            const float bdx = r.cb * dx;
+            float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
+            bool valid = false;
+#pragma unroll
+            for (int k = 0; k < WPIX; ++k) {
+                const float dy = r.py - pfy[k];
+                const float power = -0.5f * (adx2 + r.cc * dy * dy) - bdx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, r.opacity * G);
+                {
+                    {
+                        if (position < last_contrib[k] && power <= 0.f && alpha >= 1.f / 255.f) {
+                            valid = true;
+                            T[k] = T[k] / (1.f - alpha);
+                            const float w = alpha * T[k];
+                            acc0[k] = last_alpha[k] * lc0[k] + (1.f - last_alpha[k]) * acc0[k]; lc0[k] = r.r;
+                            acc1[k] = last_alpha[k] * lc1[k] + (1.f - last_alpha[k]) * acc1[k]; lc1[k] = r.g;
+                            acc2[k] = last_alpha[k] * lc2[k] + (1.f - last_alpha[k]) * acc2[k]; lc2[k] = r.b;
+                            accd[k] = last_alpha[k] * lcd[k] + (1.f - last_alpha[k]) * accd[k]; lcd[k] = r.depth;
+                            float dL_dalpha = (r.r - acc0[k]) * dp0[k] + (r.g - acc1[k]) * dp1[k] + (r.b - acc2[k]) * dp2[k] +
+                                              (r.depth - accd[k]) * dpd[k];
+                            g_r += w * dp0[k]; g_g += w * dp1[k]; g_b += w * dp2[k]; g_d += w * dpd[k];
+                            dL_dalpha *= T[k];
+                            last_alpha[k] = alpha;
+                            dL_dalpha += (-T_final[k] / (1.f - alpha)) * bg_dot[k];
+                            const float dL_dG = r.opacity * dL_dalpha;
+                            const float gdx = G * dx, gdy = G * dy;
+                            g_mx += dL_dG * (-gdx * r.ca - gdy * r.cb) * ddelx_dx;
+                            g_my += dL_dG * (-gdy * r.cc - gdx * r.cb) * ddely_dy;
+                            g_ca += -0.5f * gdx * dx * dL_dG;
+                            g_cb += -gdx * dy * dL_dG;
+                            g_cc += -0.5f * gdy * dy * dL_dG;
+                            g_op += G * dL_dalpha;
+                        }
+                    }
+                }
+            }
+            if (__ballot(valid) != 0ull) {   // wave-uniform: splats no pixel of the tile touches cost nothing more
+                g_mx = row_sum_to_lane15(g_mx); g_my = row_sum_to_lane15(g_my);
+                g_ca = row_sum_to_lane15(g_ca); g_cb = row_sum_to_lane15(g_cb); g_cc = row_sum_to_lane15(g_cc);
+                g_op = row_sum_to_lane15(g_op);
+                g_r = row_sum_to_lane15(g_r); g_g = row_sum_to_lane15(g_g); g_b = row_sum_to_lane15(g_b);
+                g_d = row_sum_to_lane15(g_d);
+                if ((lane & 15) == 15) {   // 4 row leaders combine in LDS
+                    float* s = s_acc[j];
+                    atomicAdd(&s[0], g_mx); atomicAdd(&s[1], g_my);
+                    atomicAdd(&s[2], g_ca); atomicAdd(&s[3], g_cb); atomicAdd(&s[4], g_cc);
+                    atomicAdd(&s[5], g_op);
+                    atomicAdd(&s[6], g_r); atomicAdd(&s[7], g_g); atomicAdd(&s[8], g_b);
+                    atomicAdd(&s[9], g_d);
+                    s[NGRAD] = 1.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (lane < n && s_acc[lane][NGRAD] != 0.f) {
+            const uint32_t id = s_id[lane];
+            const float* s = s_acc[lane];
+            atomicAdd(&a.dL_dmean2D[3 * (size_t)id + 0], s[0]);
+            atomicAdd(&a.dL_dmean2D[3 * (size_t)id + 1], s[1]);
+            atomicAdd(&a.dL_dconic[4 * (size_t)id + 0], s[2]);
+            atomicAdd(&a.dL_dconic[4 * (size_t)id + 1], s[3]);
+            atomicAdd(&a.dL_dconic[4 * (size_t)id + 2], s[4]);
+            atomicAdd(&a.dL_dopacity[id], s[5]);
+            atomicAdd(&a.dL_dcolors[3 * (size_t)id + 0], s[6]);
+            atomicAdd(&a.dL_dcolors[3 * (size_t)id + 1], s[7]);
+            atomicAdd(&a.dL_dcolors[3 * (size_t)id + 2], s[8]);
+            atomicAdd(&a.dL_ddepths[id], s[9]);
+        }
+    }
+    (void)total;
+}
+
+inline int blend_variant() {   // GSICP_BLEND=block selects the 4-wave-per-tile kernels (kept for A/B measurements)
+    static const int v = [] { const char* e = getenv("GSICP_BLEND"); return (e && std::strcmp(e, "block") == 0) ? 1 : 0; }();
+    return v;
+}
+
 inline int tile_bits(int T) {
     int b = 1;
     while ((1 << b) < T) ++b;
@@ -429,8 +679,8 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     (void)prefiltered; (void)debug;
     hipStream_t stream = (hipStream_t)stream_v;
     if (width <= 0 || height <= 0 || P < 0) { g_last_error = "gsicp_raster_forward: bad sizes"; return -2; }
-    if ((shs == nullptr) == (colors_precomp == nullptr)) { g_last_error = "provide exactly one of shs / colors_precomp"; return -2; }
-    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
+    if (P > 0 && (shs == nullptr) == (colors_precomp == nullptr)) { g_last_error = "provide exactly one of shs / colors_precomp"; return -2; }
+    if (P > 0 && ((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
         g_last_error = "provide exactly one of (scales, rotations) / cov3D_precomp"; return -2;
     }
     if (shs && (D < 0 || D > 3 || M < (D + 1) * (D + 1))) { g_last_error = "sh degree / coefficient count mismatch"; return -2; }
@@ -521,7 +771,8 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     if (ba.n_tiles_local > 0) {
         const int nblocks = (ba.n_tiles_local + 7) / 8 * 8;
         ProfileScope ps(ST_BLEND_FWD, stream);
-        hipLaunchKernelGGL(blend_forward_kernel, dim3(nblocks), dim3(TILE_PIX), 0, stream, ba);
+        if (blend_variant() == 1) hipLaunchKernelGGL(blend_forward_kernel, dim3(nblocks), dim3(TILE_PIX), 0, stream, ba);
+        else hipLaunchKernelGGL(blend_forward_wave_kernel, dim3(nblocks), dim3(64), 0, stream, ba);
     }
     GS_CHECK(hipGetLastError());
     return num_rendered;
@@ -569,7 +820,8 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     if (num_rendered > 0 && ba.n_tiles_local > 0) {
         const int nblocks = (ba.n_tiles_local + 7) / 8 * 8;
         ProfileScope ps(ST_BLEND_BWD, stream);
-        hipLaunchKernelGGL(blend_backward_kernel, dim3(nblocks), dim3(TILE_PIX), 0, stream, ba);
+        if (blend_variant() == 1) hipLaunchKernelGGL(blend_backward_kernel, dim3(nblocks), dim3(TILE_PIX), 0, stream, ba);
+        else hipLaunchKernelGGL(blend_backward_wave_kernel, dim3(nblocks), dim3(64), 0, stream, ba);
     }
 
     PreprocessBwdArgs pb;

@@ -19,7 +19,7 @@
 //        convergence max(|dR - I| / 2e-3, |dt| / 5e-4) < 1, final transform rounded through float.
 // Fork-specific semantics that cannot be verified here: exported scales are sqrt(eigenvalues) of the
 // RAW k-NN covariance (descending), quaternions (x,y,z,w) of the eigenvector frame with det = +1;
-// set_target_covariances_fromqs builds R diag(s^2) R^T; target filter restricts which target points can be matched;
+// set_target_covariances_fromqs builds R diag(s^2) R^T and applies the same regularisation as the k-NN path; target filter restricts which target points can be matched;
 // max_knn_distance drops neighbours farther than that radius from the covariance estimate.
 #include <omp.h>
 
@@ -571,9 +571,20 @@ int oracle_gicp_set_target_cov_fromqs(void* h, const float* rots, int n_rots, co
         quat_xyzw_to_rot(q, R);
         const double s2[3] = {(double)scales[3 * i] * scales[3 * i], (double)scales[3 * i + 1] * scales[3 * i + 1],
                               (double)scales[3 * i + 2] * scales[3 * i + 2]};
+        double raw[6];
         int k = 0;
         for (int r = 0; r < 3; ++r)
-            for (int c = r; c < 3; ++c) g.tgt.cov[6 * i + k++] = R[3 * r] * s2[0] * R[3 * c] + R[3 * r + 1] * s2[1] * R[3 * c + 1] + R[3 * r + 2] * s2[2] * R[3 * c + 2];
+            for (int c = r; c < 3; ++c) raw[k++] = R[3 * r] * s2[0] * R[3 * c] + R[3 * r + 1] * s2[1] * R[3 * c + 1] + R[3 * r + 2] * s2[2] * R[3 * c + 2];
+        // The same regularisation as the k-NN path, applied to the eigen-structure the Gaussian already carries:
+        // eigenvalues = s^2 (stable descending order), eigenvectors = the matching columns of R.
+        int o0 = 0, o1 = 1, o2 = 2;
+        if (s2[o1] > s2[o0]) std::swap(o0, o1);
+        if (s2[o2] > s2[o1]) std::swap(o1, o2);
+        if (s2[o1] > s2[o0]) std::swap(o0, o1);
+        const int order[3] = {o0, o1, o2};
+        double ev[3], V[9];
+        for (int c = 0; c < 3; ++c) { ev[c] = s2[order[c]]; for (int r = 0; r < 3; ++r) V[3 * r + c] = R[3 * r + order[c]]; }
+        regularise(g.reg, ev, V, raw, g.tgt.cov.data() + 6 * i);
     }
     g.tgt.cov_valid = true;
     return 0;

@@ -1,7 +1,7 @@
 """GPU parity: HIP rasteriser (through the drop-in diff_gaussian_rasterization API / C ABI) vs the CPU oracle.
 
 Bars (BASELINE.json north_star): bit-exact tile / Gaussian indices; RGB and depth within 1e-5.  exp() differs in
-the last ulp between libm and the GPU, so a pixel whose alpha / transmittance test sits within 1e-4 (relative) of
+the last ulps between libm and the GPU, so a pixel whose alpha / transmittance test sits within 1e-5 (relative) of
 its threshold may legitimately flip; the oracle reports that margin per pixel and such pixels (a few per million)
 are excluded from the 1e-5 bar but bounded in number.
 """
@@ -13,19 +13,15 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-FRAGILE = 1e-4
+FRAGILE = 1e-5
 
 
 def run_product(g, cam, bg, sh_degree=0, grads=None, tile_mod=1, tile_rem=0):
     import torch
     from diff_gaussian_rasterization import GaussianRasterizer
-    from gs_icp_slam_amd import rasterizer as R
     t = util.torch_inputs(g, requires_grad=grads is not None)
     rs = util.make_settings(cam, bg, sh_degree, tile_mod=tile_mod, tile_rem=tile_rem)
     means2D = torch.zeros_like(t["means3D"], requires_grad=True)
-    captured = {}
-    orig_save = torch.autograd.function.FunctionCtx.save_for_backward
-
     rast = GaussianRasterizer(raster_settings=rs)
     depth, color, radii, is_used = rast(means3D=t["means3D"], means2D=means2D, shs=t.get("shs"), colors_precomp=t.get("colors_precomp"),
                                         opacities=t["opacities"], scales=t.get("scales"), rotations=t.get("rotations"),
