@@ -138,7 +138,7 @@ def main():
     # ---------------- roofline of the dominant kernel ----------------
     per_launch_us = {k: (1e3 * ms / max(c, 1)) for k, (ms, c) in prof.items() if c > 0}
     raster_stages = ["preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "tile_ranges", "blend_forward", "blend_backward",
-                     "preprocess_backward", "memset"]
+                     "preprocess_backward", "entry_grad_sum"]
     dominant = max((k for k in raster_stages if k in per_launch_us), key=lambda k: per_launch_us[k])
     num_rendered = 0
     fn_probe = None
@@ -160,7 +160,7 @@ def main():
     alg_bytes = {"blend_forward": bytes_fwd_blend, "blend_backward": bytes_bwd_blend,
                  "preprocess": 128.0 * P, "preprocess_backward": 184.0 * P, "tile_sort": 16.0 * n_pass * D_local,
                  "depth_sort": 16.0 * 4 * P, "duplicate": 8.0 * D_local + 56.0 * P_vis, "tile_ranges": 4.0 * D_local,
-                 "scan": 12.0 * P, "memset": 44.0 * P}
+                 "scan": 12.0 * P, "entry_grad_sum": 240.0 * D_local}
     ach = alg_bytes[dominant] / (per_launch_us[dominant] * 1e-6) / 1e9
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "kernel_us": round(per_launch_us[dominant], 2),

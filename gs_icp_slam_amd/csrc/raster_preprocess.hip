@@ -202,8 +202,18 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
                 }
                 rec.r = rgb[0]; rec.g = rgb[1]; rec.b = rgb[2];
                 rec.depth = pv[2];
-                rec.radius = (float)rad;
                 rec.opacity = a.opacities[idx];
+                // Footprint of alpha = min(0.99, o * exp(power)) >= 1/255:  q(d) = -2 power <= 2 ln(255 o).  Its bounding
+                // box has half-extents sqrt(2 tau * Sigma2_xx), sqrt(2 tau * Sigma2_yy).  tau is padded by 0.01 (1 % in
+                // alpha) and the box by half a pixel, far more than any fp32 / __expf rounding, so culling with it never
+                // drops a pixel the exact per-pixel test would accept.
+                const float tau = logf(255.f * rec.opacity) + 0.01f;
+                if (tau > 0.f) {
+                    rec.hx = sqrtf(2.f * tau * abc[0]) + 0.5f;
+                    rec.hy = sqrtf(2.f * tau * abc[2]) + 0.5f;
+                } else {
+                    rec.hx = -1e30f; rec.hy = -1e30f;
+                }
                 uint32_t mine = (uint32_t)ntiles;
                 if (a.tile_mod > 1) {  // multi-GPU tile sharding: count only this rank's tiles
                     mine = 0;
@@ -297,6 +307,13 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     const bool visible = a.radii[i] > 0;
     const bool use_sh = (a.colors_precomp == nullptr) && (a.dL_dsh != nullptr);
+    // screen-space gradient sums of this Gaussian (written in depth-rank order by gaussian_grad_gather_kernel)
+    float gs[NGRAD];
+    gs[0] = a.dL_dmean2D[3 * i]; gs[1] = a.dL_dmean2D[3 * i + 1];
+    gs[2] = a.dL_dconic[4 * i]; gs[3] = a.dL_dconic[4 * i + 1]; gs[4] = a.dL_dconic[4 * i + 2];
+    gs[5] = a.dL_dopacity[i];
+    gs[6] = a.dL_dcolors[3 * i]; gs[7] = a.dL_dcolors[3 * i + 1]; gs[8] = a.dL_dcolors[3 * i + 2];
+    gs[9] = a.dL_ddepths[i];
     if (visible) {
         Cam cam;
         load_cam(a.view, a.proj, cam);
@@ -323,7 +340,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
         cov2_from_M(Mm, c6, abc);
         const float A = abc[0], B = abc[1], C = abc[2];
         const float det = A * C - B * B;
-        const float gA = a.dL_dconic[4 * i], gB = a.dL_dconic[4 * i + 1], gC = a.dL_dconic[4 * i + 2];
+        const float gA = gs[2], gB = gs[3], gC = gs[4];
         const float d2inv = 1.f / (det * det + 0.0000001f);
         float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
         if (d2inv != 0.f) {
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
         const float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * tcl[0]) * tz3 * dJ02 + (2.f * fy * tcl[1]) * tz3 * dJ12;
 #pragma unroll
         for (int k = 0; k < 3; ++k) dm[k] += cam.v[4 * k] * dtx + cam.v[4 * k + 1] * dty + cam.v[4 * k + 2] * dtz;
-        const float gd = a.dL_ddepths[i];
+        const float gd = gs[9];
 #pragma unroll
         for (int k = 0; k < 3; ++k) dm[k] += cam.v[4 * k + 2] * gd;
         {
@@ -364,13 +381,13 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
             const float ph3 = cam.p[3] * p[0] + cam.p[7] * p[1] + cam.p[11] * p[2] + cam.p[15];
             const float mw = 1.f / (ph3 + 0.0000001f);
             const float mul1 = ph0 * mw * mw, mul2 = ph1 * mw * mw;
-            const float g0 = a.dL_dmean2D[3 * i], g1 = a.dL_dmean2D[3 * i + 1];
+            const float g0 = gs[0], g1 = gs[1];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 dm[k] += (cam.p[4 * k] * mw - cam.p[4 * k + 3] * mul1) * g0 + (cam.p[4 * k + 1] * mw - cam.p[4 * k + 3] * mul2) * g1;
         }
         if (use_sh) {
-            const float dcol[3] = {a.dL_dcolors[3 * i], a.dL_dcolors[3 * i + 1], a.dL_dcolors[3 * i + 2]};
+            const float dcol[3] = {gs[6], gs[7], gs[8]};
             sh_backward(a.D, a.M, p, a.campos, a.shs + (size_t)3 * a.M * i, a.clamped[i], dcol, a.dL_dsh + (size_t)3 * a.M * i, dm);
         }
         if (!a.cov3D_precomp) {

@@ -135,11 +135,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             dL_dsh = torch.empty((P, M, 3), **f32) if sh_c is not None else None
             dL_dscales = torch.empty((P, 3), **f32) if sc_c is not None else None
             dL_drots = torch.empty((P, 4), **f32) if rot_c is not None else None
+            scratch = torch.empty(int(lib.gsicp_raster_backward_scratch_bytes(int(ctx.num_rendered), W, H)), dtype=torch.uint8, device=dev)
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             rc = lib.gsicp_raster_backward(
                 P, int(rs.sh_degree), M, int(ctx.num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh_c), _ptr(col_c), _ptr(sc_c),
                 float(rs.scale_modifier), _ptr(rot_c), _ptr(cov_c), _ptr(view), _ptr(proj), _ptr(campos), float(rs.tanfovx),
-                float(rs.tanfovy), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img), _ptr(g_color), _ptr(g_depth),
+                float(rs.tanfovy), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img), _ptr(scratch), _ptr(g_color), _ptr(g_depth),
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), _ptr(dL_dmeans3D),
                 _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drots), int(rs.tile_mod), int(rs.tile_rem),
                 int(bool(rs.debug)), stream)

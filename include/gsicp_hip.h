@@ -67,8 +67,14 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
                          const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                          float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug, void* stream);
 
+/* Bytes of DEVICE scratch gsicp_raster_backward needs (per-(list entry, strip) gradient slots; contents need no
+ * initialisation and are dead after the call). */
+size_t gsicp_raster_backward_scratch_bytes(int num_rendered, int width, int height);
+
 /* Backward of the call above.  geom/binning/img buffers are the ones the forward call filled; num_rendered its
- * return value.  dL_dpix (3,H,W) and dL_ddepth (1,H,W; may be NULL) are the incoming image gradients.
+ * return value; `scratch` is a DEVICE buffer of gsicp_raster_backward_scratch_bytes() bytes.
+ * dL_dpix (3,H,W) and dL_ddepth (1,H,W; may be NULL) are the incoming image gradients.
+ * No atomics are used: gradients are bit-reproducible from run to run.
  * Gradient outputs (all DEVICE, all fully overwritten): dL_dmeans2D (P,3) [x,y in NDC-scaled units, z = 0],
  * dL_dconic (P,4) scratch, dL_dopacity (P), dL_dcolors (P,3), dL_ddepths (P) scratch, dL_dmeans3D (P,3),
  * dL_dcov3D (P,6), dL_dsh (P,M,3; may be NULL when colors_precomp is used), dL_dscales (P,3), dL_drots (P,4).
@@ -78,10 +84,10 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
                           const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                           float tan_fovy, const int* radii, const char* geom_buffer, const char* binning_buffer,
-                          const char* img_buffer, const float* dL_dpix, const float* dL_ddepth, float* dL_dmeans2D,
-                          float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_ddepths, float* dL_dmeans3D,
-                          float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, int tile_mod, int tile_rem,
-                          int debug, void* stream);
+                          const char* img_buffer, char* scratch, const float* dL_dpix, const float* dL_ddepth,
+                          float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_ddepths,
+                          float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, int tile_mod,
+                          int tile_rem, int debug, void* stream);
 
 /* present[i] = 1 iff Gaussian i passes the frustum test (view-space z > 0.2).  Asynchronous. */
 int gsicp_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -90,8 +96,9 @@ int gsicp_raster_mark_visible(int P, const float* means3D, const float* viewmatr
 /* Introspection used by the parity tests: byte offsets of the sections inside the three scratch buffers
  * (so tests can read the sorted (tile, Gaussian) lists and tile ranges bit-exactly).  out[] receives
  * {geom_bytes, binning_bytes, img_bytes, off_records, off_point_list, off_tile_keys, off_ranges, off_final_T,
- *  off_n_contrib, off_clamped}. */
-int gsicp_raster_layout(int P, int num_rendered, int width, int height, size_t out[10]);
+ *  off_n_contrib, off_clamped, off_entry_gauss, off_entry_pos}.  A point_list word holds an emission-slot index in
+ * its low 28 bits (entry_gauss[slot] is the Gaussian id) and 4 strip bits on top. */
+int gsicp_raster_layout(int P, int num_rendered, int width, int height, size_t out[12]);
 
 /* --------------------------------------------------------------------------------------------------------
  * 2. simple_knn — replaces simple_knn._C.distCUDA2 [REF scene/gaussian_model.py:20 (import site)].

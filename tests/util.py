@@ -46,14 +46,16 @@ def read_scratch(lib, ctx_tensors, P, num_rendered, W, H):
     import ctypes
     import torch
     geom, binning, img = ctx_tensors
-    out = (ctypes.c_size_t * 10)()
+    out = (ctypes.c_size_t * 12)()
     lib.gsicp_raster_layout(P, num_rendered, W, H, out)
     T = ((W + 15) // 16) * ((H + 15) // 16)
     g8, b8, i8 = geom.cpu().numpy(), binning.cpu().numpy(), img.cpu().numpy()
     rec = g8[out[3]: out[3] + P * 48].view(np.float32).reshape(P, 12)
-    pl = b8[out[4]: out[4] + num_rendered * 4].view(np.uint32)
+    pl_raw = b8[out[4]: out[4] + num_rendered * 4].view(np.uint32)
+    entry_gauss = b8[out[10]: out[10] + num_rendered * 4].view(np.uint32)
+    pl = entry_gauss[pl_raw & np.uint32(0x0FFFFFFF)] if num_rendered else pl_raw   # low 28 bits = emission slot -> Gaussian id
     tk = b8[out[5]: out[5] + num_rendered * 4].view(np.uint32)
     ranges = i8[out[6]: out[6] + T * 8].view(np.uint32).reshape(T, 2)
     fT = i8[out[7]: out[7] + W * H * 4].view(np.float32).reshape(H, W)
     nc = i8[out[8]: out[8] + W * H * 4].view(np.uint32).reshape(H, W)
-    return dict(rec=rec, point_list=pl, tile_keys=tk, ranges=ranges, final_T=fT, n_contrib=nc)
+    return dict(rec=rec, point_list=pl, strip_bits=pl_raw >> np.uint32(28), tile_keys=tk, ranges=ranges, final_T=fT, n_contrib=nc)
