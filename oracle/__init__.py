@@ -65,7 +65,7 @@ def raster_forward(means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, 
     means3D = _arr(means3D, dt, (-1, 3))
     P = means3D.shape[0]
     shs = _arr(shs, dt)
-    M = 0 if shs is None else shs.reshape(P, -1, 3).shape[1]
+    M = 0 if shs is None else (shs.reshape(P, -1, 3).shape[1] if P > 0 else max(1, int(np.prod(shs.shape[1:])) // 3))
     colors_precomp = _arr(colors_precomp, dt)
     opacities = _arr(opacities, dt, (-1,))
     scales = _arr(scales, dt)
@@ -112,7 +112,7 @@ def raster_backward(means3D, opacities, viewmatrix, projmatrix, campos, tanfovx,
     means3D = _arr(means3D, dt, (-1, 3))
     P = means3D.shape[0]
     shs = _arr(shs, dt)
-    M = 0 if shs is None else shs.reshape(P, -1, 3).shape[1]
+    M = 0 if shs is None else (shs.reshape(P, -1, 3).shape[1] if P > 0 else max(1, int(np.prod(shs.shape[1:])) // 3))
     colors_precomp = _arr(colors_precomp, dt)
     opacities = _arr(opacities, dt, (-1,))
     scales = _arr(scales, dt)

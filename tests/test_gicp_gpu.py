@@ -52,7 +52,7 @@ def quat_cov(q, s):
 
 def pose_err(T, gt):
     dR = T[:3, :3].astype(np.float64) @ gt[:3, :3].T
-    ang = np.degrees(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
+    ang = np.degrees(np.linalg.norm(dR - np.eye(3)) / np.sqrt(2.0))   # small-angle rotation error; acos(trace) loses precision near 0
     return ang, 1e3 * np.linalg.norm(T[:3, 3] - gt[:3, 3])
 
 

@@ -1,0 +1,112 @@
+"""CPU, 2 processes over gloo: the tile-sharded mapper path (gs_icp_slam_amd/sharded.py) must reproduce the single-process
+result — same image on every rank, and gradients that sum to the unsharded gradients.  The collectives and autograd
+plumbing are the product's; the per-rank rasteriser is an oracle-backed stand-in (test infrastructure) because the HIP
+kernels need a GPU.  The same property is checked on real hardware in tests/test_raster_gpu.py (tile sharding test)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gs_icp_slam_amd import synth
+from tests import util
+
+
+def _tile_mask(W, H, mod, rem):
+    ty, tx = np.meshgrid(np.arange(H) // 16, np.arange(W) // 16, indexing="ij")
+    tid = ty * ((W + 15) // 16) + tx
+    return torch.from_numpy((tid % mod) == rem)
+
+
+class _OracleRasterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, rs):
+        g = dict(means3D=means3D.detach().numpy(), shs=shs.detach().numpy(), opacities=opacities.detach().numpy(),
+                 scales=scales.detach().numpy(), rotations=rotations.detach().numpy())
+        cam = dict(viewmatrix=rs.viewmatrix.numpy(), projmatrix=rs.projmatrix.numpy(), campos=rs.campos.numpy(), tanfovx=rs.tanfovx,
+                   tanfovy=rs.tanfovy, W=rs.image_width, H=rs.image_height)
+        o = util.oracle_forward(g, cam, rs.bg.numpy(), 0)
+        mask = _tile_mask(rs.image_width, rs.image_height, rs.tile_mod, rs.tile_rem)
+        ctx.g, ctx.cam, ctx.rs, ctx.mask = g, cam, rs, mask
+        color = torch.from_numpy(o["color"]) * mask
+        depth = torch.from_numpy(o["depth"])[None] * mask
+        return depth, color, torch.from_numpy(o["radii"]), torch.from_numpy(o["is_used"])
+
+    @staticmethod
+    def backward(ctx, g_depth, g_color, *_):
+        gc = (g_color * ctx.mask).numpy()
+        gd = (g_depth[0] * ctx.mask).numpy()
+        b = util.oracle_backward(ctx.g, ctx.cam, ctx.rs.bg.numpy(), gc, gd, 0)
+        t = torch.from_numpy
+        return (t(b["dL_dmeans3D"]), t(b["dL_dmeans2D"]), t(b["dL_dsh"]), t(b["dL_dopacity"])[:, None], t(b["dL_dscales"]),
+                t(b["dL_drots"]), None)
+
+
+class _OracleRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.rs = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        return _OracleRasterFn.apply(means3D, means2D, shs, opacities, scales, rotations, self.rs)
+
+
+def _settings(cam):
+    from gs_icp_slam_amd.rasterizer import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=cam["H"], image_width=cam["W"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.tensor([0.1, 0.2, 0.3]),
+        scale_modifier=1.0, viewmatrix=torch.from_numpy(cam["viewmatrix"]), projmatrix=torch.from_numpy(cam["projmatrix"]), sh_degree=0,
+        campos=torch.from_numpy(cam["campos"]), prefiltered=False, debug=False)
+
+
+def _run(rasterizer, g, target):
+    t = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in g.items()}
+    m2d = torch.zeros_like(t["means3D"], requires_grad=True)
+    depth, color, radii, used = rasterizer(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
+                                           rotations=t["rotations"])
+    loss = (color - target[:3]).abs().mean() + 0.1 * (depth - target[3:]).abs().mean()
+    loss.backward()
+    return color.detach(), depth.detach(), {k: v.grad.clone() for k, v in t.items()}, used
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gs_icp_slam_amd.sharded import ShardedGaussianRasterizer
+    cam = synth.make_camera(80, 48, 64.0, 64.0)
+    g = synth.random_gaussians(120, seed=4)
+    target = torch.from_numpy(np.random.default_rng(0).random((4, 48, 80)).astype(np.float32))
+    color, depth, grads, used = _run(ShardedGaussianRasterizer(_settings(cam), rasterizer_cls=_OracleRasterizer), g, target)
+    q.put((rank, color.numpy(), depth.numpy(), {k: v.numpy() for k, v in grads.items()}, used.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cam = synth.make_camera(80, 48, 64.0, 64.0)
+    g = synth.random_gaussians(120, seed=4)
+    target = torch.from_numpy(np.random.default_rng(0).random((4, 48, 80)).astype(np.float32))
+    color, depth, grads, used = _run(_OracleRasterizer(_settings(cam)), g, target)
+    for rank, c, d, gr, u in outs:
+        assert np.array_equal(c, color.numpy()) and np.array_equal(d, depth.numpy()), f"rank {rank}: image differs"
+        assert np.array_equal(u, used.numpy())
+        for k in grads:
+            np.testing.assert_allclose(gr[k], grads[k].numpy(), rtol=1e-5, atol=1e-7 * (np.abs(grads[k].numpy()).max() + 1e-30))
+    for k in grads:   # both ranks hold identical (all-reduced) gradients
+        assert np.array_equal(outs[0][3][k], outs[1][3][k])
