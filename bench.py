@@ -136,14 +136,10 @@ def main():
         dt = float(tmax.item())
 
     # ---------------- roofline of the dominant kernel ----------------
-    per_launch_us = {k: (1e3 * ms / max(c, 1)) for k, (ms, c) in prof.items() if c > 0}
-    raster_stages = ["preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "tile_ranges", "blend_forward", "blend_backward",
-                     "preprocess_backward", "entry_grad_sum"]
+    per_launch_us = {k: (1e3 * ms / args.steps) for k, (ms, c) in prof.items() if c > 0}   # us per step (a stage may be several launches)
+    raster_stages = ["preprocess", "tile_scan_lpt", "scatter", "tile_sort", "blend_forward", "blend_backward", "entry_grad_sum",
+                     "preprocess_backward"]
     dominant = max((k for k in raster_stages if k in per_launch_us), key=lambda k: per_launch_us[k])
-    num_rendered = 0
-    fn_probe = None
-    with torch.no_grad():
-        pass
     # D (duplicates) and P_vis from one extra forward
     means2D = torch.zeros_like(params["means3D"], requires_grad=True)
     depth, color, radii, used = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
@@ -154,13 +150,12 @@ def main():
     D_local = int(getattr(node, "num_rendered", 0))
     P_vis = int((radii > 0).sum())
     T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    n_pass = 2  # tile sort: 8 B (key+value) read + written per pass, ceil(bits/8) = 2 passes for T <= 65 536 tiles
-    bytes_fwd_blend = 52.0 * D_local + 24.0 * W * H / world + 8.0 * T_tiles / world        # list + gather 48 B, pixel writes
-    bytes_bwd_blend = 52.0 * D_local + 40.0 * W * H / world + 44.0 * P_vis                  # SURVEY §8d backward formula
-    alg_bytes = {"blend_forward": bytes_fwd_blend, "blend_backward": bytes_bwd_blend,
-                 "preprocess": 128.0 * P, "preprocess_backward": 184.0 * P, "tile_sort": 16.0 * n_pass * D_local,
-                 "depth_sort": 16.0 * 4 * P, "duplicate": 8.0 * D_local + 56.0 * P_vis, "tile_ranges": 4.0 * D_local,
-                 "scan": 12.0 * P, "entry_grad_sum": 240.0 * D_local}
+    # Algorithmic bytes per launch: list word 4 B per (strip, entry) visit = 16 B per duplicate,
+    # 48 B record per duplicate (an upper bound: only staged records are gathered), per-pixel state, gradient slots.
+    alg_bytes = {"blend_forward": 64.0 * D_local + 24.0 * W * H / world + 8.0 * T_tiles / world,
+                 "blend_backward": 64.0 * D_local + 40.0 * W * H / world + 48.0 * D_local,
+                 "preprocess": 128.0 * P, "preprocess_backward": 184.0 * P + 48.0 * D_local, "tile_sort": 24.0 * D_local,
+                 "scatter": 16.0 * D_local + 56.0 * P_vis, "tile_scan_lpt": 16.0 * T_tiles, "entry_grad_sum": 240.0 * D_local}
     ach = alg_bytes[dominant] / (per_launch_us[dominant] * 1e-6) / 1e9
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "kernel_us": round(per_launch_us[dominant], 2),
@@ -199,7 +194,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-reduce image + grads), tracker replicated"},
             "render_bwd_ms_per_iter": round(sum(per_launch_us.get(k, 0.0) for k in raster_stages) / 1e3, 4),
             "tracker_align_kernel_us": stage_us.get("gicp_align"),
-            "stage_us_per_launch": stage_us,
+            "stage_us_per_step": stage_us,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -5,21 +5,22 @@
 // from [REF gaussian_renderer/__init__.py:294-302] and [REF mp_Mapper.py:242].
 //
 // MI355X-first design notes (details and measurements: DESIGN.md):
-//  * Binning is a TWO-LEVEL stable LSD sort instead of one 64-bit sort of all duplicates: (1) the P Gaussians are
-//    radix-sorted by view depth once (32-bit keys), (2) duplicates are emitted in that order with only the tile id
-//    as key and radix-sorted on ceil(log2 T) bits.  Stable LSD on (depth, then tile) yields exactly the order of the
-//    classic (tile<<32 | depth) sort — the parity tests check the lists bit-for-bit — while moving ~5x fewer bytes
-//    through HBM/L2 (2 passes of 8 B per duplicate instead of 6 passes of 12 B).
-//  * Blend kernels use one 256-thread workgroup (4 wave64s, each a 16x4 pixel strip) per 16x16 tile.  Binning tags
-//    every list entry with 4 strip bits (which strips the splat's alpha >= 1/255 footprint can reach); each wave
-//    compacts its own 64-entry batches by those bits and stages only the surviving 48-byte records in a
-//    wave-private LDS slab — no workgroup barriers, and culled entries cost 1/64 of a vector instruction.
-//  * blockIdx -> tile mapping is XCD-aware: block b runs on XCD b%8, so each XCD is handed a contiguous band of
-//    tiles and neighbouring tiles' shared splats hit in that XCD's private L2.
+//  * Binning is "count, scatter, sort locally", five launches in total, instead of a global radix sort of all
+//    (tile, depth) duplicates (the classic implementation: ~25 small launches through a sort library, each a
+//    dependent kernel boundary of 5-10 us on this chip).  preprocess counts the duplicates of every tile with
+//    integer atomics and hands each Gaussian a private run of "emission slots"; one single-workgroup kernel turns
+//    the tile counts into list ranges and an LPT dispatch order; the scatter kernel drops every duplicate anywhere
+//    inside its tile's range (atomic cursor); one workgroup per tile then bitonic-sorts its list in LDS by
+//    (depth bits, Gaussian id).  The (depth, id) order is total, so the lists are exactly those of a stable
+//    (tile << 32 | depth) sort of duplicates emitted in id order — the parity tests compare them bit-for-bit.
+//  * Blend kernels: one wave64 per (tile, 16x4 strip).  Binning tags every list entry with 4 strip bits (which
+//    strips the splat's alpha >= 1/255 footprint can reach); a wave compacts its 64-entry batches by its bit and
+//    stages only the surviving 48-byte records in LDS — no workgroup barriers, and culled entries cost 1/64 of a
+//    vector instruction.  Work items are dispatched longest list first (LPT).
 //  * Backward: every lane of a wave walks the same splat at the same step, so the 10 partial gradients are reduced
-//    across the 64 lanes with 60 hand-scheduled DPP adds (no LDS atomics, no wait states), parked in the wave's LDS
-//    slab and flushed with one 64-wide global atomic instruction per component per batch — 64x fewer atomics than
-//    a per-pixel scheme.  Waves in which no lane passes the alpha test skip the reduction (wave-uniform branch).
+//    across the 64 lanes with 60 hand-scheduled DPP adds and stored into a private slot per (emission slot, strip);
+//    a streaming pass adds the strips and each Gaussian sums its own contiguous run.  No float atomics anywhere:
+//    device-scope atomics resolve at the memory side on this 8-XCD part, and gradients stay bit-reproducible.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +30,6 @@
 #include <vector>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "../../include/gsicp_hip.h"
 #include "raster_common.hpp"
@@ -46,8 +46,8 @@ std::vector<ProfRec> g_prof_log;
 std::vector<hipEvent_t> g_prof_pool;
 hipEvent_t g_prof_open[ST_COUNT];
 std::atomic<int> g_prof_enabled{0};
-const char* const g_stage_names[ST_COUNT] = {"preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "tile_ranges", "blend_forward",
-                                             "blend_backward", "preprocess_backward", "entry_grad_sum", "gicp_knn_cov", "gicp_grid_build",
+const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "scatter", "tile_sort", "blend_forward",
+                                             "blend_backward", "entry_grad_sum", "preprocess_backward", "gicp_knn_cov", "gicp_grid_build",
                                              "gicp_align", "gicp_exact_nn"};
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
@@ -83,23 +83,77 @@ void profile_end(int stage, hipStream_t s) {
 namespace {
 
 // ------------------------------------------------------------------------------------------------ binning
-struct TilesOfSorted {
-    const uint32_t* tiles_touched;
-    __device__ uint32_t operator()(uint32_t id) const { return tiles_touched[id]; }
-};
+// Single workgroup: exclusive scan of the per-tile duplicate counts -> list ranges, and an LPT dispatch order by a
+// counting sort over 64 length buckets (exact ordering is not needed for load balance).  Any T; one launch.
+constexpr int LPT_BUCKETS = 64;
+__global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int tile_mod, int tile_rem, const uint32_t* __restrict__ tile_count,
+                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_hist[LPT_BUCKETS];
+    __shared__ uint32_t s_maxlen;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_carry = 0; s_maxlen = 0; }
+    if (tid < LPT_BUCKETS) s_hist[tid] = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+        const int t = base + tid;
+        const uint32_t c = t < T ? tile_count[t] : 0u;
+        uint32_t incl = c;   // wave inclusive scan
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+        const uint32_t start = s_carry + wave_off + incl - c;
+        if (t < T) ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);   // empty tiles read (0,0), as the reference leaves them
+        uint32_t wmax = c;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(wmax, off, 64); wmax = o > wmax ? o : wmax; }
+        if (lane == 0 && wmax > 0) atomicMax(&s_maxlen, wmax);
+        __syncthreads();
+        if (tid == 1023) s_carry = start + c;
+        __syncthreads();
+    }
+    // LPT order over this rank's tiles
+    const uint32_t maxlen = s_maxlen;
+    const uint32_t div = maxlen / LPT_BUCKETS + 1;
+    const int n_local = (T - tile_rem + tile_mod - 1) / tile_mod;
+    for (int i = tid; i < n_local; i += 1024) {
+        const uint32_t c = tile_count[i * tile_mod + tile_rem];
+        atomicAdd(&s_hist[LPT_BUCKETS - 1 - (c / div)], 1u);     // bucket 0 = longest lists
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < LPT_BUCKETS; ++b) { const uint32_t h = s_hist[b]; s_hist[b] = run; run += h; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_local; i += 1024) {
+        const int t = i * tile_mod + tile_rem;
+        const uint32_t c = tile_count[t];
+        const uint32_t pos = atomicAdd(&s_hist[LPT_BUCKETS - 1 - (c / div)], 1u);
+        order[pos] = (uint32_t)t;
+    }
+}
 
-// One thread per depth-sorted Gaussian: emit (tile id, Gaussian id | strip bits) for every tile of its rectangle.
-__global__ __launch_bounds__(256) void duplicate_kernel(int P, const uint32_t* __restrict__ ids_sorted,
-                                                        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
-                                                        const SplatRec* __restrict__ rec, const int* __restrict__ radii, int gx, int gy,
-                                                        int tile_mod, int tile_rem, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint32_t* __restrict__ entry_gauss) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= P) return;
-    const uint32_t id = ids_sorted[k];
+// One thread per Gaussian (id order): fill its contiguous run of emission slots — tile id, depth bits, list word
+// (slot | strip bits), slot -> Gaussian map.  Coalesced-ish plain stores, no atomics.
+__global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ slot_base,
+                                                   const SplatRec* __restrict__ rec, const int* __restrict__ radii, int gx, int gy,
+                                                   int tile_mod, int tile_rem, uint32_t* __restrict__ emit_tile,
+                                                   uint32_t* __restrict__ emit_depth, uint32_t* __restrict__ entry_gauss,
+                                                   uint32_t* __restrict__ entry_bits) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= P) return;
     if (tiles_touched[id] == 0) return;
-    uint32_t off = k == 0 ? 0u : offsets[k - 1];
+    uint32_t u = slot_base[id];
     const SplatRec r = rec[id];
+    const uint32_t dbits = __float_as_uint(r.depth);
     int x0, y0, x1, y1;
     tile_rect(r.px, r.py, radii[id], gx, gy, x0, y0, x1, y1);
     const float fx0 = r.px - r.hx, fx1 = r.px + r.hx, fy0 = r.py - r.hy, fy1 = r.py + r.hy;   // alpha footprint box
@@ -115,32 +169,122 @@ __global__ __launch_bounds__(256) void duplicate_kernel(int P, const uint32_t* _
                     if (fy1 >= ylo && fy0 <= ylo + 3.f) bits |= 1u << sidx;
                 }
             }
-            keys[off] = (uint32_t)t;
-            vals[off] = off | (bits << STRIP_SHIFT);   // the list carries the emission slot; the slot knows its Gaussian
-            entry_gauss[off] = id;
-            ++off;
+            emit_tile[u] = (uint32_t)t;
+            emit_depth[u] = dbits;
+            entry_gauss[u] = (uint32_t)id;
+            entry_bits[u] = bits;
+            ++u;
         }
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(int R, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ entry_pos) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= R) return;
-    entry_pos[vals[k] & ID_MASK] = (uint32_t)k;   // inverse of the tile sort, used by the per-Gaussian gradient gather
-    const uint32_t t = keys[k];
-    if (k == 0 || keys[k - 1] != t) ranges[t].x = (uint32_t)k;
-    if (k == R - 1 || keys[k + 1] != t) ranges[t].y = (uint32_t)(k + 1);
+// Tile multi-split, pass 1: each workgroup histograms its contiguous chunk of emission slots over all T tiles in LDS
+// (LDS atomics; no global atomics) and writes its row of the (split block, tile) count table.
+__global__ __launch_bounds__(1024) void split_hist_kernel(int R, int T, int chunk, const uint32_t* __restrict__ emit_tile,
+                                                          uint32_t* __restrict__ block_hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist_dyn[];
+    for (int t = threadIdx.x; t < T; t += 1024) s_hist_dyn[t] = 0;
+    __syncthreads();
+    const int lo = blockIdx.x * chunk, hi = (lo + chunk) < R ? (lo + chunk) : R;
+    for (int u = lo + threadIdx.x; u < hi; u += 1024) atomicAdd(&s_hist_dyn[emit_tile[u]], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 1024) block_hist[(size_t)blockIdx.x * T + t] = s_hist_dyn[t];
+}
+// pass 2: one thread per tile turns its column of the table into exclusive prefixes and yields the tile's total
+__global__ __launch_bounds__(256) void split_colscan_kernel(int T, int nb, uint32_t* __restrict__ block_hist, uint32_t* __restrict__ tile_count) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    uint32_t run = 0;
+    for (int b = 0; b < nb; ++b) {
+        const uint32_t c = block_hist[(size_t)b * T + t];
+        block_hist[(size_t)b * T + t] = run;
+        run += c;
+    }
+    tile_count[t] = run;
+}
+// pass 3: scatter every emission slot into its tile's range; the rank inside the (block, tile) cell comes from an LDS
+// cursor.  Order inside a tile is arbitrary here — the per-tile sort that follows makes it unique.
+__global__ __launch_bounds__(1024) void split_scatter_kernel(int R, int T, int chunk, const uint32_t* __restrict__ emit_tile,
+                                                             const uint32_t* __restrict__ emit_depth, const uint32_t* __restrict__ entry_bits,
+                                                             const uint32_t* __restrict__ block_hist, const uint2* __restrict__ ranges,
+                                                             uint32_t* __restrict__ sc_keys, uint32_t* __restrict__ sc_vals) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist_dyn[];
+    for (int t = threadIdx.x; t < T; t += 1024) s_hist_dyn[t] = 0;
+    __syncthreads();
+    const int lo = blockIdx.x * chunk, hi = (lo + chunk) < R ? (lo + chunk) : R;
+    for (int u = lo + threadIdx.x; u < hi; u += 1024) {
+        const uint32_t t = emit_tile[u];
+        const uint32_t r = atomicAdd(&s_hist_dyn[t], 1u);
+        const uint32_t pos = ranges[t].x + block_hist[(size_t)blockIdx.x * T + t] + r;
+        sc_keys[pos] = emit_depth[u];
+        sc_vals[pos] = (uint32_t)u | (entry_bits[u] << STRIP_SHIFT);
+    }
 }
 
-// Longest-processing-time-first dispatch: key = ~length so that an ascending radix sort yields longest tiles first.
-__global__ __launch_bounds__(256) void tile_order_keys_kernel(int n_local, int tile_mod, int tile_rem, const uint2* __restrict__ ranges,
-                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_local) return;
-    const int t = i * tile_mod + tile_rem;
-    const uint2 r = ranges[t];
-    keys[i] = 0xFFFFFFFFu - (r.y - r.x);
-    vals[i] = (uint32_t)t;
+// One workgroup per tile: sort the tile's list by (depth bits, Gaussian id) — a total order, so the result is unique.
+// Lists up to SORT_CAP entries are bitonic-sorted in LDS; longer ones fall back to an O(n^2) rank sort in global memory
+// (correct, slow, and not reached by the scenes in BASELINE.json: their longest lists are a few hundred entries).
+constexpr int SORT_CAP = 4096;     // large-list kernel: 256 threads, 48 KB LDS
+constexpr int SORT_SMALL = 512;    // small-list kernel: 128 threads, 6 KB LDS -> many workgroups per CU
+template <int CAP, int THREADS, int MIN_N>
+__global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __restrict__ order, const uint2* __restrict__ ranges,
+                                                        const uint32_t* __restrict__ sc_keys, const uint32_t* __restrict__ sc_vals,
+                                                        const uint32_t* __restrict__ entry_gauss, uint32_t* __restrict__ point_list,
+                                                        uint32_t* __restrict__ tile_keys) {
+    __shared__ unsigned long long s_key[CAP];
+    __shared__ uint32_t s_val[CAP];
+    const uint32_t tile = order[blockIdx.x];
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    if (n <= MIN_N || (MIN_N == 0 && n > CAP)) return;   // the other size class's kernel handles this tile
+    const int tid = threadIdx.x;
+    if (n > CAP) {
+        for (int i = tid; i < n; i += THREADS) {
+            const uint32_t v = sc_vals[range.x + i];
+            const unsigned long long k = ((unsigned long long)sc_keys[range.x + i] << 32) | entry_gauss[v & ID_MASK];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const uint32_t vj = sc_vals[range.x + j];
+                const unsigned long long kj = ((unsigned long long)sc_keys[range.x + j] << 32) | entry_gauss[vj & ID_MASK];
+                rank += kj < k;
+            }
+            point_list[range.x + rank] = v;
+            tile_keys[range.x + rank] = tile;
+        }
+        return;
+    }
+    int npad = 64;
+    while (npad < n) npad <<= 1;
+    for (int i = tid; i < npad; i += THREADS) {
+        if (i < n) {
+            const uint32_t v = sc_vals[range.x + i];
+            s_val[i] = v;
+            s_key[i] = ((unsigned long long)sc_keys[range.x + i] << 32) | entry_gauss[v & ID_MASK];
+        } else {
+            s_key[i] = ~0ull;
+            s_val[i] = 0;
+        }
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npad; i += THREADS) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = s_key[i], b = s_key[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s_key[i] = b; s_key[l] = a;
+                        const uint32_t va = s_val[i]; s_val[i] = s_val[l]; s_val[l] = va;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += THREADS) {
+        point_list[range.x + i] = s_val[i];
+        tile_keys[range.x + i] = tile;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ blending
@@ -411,12 +555,12 @@ __global__ __launch_bounds__(64) void blend_backward_strip_kernel(BlendArgs a) {
 }
 
 // Entry-parallel: add up each emission slot's (up to four) strip slots into one 12-float record, so that the
-// per-Gaussian pass only streams a contiguous array.  Fully parallel, no dependent chains.
+// per-Gaussian pass (preprocess_backward) only streams a contiguous array.  Fully parallel, no dependent chains.
 __global__ __launch_bounds__(256) void entry_sum_kernel(int R, const uint32_t* __restrict__ entry_bits, const float* __restrict__ slots,
                                                         float* __restrict__ entry_sum) {
     const int u = blockIdx.x * 256 + threadIdx.x;
     if (u >= R) return;
-    const uint32_t bits = entry_bits[u] >> STRIP_SHIFT;
+    const uint32_t bits = entry_bits[u];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) {
@@ -430,62 +574,6 @@ __global__ __launch_bounds__(256) void entry_sum_kernel(int R, const uint32_t* _
     }
     float4* dst = (float4*)(entry_sum + (size_t)u * SLOT_F);
     dst[0] = a0; dst[1] = a1; dst[2] = a2;
-}
-
-// One thread per Gaussian IN DEPTH-RANK ORDER: rank r owns the contiguous emission slots [offsets[r-1], offsets[r]), so a
-// wave reads one contiguous stretch of entry_sum (coalesced, TLB-friendly) and scatters ten sums per Gaussian.
-__global__ __launch_bounds__(256) void gaussian_grad_gather_kernel(int P, const uint32_t* __restrict__ ids_sorted,
-                                                                   const uint32_t* __restrict__ offsets, const float* __restrict__ entry_sum,
-                                                                   float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-                                                                   float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors,
-                                                                   float* __restrict__ dL_ddepths) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= P) return;
-    const uint32_t id = ids_sorted[r];
-    const uint32_t u0 = r == 0 ? 0u : offsets[r - 1], u1 = offsets[r];
-    float gs[NGRAD];
-#pragma unroll
-    for (int c = 0; c < NGRAD; ++c) gs[c] = 0.f;
-    const float4* es = (const float4*)entry_sum;
-    for (uint32_t u = u0; u < u1; ++u) {
-        const float4 p0 = es[3 * (size_t)u], p1 = es[3 * (size_t)u + 1], p2 = es[3 * (size_t)u + 2];
-        gs[0] += p0.x; gs[1] += p0.y; gs[2] += p0.z; gs[3] += p0.w;
-        gs[4] += p1.x; gs[5] += p1.y; gs[6] += p1.z; gs[7] += p1.w;
-        gs[8] += p2.x; gs[9] += p2.y;
-    }
-    dL_dmean2D[3 * (size_t)id] = gs[0]; dL_dmean2D[3 * (size_t)id + 1] = gs[1]; dL_dmean2D[3 * (size_t)id + 2] = 0.f;
-    dL_dconic[4 * (size_t)id] = gs[2]; dL_dconic[4 * (size_t)id + 1] = gs[3]; dL_dconic[4 * (size_t)id + 2] = gs[4]; dL_dconic[4 * (size_t)id + 3] = 0.f;
-    dL_dopacity[id] = gs[5];
-    dL_dcolors[3 * (size_t)id] = gs[6]; dL_dcolors[3 * (size_t)id + 1] = gs[7]; dL_dcolors[3 * (size_t)id + 2] = gs[8];
-    dL_ddepths[id] = gs[9];
-}
-
-inline int tile_bits(int T) {
-    int b = 1;
-    while ((1 << b) < T) ++b;
-    return b;
-}
-
-inline size_t geom_temp_bytes(int P, hipStream_t s) {
-    size_t sort_b = 0, scan_b = 0;
-    const int n = P > 0 ? P : 1;
-    (void)rocprim::radix_sort_pairs(nullptr, sort_b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                              (size_t)n, 0, 32, s);
-    auto it = rocprim::make_transform_iterator((const uint32_t*)nullptr, TilesOfSorted{nullptr});
-    (void)rocprim::inclusive_scan(nullptr, scan_b, it, (uint32_t*)nullptr, (size_t)n, rocprim::plus<uint32_t>(), s);
-    return sort_b > scan_b ? sort_b : scan_b;
-}
-inline size_t order_temp_bytes(int T, hipStream_t s) {
-    size_t b = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                    (size_t)(T > 0 ? T : 1), 0, 32, s);
-    return b;
-}
-inline size_t bin_temp_bytes(size_t R, int bits, hipStream_t s) {
-    size_t b = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                              R > 0 ? R : 1, 0, bits, s);
-    return b;
 }
 
 }  // namespace
@@ -521,12 +609,12 @@ int gsicp_profile_read(double* ms_out, int* count_out, int capacity) {
 }
 
 int gsicp_raster_layout(int P, int num_rendered, int width, int height, size_t out[12]) {
-    const int T = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-    const GeomLayout G = geom_layout(P, geom_temp_bytes(P, nullptr));
-    const BinLayout B = bin_layout((size_t)num_rendered, bin_temp_bytes((size_t)num_rendered, tile_bits(T), nullptr));
-    const ImgLayout I = img_layout(width, height, order_temp_bytes(T, nullptr));
+    const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    const GeomLayout G = geom_layout(P);
+    const BinLayout B = bin_layout((size_t)num_rendered, T);
+    const ImgLayout I = img_layout(width, height);
     out[0] = G.total; out[1] = B.total; out[2] = I.total; out[3] = G.records; out[4] = B.point_list; out[5] = B.tile_keys;
-    out[6] = I.ranges; out[7] = I.final_T; out[8] = I.n_contrib; out[9] = G.clamped; out[10] = B.entry_gauss; out[11] = B.entry_pos;
+    out[6] = I.ranges; out[7] = I.final_T; out[8] = I.n_contrib; out[9] = G.clamped; out[10] = B.entry_gauss; out[11] = B.entry_bits;
     return 0;
 }
 
@@ -540,6 +628,7 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     (void)prefiltered; (void)debug;
     hipStream_t stream = (hipStream_t)stream_v;
     if (width <= 0 || height <= 0 || P < 0) { g_last_error = "gsicp_raster_forward: bad sizes"; return -2; }
+    if (P > (int)ID_MASK) { g_last_error = "more than 2^28 Gaussians are not supported"; return -2; }
     if (P > 0 && (shs == nullptr) == (colors_precomp == nullptr)) { g_last_error = "provide exactly one of shs / colors_precomp"; return -2; }
     if (P > 0 && ((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
         g_last_error = "provide exactly one of (scales, rotations) / cov3D_precomp"; return -2;
@@ -549,26 +638,28 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     if (!geom_alloc || !binning_alloc || !img_alloc) { g_last_error = "null resize callback"; return -2; }
 
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE, T = gx * gy;
-    const size_t HW = (size_t)width * height;
 
-    const ImgLayout IL = img_layout(width, height, order_temp_bytes(T, stream));
+    const ImgLayout IL = img_layout(width, height);
     char* img = img_alloc(img_user, IL.total);
     if (!img) { g_last_error = "img resize callback returned NULL"; return -3; }
     uint2* ranges = (uint2*)(img + IL.ranges);
     float* final_T = (float*)(img + IL.final_T);
     uint32_t* n_contrib = (uint32_t*)(img + IL.n_contrib);
+    uint32_t* order = (uint32_t*)(img + IL.order);
+    uint32_t* tile_count = (uint32_t*)(img + IL.tile_count);   // [T] counts, [T] cursors, [64] counters: one memset
+    uint32_t* total_counter = tile_count + 2 * T;
 
-    GS_CHECK(hipMemsetAsync(ranges, 0, (size_t)T * 8, stream));
-    if (is_used && P > 0) GS_CHECK(hipMemsetAsync(is_used, 0, (size_t)P * 4, stream));
-
-    int num_rendered = 0;
-    const GeomLayout GL = geom_layout(P, geom_temp_bytes(P, stream));
+    const GeomLayout GL = geom_layout(P);
     char* geom = geom_alloc(geom_user, GL.total);
     if (!geom) { g_last_error = "geom resize callback returned NULL"; return -3; }
     SplatRec* rec = (SplatRec*)(geom + GL.records);
-    uint32_t* point_list = nullptr;
-    uint32_t* entry_gauss = nullptr;
+    uint32_t* tiles_touched = (uint32_t*)(geom + GL.tiles_touched);
+    uint32_t* slot_base = (uint32_t*)(geom + GL.slot_base);
 
+    GS_CHECK(hipMemsetAsync(tile_count, 0, ((size_t)2 * T + 64) * 4, stream));
+    if (is_used && P > 0) GS_CHECK(hipMemsetAsync(is_used, 0, (size_t)P * 4, stream));
+
+    int num_rendered = 0;
     if (P > 0) {
         PreprocessArgs pa;
         pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height;
@@ -577,52 +668,62 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
         pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos; pa.tanfovx = tan_fovx; pa.tanfovy = tan_fovy;
         pa.tile_mod = tile_mod; pa.tile_rem = tile_rem;
         pa.rec = rec; pa.clamped = (unsigned char*)(geom + GL.clamped);
-        pa.tiles_touched = (uint32_t*)(geom + GL.tiles_touched);
-        pa.depth_keys = (uint32_t*)(geom + GL.depth_keys); pa.ids = (uint32_t*)(geom + GL.ids);
+        pa.tiles_touched = tiles_touched; pa.slot_base = slot_base; pa.total_counter = total_counter;
         pa.radii = radii;
         { ProfileScope ps(ST_PREPROCESS, stream); launch_preprocess(pa, stream); }
-
-        uint32_t* keys_sorted = (uint32_t*)(geom + GL.depth_keys_sorted);
-        uint32_t* ids_sorted = (uint32_t*)(geom + GL.ids_sorted);
-        uint32_t* offsets = (uint32_t*)(geom + GL.offsets);
-        size_t tb = GL.temp_bytes;
-        { ProfileScope ps(ST_DEPTH_SORT, stream);
-          GS_CHECK(rocprim::radix_sort_pairs(geom + GL.temp, tb, pa.depth_keys, keys_sorted, pa.ids, ids_sorted, (size_t)P, 0, 32, stream)); }
-        auto it = rocprim::make_transform_iterator((const uint32_t*)ids_sorted, TilesOfSorted{pa.tiles_touched});
-        tb = GL.temp_bytes;
-        { ProfileScope ps(ST_SCAN, stream);
-          GS_CHECK(rocprim::inclusive_scan(geom + GL.temp, tb, it, offsets, (size_t)P, rocprim::plus<uint32_t>(), stream)); }
         uint32_t total = 0;
-        GS_CHECK(hipMemcpyAsync(&total, offsets + (P - 1), 4, hipMemcpyDeviceToHost, stream));
-        GS_CHECK(hipStreamSynchronize(stream));
+        GS_CHECK(hipMemcpyAsync(&total, total_counter, 4, hipMemcpyDeviceToHost, stream));
+        GS_CHECK(hipStreamSynchronize(stream));   // the one host sync of the forward: the binning buffer is sized by it
+        if (total > ID_MASK) { g_last_error = "more than 2^28 (Gaussian, tile) duplicates are not supported"; return -2; }
         num_rendered = (int)total;
-
-        const int bits = tile_bits(T);
-        const BinLayout BL = bin_layout((size_t)num_rendered, bin_temp_bytes((size_t)num_rendered, bits, stream));
-        char* bin = binning_alloc(binning_user, BL.total);
-        if (!bin) { g_last_error = "binning resize callback returned NULL"; return -3; }
-        point_list = (uint32_t*)(bin + BL.point_list);
-        entry_gauss = (uint32_t*)(bin + BL.entry_gauss);
-        if (num_rendered > 0) {
-            uint32_t* keys_u = (uint32_t*)(bin + BL.tile_keys_unsorted);
-            uint32_t* vals_u = (uint32_t*)(bin + BL.point_list_unsorted);
-            uint32_t* keys_s = (uint32_t*)(bin + BL.tile_keys);
-            { ProfileScope ps(ST_DUPLICATE, stream);
-              hipLaunchKernelGGL(duplicate_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, ids_sorted, offsets,
-                                 pa.tiles_touched, rec, radii, gx, gy, tile_mod, tile_rem, keys_u, vals_u, (uint32_t*)(bin + BL.entry_gauss)); }
-            size_t tb2 = BL.temp_bytes;
-            { ProfileScope ps(ST_TILE_SORT, stream);
-              GS_CHECK(rocprim::radix_sort_pairs(bin + BL.temp, tb2, keys_u, keys_s, vals_u, point_list, (size_t)num_rendered, 0, bits, stream)); }
-            { ProfileScope ps(ST_RANGES, stream);
-              hipLaunchKernelGGL(tile_ranges_kernel, dim3((num_rendered + 255) / 256), dim3(256), 0, stream, num_rendered, keys_s, point_list, ranges,
-                                 (uint32_t*)(bin + BL.entry_pos)); }
-        }
     } else {
         GS_CHECK(hipStreamSynchronize(stream));
-        char* bin = binning_alloc(binning_user, bin_layout(0, 0).total);
-        if (!bin) { g_last_error = "binning resize callback returned NULL"; return -3; }
-        point_list = (uint32_t*)bin;
-        entry_gauss = (uint32_t*)bin;
+    }
+
+    const BinLayout BL = bin_layout((size_t)num_rendered, (size_t)T);
+    char* bin = binning_alloc(binning_user, BL.total);
+    if (!bin) { g_last_error = "binning resize callback returned NULL"; return -3; }
+    uint32_t* point_list = (uint32_t*)(bin + BL.point_list);
+    uint32_t* entry_gauss = (uint32_t*)(bin + BL.entry_gauss);
+
+    int nb = (num_rendered + 4095) / 4096;            // split blocks: >= 4096 slots each, at most SPLIT_BLOCKS_MAX
+    if (nb < 1) nb = 1;
+    if (nb > SPLIT_BLOCKS_MAX) nb = SPLIT_BLOCKS_MAX;
+    const int chunk = (num_rendered + nb - 1) / nb;
+    const size_t lds_bytes = (size_t)T * 4;
+    if (lds_bytes > 160 * 1024) { g_last_error = "image has too many tiles for the LDS tile histogram (> 40 960)"; return -2; }
+    uint32_t* emit_tile = (uint32_t*)(bin + BL.emit_tile);
+    uint32_t* emit_depth = (uint32_t*)(bin + BL.emit_depth);
+    uint32_t* entry_bits = (uint32_t*)(bin + BL.entry_bits);
+    uint32_t* block_hist = (uint32_t*)(bin + BL.block_hist);
+    if (num_rendered > 0) {
+        ProfileScope ps(ST_DUPLICATE, stream);
+        hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, tiles_touched, slot_base, rec, radii, gx, gy,
+                           tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits);
+        hipLaunchKernelGGL(split_hist_kernel, dim3(nb), dim3(1024), lds_bytes, stream, num_rendered, T, chunk, emit_tile, block_hist);
+        hipLaunchKernelGGL(split_colscan_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, nb, block_hist, tile_count);
+    }
+    {
+        ProfileScope ps(ST_RANGES, stream);
+        hipLaunchKernelGGL(tile_scan_lpt_kernel, dim3(1), dim3(1024), 0, stream, T, tile_mod, tile_rem, tile_count, ranges, order);
+    }
+    if (num_rendered > 0) {
+        {
+            ProfileScope ps(ST_DUPLICATE, stream);
+            hipLaunchKernelGGL(split_scatter_kernel, dim3(nb), dim3(1024), lds_bytes, stream, num_rendered, T, chunk, emit_tile, emit_depth,
+                               entry_bits, block_hist, ranges, (uint32_t*)(bin + BL.scatter_keys), (uint32_t*)(bin + BL.scatter_vals));
+        }
+        const int n_local = (T - tile_rem + tile_mod - 1) / tile_mod;
+        {
+            ProfileScope ps(ST_TILE_SORT, stream);
+            // two size classes over the same (LPT-ordered) tile list; each kernel skips the other class's tiles
+            hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP, 256, SORT_SMALL>), dim3(n_local), dim3(256), 0, stream, order, ranges,
+                               (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
+                               (uint32_t*)(bin + BL.tile_keys));
+            hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 128, 0>), dim3(n_local), dim3(128), 0, stream, order, ranges,
+                               (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
+                               (uint32_t*)(bin + BL.tile_keys));
+        }
     }
 
     BlendArgs ba;
@@ -630,21 +731,9 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     ba.W = width; ba.H = height; ba.gx = gx; ba.tile_mod = tile_mod; ba.tile_rem = tile_rem;
     ba.n_tiles_local = (T - tile_rem + tile_mod - 1) / tile_mod;
     ba.ranges = ranges; ba.point_list = point_list; ba.rec = rec; ba.entry_gauss = entry_gauss;
-    uint32_t* order = (uint32_t*)(img + IL.order);
-    if (ba.n_tiles_local > 0) {
-        ProfileScope ps(ST_RANGES, stream);
-        uint32_t* ok = (uint32_t*)(img + IL.order_tmp_keys);
-        uint32_t* ov = (uint32_t*)(img + IL.order_tmp_vals);
-        hipLaunchKernelGGL(tile_order_keys_kernel, dim3((ba.n_tiles_local + 255) / 256), dim3(256), 0, stream, ba.n_tiles_local, tile_mod,
-                           tile_rem, ranges, ok, ov);
-        size_t tb3 = IL.sort_temp_bytes;
-        GS_CHECK(rocprim::radix_sort_pairs(img + IL.sort_temp, tb3, ok, (uint32_t*)(img + IL.order_keys), ov, order,
-                                           (size_t)ba.n_tiles_local, 0, 32, stream));
-    }
     ba.order = order;
     ba.bg = background;
     ba.out_color = out_color; ba.out_depth = out_depth; ba.final_T = final_T; ba.n_contrib = n_contrib; ba.is_used = is_used;
-    (void)HW;
     if (ba.n_tiles_local > 0) {
         ProfileScope ps(ST_BLEND_FWD, stream);
         hipLaunchKernelGGL(blend_forward_strip_kernel, dim3(ba.n_tiles_local * 4), dim3(64), 0, stream, ba);
@@ -654,9 +743,8 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
 }
 
 size_t gsicp_raster_backward_scratch_bytes(int num_rendered, int width, int height) {
-    const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    (void)width; (void)height;
     const size_t R = num_rendered > 0 ? (size_t)num_rendered : 1;
-    (void)T;
     return align_up(R * 4 * SLOT_F * sizeof(float)) + align_up(R * SLOT_F * sizeof(float));
 }
 
@@ -674,8 +762,8 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     if (tile_mod < 1 || tile_rem < 0 || tile_rem >= tile_mod) { g_last_error = "bad tile_mod / tile_rem"; return -2; }
     if (!scratch) { g_last_error = "gsicp_raster_backward: scratch buffer is NULL (size it with gsicp_raster_backward_scratch_bytes)"; return -2; }
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE, T = gx * gy;
-    const GeomLayout GL = geom_layout(P, 0);
-    const BinLayout BL = bin_layout((size_t)num_rendered, 0);
+    const GeomLayout GL = geom_layout(P);
+    const BinLayout BL = bin_layout((size_t)num_rendered, (size_t)T);
     const ImgLayout IL = img_layout(width, height);
     float* slots = (float*)scratch;
     float* entry_sum = (float*)(scratch + align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * 4 * SLOT_F * sizeof(float)));
@@ -699,24 +787,9 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
         hipLaunchKernelGGL(blend_backward_strip_kernel, dim3(ba.n_tiles_local * 4), dim3(64), 0, stream, ba);
     }
     if (num_rendered > 0) {
-        ProfileScope ps(ST_MEMSET, stream);   // stage name kept for the profile table: "entry gradient sum"
+        ProfileScope ps(ST_ENTRY_SUM, stream);
         hipLaunchKernelGGL(entry_sum_kernel, dim3((num_rendered + 255) / 256), dim3(256), 0, stream, num_rendered,
-                           (const uint32_t*)(binning_buffer + BL.point_list_unsorted), slots, entry_sum);
-    }
-    {
-        ProfileScope ps(ST_MEMSET, stream);
-        const uint32_t* offsets = (const uint32_t*)(geom_buffer + GL.offsets);
-        if (num_rendered > 0) {
-            hipLaunchKernelGGL(gaussian_grad_gather_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P,
-                               (const uint32_t*)(geom_buffer + GL.ids_sorted), offsets, entry_sum, dL_dmeans2D, dL_dconic, dL_dopacity,
-                               dL_dcolors, dL_ddepths);
-        } else {
-            GS_CHECK(hipMemsetAsync(dL_dmeans2D, 0, (size_t)P * 12, stream));
-            GS_CHECK(hipMemsetAsync(dL_dconic, 0, (size_t)P * 16, stream));
-            GS_CHECK(hipMemsetAsync(dL_dopacity, 0, (size_t)P * 4, stream));
-            GS_CHECK(hipMemsetAsync(dL_dcolors, 0, (size_t)P * 12, stream));
-            GS_CHECK(hipMemsetAsync(dL_ddepths, 0, (size_t)P * 4, stream));
-        }
+                           (const uint32_t*)(binning_buffer + BL.entry_bits), slots, entry_sum);
     }
 
     PreprocessBwdArgs pb;
@@ -725,6 +798,9 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     pb.cov3D_precomp = cov3D_precomp; pb.scale_modifier = scale_modifier; pb.view = viewmatrix; pb.proj = projmatrix;
     pb.campos = cam_pos; pb.tanfovx = tan_fovx; pb.tanfovy = tan_fovy; pb.radii = radii;
     pb.clamped = (const unsigned char*)(geom_buffer + GL.clamped);
+    pb.entry_sum = entry_sum;
+    pb.slot_base = (const uint32_t*)(geom_buffer + GL.slot_base);
+    pb.tiles_touched = (const uint32_t*)(geom_buffer + GL.tiles_touched);
     pb.dL_dmean2D = dL_dmeans2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
     pb.dL_ddepths = dL_ddepths;
     pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = dL_dsh; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;

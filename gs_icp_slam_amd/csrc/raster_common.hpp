@@ -27,52 +27,40 @@ constexpr int SLOT_F = 12;   // floats per (entry, strip) gradient slot: NGRAD +
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-// Section offsets inside the three torch-owned scratch buffers.  Sections needed by backward come first.
-struct GeomLayout {
-    size_t records, clamped, offsets, ids_sorted, tiles_touched, depth_keys, depth_keys_sorted, ids, scalars, temp, total;
-    size_t temp_bytes;
-};
-struct BinLayout {
-    size_t point_list, tile_keys, entry_gauss, entry_pos, point_list_unsorted, tile_keys_unsorted, temp, total;
-    size_t temp_bytes;
-};
-struct ImgLayout {
-    size_t ranges, final_T, n_contrib, order, order_keys, order_tmp_keys, order_tmp_vals, sort_temp, total;
-    size_t sort_temp_bytes;
-};
+// Section offsets inside the three torch-owned scratch buffers.
+struct GeomLayout { size_t records, clamped, slot_base, tiles_touched, total; };
+struct BinLayout { size_t point_list, tile_keys, entry_gauss, entry_bits, emit_tile, emit_depth, scatter_keys, scatter_vals, block_hist, total; };
+constexpr int SPLIT_BLOCKS_MAX = 128;   // workgroups of the tile multi-split (each owns a contiguous chunk of emission slots)
+struct ImgLayout { size_t ranges, final_T, n_contrib, order, tile_count, total; };
 
-inline GeomLayout geom_layout(int P, size_t temp_bytes) {
+inline GeomLayout geom_layout(int P) {
     GeomLayout L;
     size_t o = 0;
     const size_t Pp = (size_t)(P > 0 ? P : 1);
     L.records = o; o = align_up(o + Pp * sizeof(SplatRec));
     L.clamped = o; o = align_up(o + Pp);
-    L.offsets = o; o = align_up(o + Pp * 4);          // inclusive scan of tiles_touched in depth-sorted order
-    L.ids_sorted = o; o = align_up(o + Pp * 4);       // Gaussian ids in depth order (needed again by backward)
-    L.tiles_touched = o; o = align_up(o + Pp * 4);
-    L.depth_keys = o; o = align_up(o + Pp * 4);
-    L.depth_keys_sorted = o; o = align_up(o + Pp * 4);
-    L.ids = o; o = align_up(o + Pp * 4);
-    L.scalars = o; o = align_up(o + 256);
-    L.temp = o; L.temp_bytes = temp_bytes; o = align_up(o + temp_bytes);
+    L.slot_base = o; o = align_up(o + Pp * 4);        // first emission slot of each Gaussian (its slots are contiguous)
+    L.tiles_touched = o; o = align_up(o + Pp * 4);    // number of emission slots (tiles of this rank it touches)
     L.total = o;
     return L;
 }
-inline BinLayout bin_layout(size_t R, size_t temp_bytes) {
+inline BinLayout bin_layout(size_t R, size_t T) {
     BinLayout L;
     size_t o = 0;
     const size_t Rp = R > 0 ? R : 1;
-    L.point_list = o; o = align_up(o + Rp * 4);
-    L.tile_keys = o; o = align_up(o + Rp * 4);
-    L.entry_gauss = o; o = align_up(o + Rp * 4);      // Gaussian id of emission slot u (emission order = depth order)
-    L.entry_pos = o; o = align_up(o + Rp * 4);        // entry_pos[u] = position of emission slot u in the tile-sorted list
-    L.point_list_unsorted = o; o = align_up(o + Rp * 4);
-    L.tile_keys_unsorted = o; o = align_up(o + Rp * 4);
-    L.temp = o; L.temp_bytes = temp_bytes; o = align_up(o + temp_bytes);
+    L.point_list = o; o = align_up(o + Rp * 4);       // per tile, depth-sorted: emission slot | strip bits << 28
+    L.tile_keys = o; o = align_up(o + Rp * 4);        // tile id of every list entry
+    L.entry_gauss = o; o = align_up(o + Rp * 4);      // emission slot -> Gaussian id
+    L.entry_bits = o; o = align_up(o + Rp * 4);       // emission slot -> strip bits
+    L.emit_tile = o; o = align_up(o + Rp * 4);        // forward-only: tile id of each emission slot
+    L.emit_depth = o; o = align_up(o + Rp * 4);       // forward-only: depth bits of each emission slot
+    L.scatter_keys = o; o = align_up(o + Rp * 4);     // forward-only: depth bits in scatter order
+    L.scatter_vals = o; o = align_up(o + Rp * 4);     // forward-only: list words in scatter order
+    L.block_hist = o; o = align_up(o + (size_t)SPLIT_BLOCKS_MAX * (T > 0 ? T : 1) * 4);   // forward-only: per-(split block, tile) counts
     L.total = o;
     return L;
 }
-inline ImgLayout img_layout(int W, int H, size_t sort_temp_bytes = 0) {
+inline ImgLayout img_layout(int W, int H) {
     ImgLayout L;
     const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const size_t HW = (size_t)W * H;
@@ -80,11 +68,8 @@ inline ImgLayout img_layout(int W, int H, size_t sort_temp_bytes = 0) {
     L.ranges = o; o = align_up(o + T * 8);
     L.final_T = o; o = align_up(o + HW * 4);
     L.n_contrib = o; o = align_up(o + HW * 4);
-    L.order = o; o = align_up(o + T * 4);            // tiles sorted by list length, longest first (LPT dispatch order)
-    L.order_keys = o; o = align_up(o + T * 4);
-    L.order_tmp_keys = o; o = align_up(o + T * 4);
-    L.order_tmp_vals = o; o = align_up(o + T * 4);
-    L.sort_temp = o; L.sort_temp_bytes = sort_temp_bytes; o = align_up(o + sort_temp_bytes);
+    L.order = o; o = align_up(o + T * 4);             // this rank's tiles, longest list first (LPT dispatch order)
+    L.tile_count = o; o = align_up(o + (2 * T + 64) * 4);   // forward-only: per-tile counts, cursors, 64 counters
     L.total = o;
     return L;
 }
@@ -99,8 +84,8 @@ struct PreprocessArgs {
     SplatRec* rec;
     unsigned char* clamped;
     uint32_t* tiles_touched;
-    uint32_t* depth_keys;
-    uint32_t* ids;
+    uint32_t* slot_base;
+    uint32_t* total_counter;   // [1] emission-slot allocator
     int* radii;
 };
 static_assert(sizeof(SplatRec) == 48, "SplatRec must stay 48 bytes");
@@ -113,13 +98,15 @@ struct PreprocessBwdArgs {
     float tanfovx, tanfovy;
     const int* radii;
     const unsigned char* clamped;
-    const float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolors, *dL_ddepths;   // (P,3) (P,4) (P) (P,3) (P)
+    const float* entry_sum;        // (R, SLOT_F) per-emission-slot gradient sums (strips already added)
+    const uint32_t *slot_base, *tiles_touched;
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolors, *dL_ddepths;   // (P,3) (P,4) (P) (P,3) (P): written here
     float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
 
 // ---- per-stage hipEvent profiler (implemented in raster.hip, shared with gicp.hip)
-enum Stage { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_DUPLICATE, ST_TILE_SORT, ST_RANGES, ST_BLEND_FWD, ST_BLEND_BWD,
-             ST_PREPROCESS_BWD, ST_MEMSET, ST_GICP_COV, ST_GICP_GRID, ST_GICP_ALIGN, ST_GICP_MISS, ST_COUNT };
+enum Stage { ST_PREPROCESS = 0, ST_RANGES, ST_DUPLICATE, ST_TILE_SORT, ST_BLEND_FWD, ST_BLEND_BWD, ST_ENTRY_SUM,
+             ST_PREPROCESS_BWD, ST_GICP_COV, ST_GICP_GRID, ST_GICP_ALIGN, ST_GICP_MISS, ST_COUNT };
 bool profile_on();
 void profile_begin(int stage, hipStream_t s);
 void profile_end(int stage, hipStream_t s);

@@ -138,7 +138,9 @@ __device__ inline void sh_to_rgb(int deg, const float* mean, const float* campos
 
 __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
+    const bool in_range = idx < a.P;
+    uint32_t mine = 0;    // emission slots this Gaussian needs (tiles of this rank it touches)
+    if (in_range) {
     Cam cam;
     load_cam(a.view, a.proj, cam);
     const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
@@ -146,9 +148,6 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
 
     // defaults for a culled Gaussian
     a.radii[idx] = 0;
-    a.tiles_touched[idx] = 0;
-    a.depth_keys[idx] = 0xFFFFFFFFu;
-    a.ids[idx] = (uint32_t)idx;
     a.clamped[idx] = 0;
     SplatRec rec = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -214,21 +213,44 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
                 } else {
                     rec.hx = -1e30f; rec.hy = -1e30f;
                 }
-                uint32_t mine = (uint32_t)ntiles;
-                if (a.tile_mod > 1) {  // multi-GPU tile sharding: count only this rank's tiles
+                mine = (uint32_t)ntiles;
+                if (a.tile_mod > 1) {  // multi-GPU tile sharding: only this rank's tiles get emission slots
                     mine = 0;
                     for (int y = y0; y < y1; ++y)
                         for (int x = x0; x < x1; ++x) mine += ((y * gx + x) % a.tile_mod) == a.tile_rem;
                 }
                 a.radii[idx] = rad;
-                a.tiles_touched[idx] = mine;
-                a.depth_keys[idx] = __float_as_uint(pv[2]);
                 a.clamped[idx] = (unsigned char)cm;
             }
         }
     }
     if (!ok) rec = SplatRec{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     a.rec[idx] = rec;
+    }  // in_range
+    // Emission-slot allocation: each Gaussian gets a private contiguous run of `mine` slots.  The runs need no global
+    // order (only contiguity), so one block-aggregated atomic per workgroup replaces a device-wide prefix scan.
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = tot ? atomicAdd(a.total_counter, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+    if (in_range) {
+        a.tiles_touched[idx] = mine;
+        a.slot_base[idx] = s_base + wave_off + incl - mine;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -307,13 +329,25 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     const bool visible = a.radii[i] > 0;
     const bool use_sh = (a.colors_precomp == nullptr) && (a.dL_dsh != nullptr);
-    // screen-space gradient sums of this Gaussian (written in depth-rank order by gaussian_grad_gather_kernel)
+    // screen-space gradient sums of this Gaussian: its emission slots are one contiguous run of entry_sum
     float gs[NGRAD];
-    gs[0] = a.dL_dmean2D[3 * i]; gs[1] = a.dL_dmean2D[3 * i + 1];
-    gs[2] = a.dL_dconic[4 * i]; gs[3] = a.dL_dconic[4 * i + 1]; gs[4] = a.dL_dconic[4 * i + 2];
-    gs[5] = a.dL_dopacity[i];
-    gs[6] = a.dL_dcolors[3 * i]; gs[7] = a.dL_dcolors[3 * i + 1]; gs[8] = a.dL_dcolors[3 * i + 2];
-    gs[9] = a.dL_ddepths[i];
+#pragma unroll
+    for (int c = 0; c < NGRAD; ++c) gs[c] = 0.f;
+    {
+        const uint32_t n_slots = a.tiles_touched[i];
+        const float4* es = (const float4*)a.entry_sum + 3 * (size_t)a.slot_base[i];
+        for (uint32_t u = 0; u < n_slots; ++u) {
+            const float4 p0 = es[3 * u], p1 = es[3 * u + 1], p2 = es[3 * u + 2];
+            gs[0] += p0.x; gs[1] += p0.y; gs[2] += p0.z; gs[3] += p0.w;
+            gs[4] += p1.x; gs[5] += p1.y; gs[6] += p1.z; gs[7] += p1.w;
+            gs[8] += p2.x; gs[9] += p2.y;
+        }
+    }
+    a.dL_dmean2D[3 * i] = gs[0]; a.dL_dmean2D[3 * i + 1] = gs[1]; a.dL_dmean2D[3 * i + 2] = 0.f;
+    a.dL_dconic[4 * i] = gs[2]; a.dL_dconic[4 * i + 1] = gs[3]; a.dL_dconic[4 * i + 2] = gs[4]; a.dL_dconic[4 * i + 3] = 0.f;
+    a.dL_dopacity[i] = gs[5];
+    a.dL_dcolors[3 * i] = gs[6]; a.dL_dcolors[3 * i + 1] = gs[7]; a.dL_dcolors[3 * i + 2] = gs[8];
+    a.dL_ddepths[i] = gs[9];
     if (visible) {
         Cam cam;
         load_cam(a.view, a.proj, cam);
