@@ -252,13 +252,18 @@ __global__ __launch_bounds__(256) void knn_cov_kernel(int n, int k, int batch_st
     // monotone approach towards the query would make almost every candidate an insertion.  The final sorted list
     // does not depend on the visiting order (the order is a total one).
     const int nb = (n + 63) / 64;
-    for (int b = 0, pb = 0; b < nb; ++b, pb += batch_stride) {
-        if (pb >= nb) pb -= nb;
+    // software pipeline: the load of the next batch is in flight while this one is tested / inserted
+    float4 pnext = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < n) pnext = pts[lane];
+    for (int b = 0, pb = 0; b < nb; ++b) {
         const int j = pb * 64 + lane;
+        const float4 p = pnext;
+        pb += batch_stride;
+        if (pb >= nb) pb -= nb;
+        if (b + 1 < nb && pb * 64 + lane < n) pnext = pts[pb * 64 + lane];
         float d = FLT_MAX;
         int id = 0x7fffffff;
         if (j < n) {
-            const float4 p = pts[j];
             d = dist2(Q.x, Q.y, Q.z, p.x, p.y, p.z);
             id = j;
         }
@@ -788,6 +793,7 @@ __global__ __launch_bounds__(256) void brute_nn_kernel(const int* __restrict__ m
     const float qz = ((Rf[6] * p.x + Rf[7] * p.y) + Rf[8] * p.z) + tf[2];
     float bd = FLT_MAX;
     int bi = 0x7fffffff;
+#pragma unroll 4
     for (int j = lane; j < n_tgt; j += 64) {
         const float4 t = sorted[j];
         const float d = dist2(qx, qy, qz, t.x, t.y, t.z);

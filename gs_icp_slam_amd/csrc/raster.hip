@@ -194,7 +194,15 @@ __global__ __launch_bounds__(256) void split_colscan_kernel(int T, int nb, uint3
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
     uint32_t run = 0;
-    for (int b = 0; b < nb; ++b) {
+    int b = 0;
+    for (; b + 8 <= nb; b += 8) {   // eight independent (coalesced across threads) loads in flight per step
+        uint32_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = block_hist[(size_t)(b + k) * T + t];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { block_hist[(size_t)(b + k) * T + t] = run; run += c[k]; }
+    }
+    for (; b < nb; ++b) {
         const uint32_t c = block_hist[(size_t)b * T + t];
         block_hist[(size_t)b * T + t] = run;
         run += c;
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(1024) void split_scatter_kernel(int R, int T, int c
 // Lists up to SORT_CAP entries are bitonic-sorted in LDS; longer ones fall back to an O(n^2) rank sort in global memory
 // (correct, slow, and not reached by the scenes in BASELINE.json: their longest lists are a few hundred entries).
 constexpr int SORT_CAP = 4096;     // large-list kernel: 256 threads, 48 KB LDS
-constexpr int SORT_SMALL = 512;    // small-list kernel: 128 threads, 6 KB LDS -> many workgroups per CU
+constexpr int SORT_SMALL = 512;    // small-list kernel: 128 threads, 6 KB LDS -> many workgroups per CU (a one-wave variant measured slower)
 template <int CAP, int THREADS, int MIN_N>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __restrict__ order, const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ sc_keys, const uint32_t* __restrict__ sc_vals,
@@ -264,7 +272,8 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __re
             s_val[i] = 0;
         }
     }
-    __syncthreads();
+    // a single wave needs no s_barrier: its LDS operations execute in program order
+    if (THREADS == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     for (int k = 2; k <= npad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < npad; i += THREADS) {
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __re
                     }
                 }
             }
-            __syncthreads();
+            if (THREADS == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
         }
     }
     for (int i = tid; i < n; i += THREADS) {
