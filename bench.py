@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--res", choices=["replica", "tum"], default="replica")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--serial", action="store_true", help="run tracker and mapper back-to-back on one thread (default: concurrently, as the\n                    reference runs them in two processes)")
     ap.add_argument("--pyprofile", default=None, help="write a cProfile of the timed region to this file (diagnostics)")
     args = ap.parse_args()
 
@@ -103,8 +104,24 @@ def main():
 
     last = {}
 
-    def step():
-        T, idx, d2 = tracker_step(reg)
+    # The reference runs the tracker and the mapper as two concurrent processes on one GPU [REF gs_icp_slam.py:121-131].
+    # Here: the tracker frame runs on a worker thread (its C calls release the GIL and use the tracker's own HIP stream)
+    # while the main thread drives the mapper iteration on torch's stream; a step ends when both are done.
+    import queue
+    import threading
+    jobs, done = queue.Queue(), queue.Queue()
+
+    def tracker_worker():
+        while True:
+            if jobs.get() is None:
+                return
+            done.put(tracker_step(reg))
+    worker = None
+    if not args.serial:
+        worker = threading.Thread(target=tracker_worker, daemon=True)
+        worker.start()
+
+    def mapper_iteration():
         means2D = torch.zeros_like(params["means3D"], requires_grad=True)
         depth, color, radii, used = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
                                          scales=params["scales"], rotations=params["rotations"])
@@ -112,6 +129,16 @@ def main():
         loss.backward()
         for p in params.values():
             p.grad = None
+        return loss, radii
+
+    def step():
+        if worker is not None:
+            jobs.put(1)
+            loss, radii = mapper_iteration()
+            T, idx, d2 = done.get()
+        else:
+            T, idx, d2 = tracker_step(reg)
+            loss, radii = mapper_iteration()
         last.update(T=T, loss=loss, radii=radii)
 
     def barrier():
@@ -224,6 +251,7 @@ def main():
             "config": {"workload": f"BASELINE configs[2] shape: S-pair {args.res} tracker ({len(sp['points_b'])} pts, gate {cfg['max_corr']} m) + "
                                    f"S-map mapper iteration (P={P}, {W}x{H}, sh_degree 0)", "gaussians": P, "width": W, "height": H,
                        "duplicates_per_rank": D_local, "visible_gaussians": P_vis,
+                       "tracker_mapper_overlap": not args.serial,
                        "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-reduce image + grads), tracker replicated"},
             "render_bwd_ms_per_iter": round(sum(per_launch_us.get(k, 0.0) for k in raster_stages) / 1e3, 4),
             "tracker_align_kernel_us": stage_us.get("gicp_align"),
@@ -231,6 +259,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    if worker is not None:
+        jobs.put(None)
     if world > 1:
         dist.destroy_process_group()
 

@@ -701,6 +701,13 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     const int chunk = (num_rendered + nb - 1) / nb;
     const size_t lds_bytes = (size_t)T * 4;
     if (lds_bytes > 160 * 1024) { g_last_error = "image has too many tiles for the LDS tile histogram (> 40 960)"; return -2; }
+    if (lds_bytes > 48 * 1024) {   // gfx950 has 160 KiB of LDS per CU, but more than the default dynamic quota must be requested
+        static std::atomic<int> raised{0};
+        if (!raised.exchange(1)) {
+            GS_CHECK(hipFuncSetAttribute((const void*)split_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GS_CHECK(hipFuncSetAttribute((const void*)split_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+    }
     uint32_t* emit_tile = (uint32_t*)(bin + BL.emit_tile);
     uint32_t* emit_depth = (uint32_t*)(bin + BL.emit_depth);
     uint32_t* entry_bits = (uint32_t*)(bin + BL.entry_bits);

@@ -42,7 +42,7 @@ def run_product(g, cam, bg, sh_degree=0, grads=None, tile_mod=1, tile_rem=0):
     return out
 
 
-def check_forward(g, cam, bg, sh_degree, hip_lib, label):
+def check_forward(g, cam, bg, sh_degree, hip_lib, label, tol=TOL, max_fragile=2e-4):
     o = util.oracle_forward(g, cam, bg, sh_degree)
     p = run_product(g, cam, bg, sh_degree)
     P = g["means3D"].shape[0]
@@ -62,13 +62,13 @@ def check_forward(g, cam, bg, sh_degree, hip_lib, label):
     # ---- images
     ok = o["margin"] > FRAGILE
     frac_fragile = 1.0 - ok.mean()
-    assert frac_fragile < 2e-4, f"{label}: {frac_fragile:.2e} fragile pixels"
+    assert frac_fragile < max_fragile, f"{label}: {frac_fragile:.2e} fragile pixels"
     dc = np.abs(p["color"] - o["color"]).max(0)
     dd = np.abs(p["depth"] - o["depth"])
-    assert dc[ok].max() <= TOL, f"{label}: colour err {dc[ok].max():.3e}"
-    assert (dd[ok] / np.maximum(1.0, np.abs(o["depth"][ok]))).max() <= TOL, f"{label}: depth err {dd[ok].max():.3e}"
+    assert dc[ok].max() <= tol, f"{label}: colour err {dc[ok].max():.3e}"
+    assert (dd[ok] / np.maximum(1.0, np.abs(o["depth"][ok]))).max() <= tol, f"{label}: depth err {dd[ok].max():.3e}"
     assert np.array_equal(s["n_contrib"][ok], o["n_contrib"][ok]), f"{label}: n_contrib differs on robust pixels"
-    np.testing.assert_allclose(s["final_T"][ok], o["final_T"][ok], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(s["final_T"][ok], o["final_T"][ok], rtol=max(1e-4, 20 * tol), atol=1e-6)
     # is_used: robust subset relation (flips only through fragile pixels)
     diff = np.flatnonzero(p["is_used"] != o["is_used"])
     assert len(diff) <= max(2, int(1e-4 * P)), f"{label}: is_used differs for {len(diff)} Gaussians"
@@ -202,3 +202,32 @@ def test_full_size_smap(hip_lib, res):
     assert np.all(np.diff(rec_depth)[same_tile] >= 0)                                   # front-to-back inside a tile
     assert int((s["ranges"][:, 1] - s["ranges"][:, 0]).sum()) == p["num_rendered"]      # ranges partition the list
     assert float(p["color"].min()) >= 0.0 and np.all(s["final_T"] <= 1.0)
+
+
+def test_long_tile_lists_use_the_fallback_sort(hip_lib):
+    """> 4096 entries in one tile: the per-tile sort leaves LDS and rank-sorts in global memory; lists must still be exact."""
+    cam = synth.make_camera(48, 32, 40.0, 40.0)
+    g = synth.random_gaussians(5000, seed=12, spread=0.2, zmin=2.0, zmax=6.0)
+    g["scales"] = (g["scales"] * 6.0).astype(np.float32)          # every Gaussian covers the whole 3x2-tile image
+    g["opacities"] = (g["opacities"] * 0.02).astype(np.float32)   # keep transmittance alive so lists are traversed deep
+    # thousands of threshold decisions per pixel: many more pixels sit near a threshold, so only the robust ones are compared
+    o, p, _ = check_forward(g, cam, [0, 0, 0], 0, hip_lib, "long lists", tol=5e-5, max_fragile=0.05)
+    assert (o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]).max() > 4096
+
+
+def test_many_tiles_uhd(hip_lib):
+    """3840x2160 = 32 400 tiles: the tile multi-split needs 127 KB of dynamic LDS per workgroup."""
+    cam = synth.make_camera(3840, 2160, 2800.0, 2800.0)
+    g = synth.random_gaussians(3000, seed=13, spread=1.5, zmin=2.0, zmax=6.0)
+    # Integer outputs stay bit-exact.  Colour tolerance is relaxed: with ~100 px splats the three terms of `power` reach 1e3 and
+    # cancel to O(1), so fp32 rounding (FMA-contracted on the GPU, plain mul/add in the oracle) shows up at ~1e-4 in alpha.
+    check_forward(g, cam, [0.1, 0.1, 0.1], 0, hip_lib, "uhd", tol=1e-3)
+
+
+def test_mark_visible():
+    import torch
+    from diff_gaussian_rasterization import GaussianRasterizer
+    cam = synth.make_camera(64, 48, 60.0, 60.0)
+    rs = util.make_settings(cam, [0, 0, 0])
+    pos = torch.tensor([[0, 0, 1.0], [0, 0, 0.1], [0, 0, -3.0], [5, 5, 0.21]], device="cuda")
+    assert GaussianRasterizer(rs).markVisible(pos).cpu().tolist() == [True, False, False, True]
