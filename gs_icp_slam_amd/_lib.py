@@ -34,6 +34,11 @@ SIGNATURES = {
     "gsicp_raster_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_raster_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "gsicp_knn_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
+    "gsicp_mapper_loss_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "gsicp_mapper_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    "gsicp_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int,
+                                c_void_p]),
     "gsicp_gicp_create": (c_void_p, []),
     "gsicp_gicp_destroy": (None, [c_void_p]),
     "gsicp_gicp_set_max_correspondence_distance": (c_int, [c_void_p, c_double]),

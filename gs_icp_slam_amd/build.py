@@ -17,6 +17,7 @@ SOURCES = [
     ("raster_preprocess.hip", ["-ffp-contract=off"]),
     ("raster.hip", []),
     ("knn.hip", []),
+    ("mapper_ops.hip", []),
     ("gicp.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",

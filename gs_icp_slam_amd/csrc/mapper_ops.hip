@@ -1,0 +1,297 @@
+// Mapper-side operators next to the rasteriser on the reference's per-iteration path:
+//   * the mapping loss  0.8 L1 + 0.2 (1 - SSIM) + 0.1 L1(depth / 10)  [REF mp_Mapper.py:225-240] with the reference's
+//     masked L1 and 11x11 Gaussian-window SSIM [REF utils/loss_utils.py:17-20, 27-69], forward AND gradient, in two
+//     launches instead of the ~60 torch launches (5 depth-wise conv2d + ~25 element-wise ops, and their backward);
+//   * one multi-tensor Adam step over the six parameter groups of GaussianModel
+//     [REF scene/gaussian_model.py:222-231; mp_Mapper.py:247] in ONE launch.
+//
+// Loss kernels: one 256-thread workgroup per 16x16 tile and channel.  The 26x26 halo tile goes through LDS once; the
+// reference's exact 11x11 float32 window (121 taps; a separable evaluation is measurably NOT equivalent, see pass 1) is
+// applied to five moment maps (x, y, xx, yy, xy) in pass 1 and to the three derivative maps in pass 2.  Everything is HBM-streaming: pass 1 reads 2 and writes 3 floats per
+// pixel-channel, pass 2 reads 5 and writes 1.  Sums are reduced per workgroup and finished by a tiny second kernel in
+// a fixed order (no float atomics: results are bit-reproducible).
+#include <cmath>
+#include <string>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/gsicp_hip.h"
+#include "raster_common.hpp"
+
+namespace gsicp {
+extern thread_local std::string g_last_error;
+
+namespace {
+
+constexpr int LT = 16;            // output tile
+constexpr int HALO = 5;           // 11x11 window
+constexpr int LW = LT + 2 * HALO; // 26
+
+struct Win { float w[121]; };   // the reference's 2-D window: float32 outer product of the normalised 11-tap Gaussian
+
+__device__ inline float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Pass 1.  grid = (tiles_x, tiles_y, 4): z = 0..2 colour channels, z = 3 the depth L1 term (no SSIM).
+// partial[(z * n_tiles + tile) * 2 + {0,1}] = {sum of masked |diff|, sum of SSIM map} of this workgroup.
+__global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict__ image, const float* __restrict__ depth,
+                                                         const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
+                                                         Win win, float d_max, float dS_scale /* = -lambda / (3HW) */,
+                                                         float* __restrict__ abc /* (3, 3, H, W): A, B, C per channel */,
+                                                         float* __restrict__ partial) {
+    __shared__ float s_x[LW][LW + 1], s_y[LW][LW + 1];
+    __shared__ float s_red[4][2];
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
+    const size_t HW = (size_t)W * H;
+    const int n_tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float l1 = 0.f, ssum = 0.f;
+    if (ch == 3) {   // depth term: L1(depth / d_max, gt_depth / d_max), masked where gt == 0
+        const int px = x0 + lx, py = y0 + ly;
+        if (px < W && py < H) {
+            const float g = gt_depth[(size_t)py * W + px] / d_max;
+            const float d = depth[(size_t)py * W + px] / d_max;
+            if (g != 0.f) l1 = fabsf(d - g);
+        }
+    } else {
+        // stage the halo tile: y = gt * (gt_depth > 0), x = where(y != 0, image, 0); zero outside the image
+        for (int i = tid; i < LW * LW; i += 256) {
+            const int r = i / LW, c = i % LW;
+            const int px = x0 + c - HALO, py = y0 + r - HALO;
+            float xv = 0.f, yv = 0.f;
+            if (px >= 0 && px < W && py >= 0 && py < H) {
+                const size_t pix = (size_t)py * W + px;
+                yv = gt_depth[pix] > 0.f ? gt_image[ch * HW + pix] : 0.f;
+                xv = yv != 0.f ? image[ch * HW + pix] : 0.f;
+            }
+            s_x[r][c] = xv; s_y[r][c] = yv;
+        }
+        __syncthreads();
+        const int px = x0 + lx, py = y0 + ly;
+        if (px < W && py < H) {
+            // 121 taps with the reference's own float32 2-D window.  (A separable 11+11 evaluation is NOT equivalent here: the
+            // rounded outer product sums to 1 - 7e-8 instead of (sum w)^2 = 1 + 9e-8, and SSIM's sigma = E[xx] - mu^2 turns that
+            // 1.6e-7 normalisation difference into a 1e-5 shift of the SSIM mean.)
+            float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 11; ++i)
+#pragma unroll
+                for (int j = 0; j < 11; ++j) {
+                    const float w = win.w[i * 11 + j];
+                    const float xv = s_x[ly + i][lx + j], yv = s_y[ly + i][lx + j];
+                    mu1 += w * xv; mu2 += w * yv; e11 += w * (xv * xv); e22 += w * (yv * yv); e12 += w * (xv * yv);
+                }
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float a = 2.f * mu12 + C1, b = 2.f * (e12 - mu12) + C2;
+            const float c = mu1_sq + mu2_sq + C1, d = (e11 - mu1_sq) + (e22 - mu2_sq) + C2;
+            const float inv_cd = 1.f / (c * d);
+            const float S = a * b * inv_cd;
+            ssum = S;
+            // dS/d(mu1), dS/d(E[xx]), dS/d(E[xy]) with mu2, E[yy] fixed (the target image carries no gradient)
+            const float dS_dmu1 = 2.f * mu2 * (b - a) * inv_cd - 2.f * mu1 * S * (d - c) * inv_cd;
+            const float dS_de11 = -S / d;
+            const float dS_de12 = 2.f * a * inv_cd;
+            const size_t pix = (size_t)py * W + px;
+            abc[(ch * 3 + 0) * HW + pix] = dS_scale * dS_dmu1;
+            abc[(ch * 3 + 1) * HW + pix] = dS_scale * dS_de11;
+            abc[(ch * 3 + 2) * HW + pix] = dS_scale * dS_de12;
+            const float xv = s_x[ly + HALO][lx + HALO], yv = s_y[ly + HALO][lx + HALO];
+            if (yv != 0.f) l1 = fabsf(xv - yv);
+        }
+    }
+    l1 = wave_sum_f(l1); ssum = wave_sum_f(ssum);
+    if ((tid & 63) == 0) { s_red[tid >> 6][0] = l1; s_red[tid >> 6][1] = ssum; }
+    __syncthreads();
+    if (tid == 0) {
+        partial[((size_t)ch * n_tiles + tile) * 2 + 0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+        partial[((size_t)ch * n_tiles + tile) * 2 + 1] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+    }
+}
+
+// Finish the sums in a fixed order and form the loss.  out = {loss, L1, SSIM mean, depth L1}.
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partial, int n_tiles, float inv_n_img, float inv_n_depth,
+                                                          float lambda_dssim, float depth_weight, float* __restrict__ out) {
+    __shared__ double s_acc[3][256];
+    const int tid = threadIdx.x;
+    double l1 = 0, ss = 0, ld = 0;
+    for (int i = tid; i < 3 * n_tiles; i += 256) { l1 += partial[(size_t)i * 2]; ss += partial[(size_t)i * 2 + 1]; }
+    for (int i = tid; i < n_tiles; i += 256) ld += partial[((size_t)3 * n_tiles + i) * 2];
+    s_acc[0][tid] = l1; s_acc[1][tid] = ss; s_acc[2][tid] = ld;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { s_acc[0][tid] += s_acc[0][tid + s]; s_acc[1][tid] += s_acc[1][tid + s]; s_acc[2][tid] += s_acc[2][tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float L1 = (float)(s_acc[0][0] * inv_n_img), SS = (float)(s_acc[1][0] * inv_n_img), LD = (float)(s_acc[2][0] * inv_n_depth);
+        out[0] = (1.f - lambda_dssim) * L1 + lambda_dssim * (1.f - SS) + depth_weight * LD;
+        out[1] = L1; out[2] = SS; out[3] = LD;
+    }
+}
+
+// Pass 2.  dL/dx(p) = sum_q w(q - p) [A_q + 2 x_p B_q + y_p C_q]  (+ the L1 sign term), masked where y == 0.
+__global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict__ image, const float* __restrict__ depth,
+                                                         const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
+                                                         Win win, float d_max, float l1_scale /* (1 - lambda) / (3HW) */,
+                                                         float depth_scale /* w_d / (HW d_max) */, const float* __restrict__ abc,
+                                                         float* __restrict__ dL_dimage, float* __restrict__ dL_ddepth) {
+    __shared__ float s_in[3][LW][LW + 1];
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
+    const size_t HW = (size_t)W * H;
+    const int px = x0 + lx, py = y0 + ly;
+    if (ch == 3) {
+        if (px < W && py < H) {
+            const size_t pix = (size_t)py * W + px;
+            const float g = gt_depth[pix] / d_max, d = depth[pix] / d_max;
+            float gr = 0.f;
+            if (g != 0.f) gr = d > g ? depth_scale : (d < g ? -depth_scale : 0.f);
+            dL_ddepth[pix] = gr;
+        }
+        return;
+    }
+    for (int i = tid; i < LW * LW; i += 256) {
+        const int r = i / LW, c = i % LW;
+        const int qx = x0 + c - HALO, qy = y0 + r - HALO;
+        float a = 0.f, b = 0.f, cc = 0.f;
+        if (qx >= 0 && qx < W && qy >= 0 && qy < H) {
+            const size_t q = (size_t)qy * W + qx;
+            a = abc[(ch * 3 + 0) * HW + q]; b = abc[(ch * 3 + 1) * HW + q]; cc = abc[(ch * 3 + 2) * HW + q];
+        }
+        s_in[0][r][c] = a; s_in[1][r][c] = b; s_in[2][r][c] = cc;
+    }
+    __syncthreads();
+    if (px < W && py < H) {
+        float cA = 0.f, cB = 0.f, cC = 0.f;
+#pragma unroll
+        for (int i = 0; i < 11; ++i)
+#pragma unroll
+            for (int j = 0; j < 11; ++j) {
+                const float w = win.w[i * 11 + j];   // symmetric window: correlation == convolution
+                cA += w * s_in[0][ly + i][lx + j]; cB += w * s_in[1][ly + i][lx + j]; cC += w * s_in[2][ly + i][lx + j];
+            }
+        const size_t pix = (size_t)py * W + px;
+        const float yv = gt_depth[pix] > 0.f ? gt_image[ch * HW + pix] : 0.f;
+        float gr = 0.f;
+        if (yv != 0.f) {
+            const float xv = image[ch * HW + pix];
+            gr = cA + 2.f * xv * cB + yv * cC;
+            gr += xv > yv ? l1_scale : (xv < yv ? -l1_scale : 0.f);
+        }
+        dL_dimage[ch * HW + pix] = gr;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+constexpr int ADAM_MAX_GROUPS = 8;
+struct AdamTable {
+    float* p[ADAM_MAX_GROUPS];
+    const float* g[ADAM_MAX_GROUPS];
+    float* m[ADAM_MAX_GROUPS];
+    float* v[ADAM_MAX_GROUPS];
+    long long end[ADAM_MAX_GROUPS];    // exclusive prefix end of each group in the flattened index space
+    float step_size[ADAM_MAX_GROUPS];  // lr / (1 - beta1^t)
+    int n;
+};
+
+// torch.optim.Adam (amsgrad off, weight decay 0, maximize off):  m += (1-b1)(g-m);  v = b2 v + (1-b2) g g;
+// p -= step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float beta1, float beta2, float eps, float inv_bc2_sqrt, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int gidx = 0;
+        long long base = 0;
+#pragma unroll
+        for (int k = 0; k < ADAM_MAX_GROUPS - 1; ++k)
+            if (k < t.n - 1 && i >= t.end[k]) { gidx = k + 1; base = t.end[k]; }
+        const long long j = i - base;
+        const float g = t.g[gidx][j];
+        float m = t.m[gidx][j], v = t.v[gidx][j];
+        m = m + (1.f - beta1) * (g - m);
+        v = beta2 * v + (1.f - beta2) * g * g;
+        t.m[gidx][j] = m; t.v[gidx][j] = v;
+        const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+        t.p[gidx][j] = t.p[gidx][j] - t.step_size[gidx] * (m / denom);
+    }
+}
+
+}  // namespace
+}  // namespace gsicp
+
+using namespace gsicp;
+
+extern "C" {
+
+size_t gsicp_mapper_loss_scratch_bytes(int width, int height) {
+    const size_t HW = (size_t)width * height;
+    const size_t tiles = (size_t)((width + LT - 1) / LT) * ((height + LT - 1) / LT);
+    return align_up(9 * HW * sizeof(float)) + align_up(4 * tiles * 2 * sizeof(float));
+}
+
+int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
+                      float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
+                      char* scratch, void* stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (width <= 0 || height <= 0 || !image || !depth || !gt_image || !gt_depth || !loss_out || !scratch) {
+        g_last_error = "gsicp_mapper_loss: bad arguments"; return -2;
+    }
+    Win win;
+    {   // the reference's window [REF utils/loss_utils.py:27-35]: g = exp(-(x-5)^2 / (2*1.5^2)) as float32, g / g.sum(),
+        // then the float32 outer product g g^T (torch.mm of an (11,1) by a (1,11) tensor = one rounded multiply per entry)
+        float g1[11];
+        double sum_d = 0.0;
+        for (int i = 0; i < 11; ++i) g1[i] = (float)std::exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5));
+        // torch's float32 .sum() of these 11 values equals the correctly rounded exact sum (a plain sequential float32 sum is one
+        // ulp lower, and that 6e-8 is visible in SSIM); tests/test_oracle_loss.py checks the construction bit-for-bit
+        for (int i = 0; i < 11; ++i) sum_d += (double)g1[i];
+        const float sum = (float)sum_d;
+        for (int i = 0; i < 11; ++i) g1[i] = g1[i] / sum;
+        for (int i = 0; i < 11; ++i)
+            for (int j = 0; j < 11; ++j) win.w[i * 11 + j] = g1[i] * g1[j];
+    }
+    const size_t HW = (size_t)width * height;
+    const dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, 4);
+    const int n_tiles = grid.x * grid.y;
+    float* abc = (float*)scratch;
+    float* partial = (float*)(scratch + align_up(9 * HW * sizeof(float)));
+    const float n_img = 3.f * (float)HW;
+    hipLaunchKernelGGL(loss_pass1_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
+                       -lambda_dssim / n_img, abc, partial);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim,
+                       depth_weight, loss_out);
+    if (dL_dimage && dL_ddepth)
+        hipLaunchKernelGGL(loss_pass2_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
+                           (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss: kernel launch failed"; return -1; }
+    return 0;
+}
+
+int gsicp_adam_step(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const long long* numel, const float* lr, float beta1, float beta2, float eps, int step, void* stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || step < 1) { g_last_error = "gsicp_adam_step: 1..8 tensors, step >= 1"; return -2; }
+    AdamTable t;
+    long long total = 0;
+    const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+    t.n = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        if (numel[k] <= 0) continue;
+        t.p[t.n] = params[k]; t.g[t.n] = grads[k]; t.m[t.n] = exp_avg[k]; t.v[t.n] = exp_avg_sq[k];
+        total += numel[k];
+        t.end[t.n] = total;
+        t.step_size[t.n] = (float)((double)lr[k] / bc1);
+        ++t.n;
+    }
+    for (int k = t.n; k < ADAM_MAX_GROUPS; ++k) { t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.end[k] = total; t.step_size[k] = 0.f; }
+    if (total == 0) return 0;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, beta1, beta2, eps, (float)(1.0 / std::sqrt(bc2)), total);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step: kernel launch failed"; return -1; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+"""Fused mapping loss: what mp_Mapper.py computes with `l1_loss`, `ssim` and a depth `l1_loss`
+[REF mp_Mapper.py:225-240; utils/loss_utils.py:17-69], forward and gradient, in three HIP launches.
+
+    loss = mapper_loss(image, depth_image, gt_image, gt_depth_image, lambda_dssim=0.2)   # replaces REF mp_Mapper.py:225-240
+    loss.backward()
+
+`gt_image` is the UNMASKED ground-truth image; the `gt_image * (gt_depth > 0)` masking of [REF mp_Mapper.py:225-228] is
+done inside.  Returns a 0-dim tensor; `mapper_loss.parts(...)` also returns (L1, SSIM mean, depth L1).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class _MapperLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, depth, gt_image, gt_depth, lambda_dssim, depth_weight, d_max):
+        lib = _lib.load()
+        if not image.is_cuda:
+            raise RuntimeError("mapper_loss (gfx950): tensors must live on the HIP device; there is no CPU path")
+        dev = image.device
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        image_c, depth_c, gt_c, gtd_c = f(image), f(depth), f(gt_image), f(gt_depth)
+        H, W = image_c.shape[-2], image_c.shape[-1]
+        if image_c.numel() != 3 * H * W or depth_c.numel() != H * W or gt_c.numel() != 3 * H * W or gtd_c.numel() != H * W:
+            raise RuntimeError("mapper_loss: expected image/gt_image (3,H,W) and depth/gt_depth (1,H,W)")
+        need_grad = image.requires_grad or depth.requires_grad
+        with torch.cuda.device(dev):
+            out = torch.empty(4, dtype=torch.float32, device=dev)
+            g_img = torch.empty_like(image_c) if need_grad else None
+            g_dep = torch.empty_like(depth_c) if need_grad else None
+            scratch = torch.empty(int(lib.gsicp_mapper_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.gsicp_mapper_loss(_p(image_c), _p(depth_c), _p(gt_c), _p(gtd_c), W, H, float(lambda_dssim), float(depth_weight),
+                                             float(d_max), _p(out), _p(g_img), _p(g_dep), _p(scratch), stream), "gsicp_mapper_loss")
+        ctx.save_for_backward(g_img, g_dep)
+        ctx.shapes = (image.shape, depth.shape)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_parts):
+        g_img, g_dep = ctx.saved_tensors
+        if g_img is None:
+            return (None,) * 7
+        return (g_img * g_loss).view(ctx.shapes[0]), (g_dep * g_loss).view(ctx.shapes[1]), None, None, None, None, None
+
+
+def mapper_loss(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_weight=0.1, d_max=10.0):
+    return _MapperLoss.apply(image, depth, gt_image, gt_depth, lambda_dssim, depth_weight, d_max)[0]
+
+
+def mapper_loss_parts(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_weight=0.1, d_max=10.0):
+    """-> (loss, tensor([loss, L1, SSIM mean, depth L1]))"""
+    return _MapperLoss.apply(image, depth, gt_image, gt_depth, lambda_dssim, depth_weight, d_max)

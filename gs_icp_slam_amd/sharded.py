@@ -66,18 +66,19 @@ class ShardedGaussianRasterizer(nn.Module):
     """Drop-in for GaussianRasterizer when torch.distributed is initialised: same call signature and return tuple.
     ``rasterizer_cls`` is injectable so that the CPU (gloo) tests can exercise the collective logic."""
 
-    def __init__(self, raster_settings, group=None, rasterizer_cls=None):
+    def __init__(self, raster_settings, group=None, rasterizer_cls=None, force_collectives=False):
         super().__init__()
         if rasterizer_cls is None:
             from .rasterizer import GaussianRasterizer as rasterizer_cls
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.group, self.world = group, world
+        self.force_collectives = bool(force_collectives) and dist.is_initialized()   # exercise the collective path at world size 1
         self.raster_settings = raster_settings._replace(tile_mod=world, tile_rem=rank)
         self.inner = rasterizer_cls(raster_settings=self.raster_settings)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return self.inner(means3D=means3D, means2D=means2D, opacities=opacities, shs=shs, colors_precomp=colors_precomp,
                               scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
         names = ["means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"]

@@ -155,6 +155,32 @@ int gsicp_gicp_num_target(gsicp_gicp*);
 int gsicp_gicp_last_align_stats(gsicp_gicp*, double out[6]);
 int gsicp_gicp_get_final_hessian(gsicp_gicp*, double out[36]);
 
+/* --------------------------------------------------------------------------------------------------------
+ * 4. Mapper-side operators next to the rasteriser.  Not extension modules in the reference:
+ *    they replace chains of torch ops in its Python, so adopting them means a three-line edit of mp_Mapper.py
+ *    (INTEGRATION.md §6).  All pointers DEVICE, contiguous f32; asynchronous on `stream`.
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* The mapping loss of [REF mp_Mapper.py:225-240] with the reference's masked L1 and 11x11 Gaussian-window SSIM
+ * [REF utils/loss_utils.py:17-20, 27-69]:
+ *     m   = gt_depth > 0;  y = gt_image * m;  x = where(y != 0, image, 0)
+ *     loss = (1 - lambda) * mean(where(y != 0, |image - y|, 0)) + lambda * (1 - mean(SSIM(x, y)))
+ *            + depth_weight * mean(where(gt_depth != 0, |depth - gt_depth| / d_max, 0))
+ * image/gt_image (3,H,W), depth/gt_depth (1,H,W).  loss_out[4] = {loss, L1, SSIM mean, depth L1}.
+ * dL_dimage (3,H,W) / dL_ddepth (1,H,W) receive d loss / d image, d depth (both may be NULL to skip the gradient pass).
+ * scratch: gsicp_mapper_loss_scratch_bytes() bytes, no initialisation needed. */
+size_t gsicp_mapper_loss_scratch_bytes(int width, int height);
+int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
+                      float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
+                      char* scratch, void* stream);
+
+/* One torch.optim.Adam step (amsgrad off, weight decay 0) over up to 8 tensors in one launch — the six parameter
+ * groups of GaussianModel [REF scene/gaussian_model.py:222-231], stepped at [REF mp_Mapper.py:247].  Arrays are HOST
+ * arrays of n_groups entries holding DEVICE pointers / element counts / learning rates; `step` is the 1-based step count
+ * after the increment (bias corrections 1 - beta^step). */
+int gsicp_adam_step(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const long long* numel, const float* lr, float beta1, float beta2, float eps, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

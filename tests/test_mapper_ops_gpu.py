@@ -1,0 +1,92 @@
+"""GPU parity for the §8f "next" operators: fused mapping loss (vs golden vectors produced by the REFERENCE'S OWN
+utils/loss_utils.py, and vs the pinned oracle at full size) and multi-tensor Adam (vs torch.optim.Adam, the reference's
+optimiser, on CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "mapper_loss.npz")
+
+
+def _run(c):
+    from gs_icp_slam_amd.loss import mapper_loss_parts
+    image = torch.tensor(c["image"], device="cuda", requires_grad=True)
+    depth = torch.tensor(c["depth"], device="cuda", requires_grad=True)
+    loss, parts = mapper_loss_parts(image, depth, torch.tensor(c["gt_image"], device="cuda"), torch.tensor(c["gt_depth"], device="cuda"))
+    loss.backward()
+    return loss.item(), parts.cpu().numpy(), image.grad.cpu().numpy(), depth.grad.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_loss_matches_reference_golden(name):
+    z = np.load(GOLD)
+    c = {k[2:]: z[k] for k in z.files if k.startswith(name + "_")}
+    loss, parts, gi, gd = _run(c)
+    assert abs(loss - c["loss"]) < 2e-6 and abs(parts[1] - c["l1"]) < 2e-6 and abs(parts[2] - c["ssim"]) < 5e-6 and abs(parts[3] - c["l1_d"]) < 1e-7
+    assert np.abs(gi - c["grad_image"]).max() <= 2e-4 * np.abs(c["grad_image"]).max()
+    assert np.array_equal(gi == 0, c["grad_image"] == 0)            # masked elements carry exactly no gradient
+    np.testing.assert_allclose(gd, c["grad_depth"], atol=1e-12, rtol=1e-5)
+
+
+@pytest.mark.parametrize("res", [(1200, 680), (640, 480)])
+def test_loss_full_size_vs_oracle(res):
+    from oracle import loss_oracle
+    W, H = res
+    rng = np.random.default_rng(W)
+    yy, xx = np.mgrid[0:H, 0:W]
+    gt = np.stack([0.5 + 0.4 * np.sin(xx / (9.0 + c) + yy / 17.0) for c in range(3)]).astype(np.float32)
+    img = np.clip(gt + rng.normal(0, 0.05, gt.shape), 0, 1).astype(np.float32)
+    gtd = (2.0 + np.sin(xx / 31.0)).astype(np.float32)[None]
+    gtd[:, H // 2: H // 2 + 20, W // 3: W // 2] = 0
+    dep = (gtd + rng.normal(0, 0.03, gtd.shape)).astype(np.float32)
+    c = dict(image=img, depth=dep, gt_image=gt, gt_depth=gtd)
+    loss, parts, gi, gd = _run(c)
+    # float64 oracle at this size: a float32 mean over 2.4 M elements (what torch does on CPU) is itself only good to ~1e-5
+    ti, td = torch.tensor(img, dtype=torch.float64, requires_grad=True), torch.tensor(dep, dtype=torch.float64, requires_grad=True)
+    lo, l1, ss, ld = loss_oracle.mapper_loss(ti, td, torch.tensor(gt, dtype=torch.float64), torch.tensor(gtd, dtype=torch.float64))
+    lo.backward()
+    assert abs(loss - lo.item()) < 2e-6 and abs(parts[2] - ss.item()) < 3e-6 and abs(parts[1] - l1.item()) < 1e-6
+    assert np.abs(gi - ti.grad.numpy()).max() <= 2e-4 * np.abs(ti.grad.numpy()).max()
+    robust = np.abs(dep / np.float32(10) - gtd / np.float32(10)) > 1e-7   # sign(0) in float32 vs a tiny residue in float64
+    np.testing.assert_allclose(gd[robust], td.grad.numpy()[robust], atol=1e-12, rtol=1e-5)
+
+
+def test_loss_scales_with_upstream_gradient_and_rejects_cpu():
+    from gs_icp_slam_amd.loss import mapper_loss
+    z = np.load(GOLD)
+    c = {k[2:]: z[k] for k in z.files if k.startswith("b_")}
+    image = torch.tensor(c["image"], device="cuda", requires_grad=True)
+    depth = torch.tensor(c["depth"], device="cuda", requires_grad=True)
+    (3.0 * mapper_loss(image, depth, torch.tensor(c["gt_image"], device="cuda"), torch.tensor(c["gt_depth"], device="cuda"))).backward()
+    np.testing.assert_allclose(image.grad.cpu().numpy(), 3.0 * c["grad_image"], atol=6e-4 * np.abs(c["grad_image"]).max())
+    with pytest.raises(RuntimeError):
+        mapper_loss(torch.zeros(3, 8, 8), torch.zeros(1, 8, 8), torch.zeros(3, 8, 8), torch.zeros(1, 8, 8))
+
+
+def test_fused_adam_matches_torch_adam():
+    """Six parameter groups with the reference's learning rates and eps [REF arguments/__init__.py:141-148; scene/gaussian_model.py:231]."""
+    from gs_icp_slam_amd.optim import FusedAdam
+    rng = np.random.default_rng(0)
+    shapes = [(5000, 3), (5000, 1, 3), (5000, 0, 3), (5000, 1), (5000, 3), (5000, 4)]
+    lrs = [1.6e-6 * 2.5, 2.5e-3, 1.25e-4, 0.05, 5e-3, 1e-3]
+    init = [rng.normal(size=s).astype(np.float32) for s in shapes]
+    ref_p = [torch.tensor(a, requires_grad=True) for a in init]
+    gpu_p = [torch.tensor(a, device="cuda", requires_grad=True) for a in init]
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref_p, lrs)], lr=0.0, eps=1e-15)
+    fused = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(gpu_p, lrs)], lr=0.0, eps=1e-15)
+    for it in range(25):
+        for p, q in zip(ref_p, gpu_p):
+            g = (rng.normal(size=tuple(p.shape)) * (10.0 ** rng.integers(-6, 1))).astype(np.float32)
+            p.grad = torch.tensor(g)
+            q.grad = torch.tensor(g, device="cuda")
+        ref.step()
+        fused.step()
+    for p, q in zip(ref_p, gpu_p):
+        if p.numel():
+            np.testing.assert_allclose(q.detach().cpu().numpy(), p.detach().numpy(), rtol=2e-5, atol=1e-7)
+    st = fused.state[gpu_p[0]]
+    assert set(st) >= {"step", "exp_avg", "exp_avg_sq"} and int(st["step"]) == 25
+    np.testing.assert_allclose(st["exp_avg"].cpu().numpy(), ref.state[ref_p[0]]["exp_avg"].numpy(), rtol=1e-5, atol=1e-7)

@@ -231,3 +231,34 @@ def test_mark_visible():
     rs = util.make_settings(cam, [0, 0, 0])
     pos = torch.tensor([[0, 0, 1.0], [0, 0, 0.1], [0, 0, -3.0], [5, 5, 0.21]], device="cuda")
     assert GaussianRasterizer(rs).markVisible(pos).cpu().tolist() == [True, False, False, True]
+
+
+def test_sharded_wrapper_collectives_on_rccl_world1(hip_lib):
+    """The N-GPU path's collectives and autograd plumbing on real device tensors: backend "nccl" (= RCCL) with a single rank
+    (gpurun exposes one GPU), forced through the all-reduce branch.  Must equal the plain rasteriser bit-for-bit."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gs_icp_slam_amd.sharded import ShardedGaussianRasterizer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cam = synth.make_camera(176, 96, 130.0, 130.0)
+        g = synth.random_gaussians(500, seed=21)
+        rs = util.make_settings(cam, [0.1, 0.2, 0.3])
+        outs = []
+        for mk in (lambda: GaussianRasterizer(rs), lambda: ShardedGaussianRasterizer(rs, force_collectives=True)):
+            t = util.torch_inputs(g, requires_grad=True)
+            m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+            d, c, r, u = mk()(means3D=t["means3D"], means2D=m2, shs=t["shs"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+            (c.square().sum() + d.sum()).backward()
+            outs.append((c.detach(), d.detach(), {k: v.grad.clone() for k, v in t.items()}, m2.grad.clone(), u))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][4], outs[1][4])
+        for k in outs[0][2]:
+            assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+        assert torch.equal(outs[0][3], outs[1][3])
+    finally:
+        dist.destroy_process_group()
