@@ -4,8 +4,9 @@
 One "step" = one SLAM frame's worth of the hot path on synthetic Replica-shaped input:
   tracker : pygicp.FastGICP  set_input_source + set_source_filter + align + get_source_correspondence
             on S-pair (8 280 points/frame, max_correspondence_distance 0.02)          [REF mp_Tracker.py:191-231]
-  mapper  : one optimisation iteration's rasteriser work — GaussianRasterizer forward (+ an L1 colour/depth loss to
-            produce image gradients) + backward, P = 300 000 surfels, 1200x680          [REF mp_Mapper.py:219-242]
+  mapper  : one full optimisation iteration — activations, GaussianRasterizer forward, the mapping loss
+            0.8 L1 + 0.2 (1-SSIM) + 0.1 L1(depth/10) (fused HIP kernel), backward, Adam step over the parameter groups
+            (fused HIP kernel), zero_grad; P = 300 000 surfels, 1200x680                 [REF mp_Mapper.py:219-248]
 With N > 1 GPUs the mapper's tiles are sharded across ranks (strong scaling; gs_icp_slam_amd/sharded.py) and the
 tracker runs as a replica on every rank (it does not shard — DESIGN.md).
 
@@ -61,7 +62,16 @@ def main():
     # ---------------- mapper inputs (S-map) ----------------
     cam = synth.make_camera(W, H, cfg["fx"], cfg["fy"], synth.DEFAULT_POSE_A)
     g = synth.s_map(P, seed=2)
-    params = {k: torch.from_numpy(g[k]).to(dev).requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    # raw (pre-activation) parameters as GaussianModel keeps them [REF scene/gaussian_model.py:105-125]: log-scales, logit
+    # opacities, un-normalised quaternions; the activations below are the reference's torch ops and are part of the step
+    params = {"means3D": torch.from_numpy(g["means3D"]), "scales": torch.log(torch.from_numpy(g["scales"])),
+              "rotations": torch.from_numpy(g["rotations"]),
+              "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-4, 1 - 1e-4)), "shs": torch.from_numpy(g["shs"])}
+    params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in params.items()}
+    from gs_icp_slam_amd.loss import mapper_loss
+    from gs_icp_slam_amd.optim import FusedAdam
+    lrs = {"means3D": 1.6e-6 * 2.5, "shs": 2.5e-3, "opacities": 0.05, "scales": 5e-3, "rotations": 1e-3}   # REF arguments/__init__.py:141-148
+    optimizer = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in lrs.items()], lr=0.0, eps=1e-15)
     rs = GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev), scale_modifier=1.0,
         viewmatrix=torch.from_numpy(cam["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(cam["projmatrix"]).to(dev), sh_degree=0,
@@ -121,14 +131,20 @@ def main():
         worker = threading.Thread(target=tracker_worker, daemon=True)
         worker.start()
 
+    def activated():
+        return dict(means3D=params["means3D"], shs=params["shs"], opacities=torch.sigmoid(params["opacities"]),
+                    scales=torch.exp(params["scales"]), rotations=torch.nn.functional.normalize(params["rotations"]))
+
     def mapper_iteration():
-        means2D = torch.zeros_like(params["means3D"], requires_grad=True)
-        depth, color, radii, used = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
-                                         scales=params["scales"], rotations=params["rotations"])
-        loss = (color - gt_color).abs().mean() + 0.1 * ((depth - gt_depth) / 10.0).abs().mean()
+        """One iteration of Mapper.mapping [REF mp_Mapper.py:219-248]: render_3 -> loss -> backward -> Adam step -> zero_grad."""
+        a = activated()
+        means2D = torch.zeros_like(a["means3D"], requires_grad=True)
+        depth, color, radii, used = rast(means3D=a["means3D"], means2D=means2D, shs=a["shs"], opacities=a["opacities"],
+                                         scales=a["scales"], rotations=a["rotations"])
+        loss = mapper_loss(color, depth, gt_color, gt_depth, lambda_dssim=0.2)
         loss.backward()
-        for p in params.values():
-            p.grad = None
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
         return loss, radii
 
     def step():
@@ -179,9 +195,10 @@ def main():
                      "preprocess_backward"]
     dominant = max((k for k in raster_stages if k in per_launch_us), key=lambda k: per_launch_us[k])
     # D (duplicates) and P_vis from one extra forward
-    means2D = torch.zeros_like(params["means3D"], requires_grad=True)
-    depth, color, radii, used = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"], opacities=params["opacities"],
-                                     scales=params["scales"], rotations=params["rotations"])
+    a_ = activated()
+    means2D = torch.zeros_like(a_["means3D"], requires_grad=True)
+    depth, color, radii, used = rast(means3D=a_["means3D"], means2D=means2D, shs=a_["shs"], opacities=a_["opacities"],
+                                     scales=a_["scales"], rotations=a_["rotations"])
     node = depth.grad_fn
     while node is not None and not hasattr(node, "num_rendered"):
         node = node.next_functions[0][0] if node.next_functions else None
@@ -244,7 +261,7 @@ def main():
         ms = 1e3 * dt / args.steps
         stage_us = {k: round(v, 2) for k, v in per_launch_us.items()}
         out = {
-            "metric": "SLAM hot-path FPS (GICP tracker align + mapper render fwd+bwd per frame), Replica room0-shaped synthetic",
+            "metric": "SLAM hot-path FPS (GICP tracker frame + one full mapper iteration: render, loss, backward, Adam), Replica room0-shaped synthetic",
             "value": round(args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",

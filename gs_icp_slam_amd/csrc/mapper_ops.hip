@@ -6,8 +6,8 @@
 //     [REF scene/gaussian_model.py:222-231; mp_Mapper.py:247] in ONE launch.
 //
 // Loss kernels: one 256-thread workgroup per 16x16 tile and channel.  The 26x26 halo tile goes through LDS once; the
-// reference's exact 11x11 float32 window (121 taps; a separable evaluation is measurably NOT equivalent, see pass 1) is
-// applied to five moment maps (x, y, xx, yy, xy) in pass 1 and to the three derivative maps in pass 2.  Everything is HBM-streaming: pass 1 reads 2 and writes 3 floats per
+// reference's 11x11 Gaussian window is applied separably (11 + 11 taps, with 1-D weights bit-identical to the reference's) to
+// five moment maps (x, y, xx, yy, xy) in pass 1 and to the three derivative maps in pass 2.  Everything is HBM-streaming: pass 1 reads 2 and writes 3 floats per
 // pixel-channel, pass 2 reads 5 and writes 1.  Sums are reduced per workgroup and finished by a tiny second kernel in
 // a fixed order (no float atomics: results are bit-reproducible).
 #include <cmath>
@@ -27,7 +27,7 @@ constexpr int LT = 16;            // output tile
 constexpr int HALO = 5;           // 11x11 window
 constexpr int LW = LT + 2 * HALO; // 26
 
-struct Win { float w[121]; };   // the reference's 2-D window: float32 outer product of the normalised 11-tap Gaussian
+struct Win { float w[11]; };   // the reference's normalised 11-tap Gaussian (its 2-D window is the float32 outer product of this)
 
 __device__ inline float wave_sum_f(float v) {
 #pragma unroll
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
                                                          float* __restrict__ abc /* (3, 3, H, W): A, B, C per channel */,
                                                          float* __restrict__ partial) {
     __shared__ float s_x[LW][LW + 1], s_y[LW][LW + 1];
+    __shared__ float s_h[5][LW][LT + 1];
     __shared__ float s_red[4][2];
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
@@ -70,20 +71,30 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
             s_x[r][c] = xv; s_y[r][c] = yv;
         }
         __syncthreads();
+        // Separable evaluation (11 + 11 taps instead of 121).  The reference convolves with the float32 outer product g g^T; the
+        // separable form differs from it only by the rounding of the 121 products (relative 6e-8, zero-mean) PROVIDED the 1-D
+        // weights are bit-identical to the reference's (an early version normalised them with a sequentially rounded sum, one ulp
+        // off, and that 6e-8 scale error alone moved the SSIM mean by 1e-5 through sigma = E[xx] - mu^2).
+        for (int i = tid; i < LW * LT; i += 256) {
+            const int r = i / LT, c = i % LT;
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float xv = s_x[r][c + k], yv = s_y[r][c + k], w = win.w[k];
+                m0 += w * xv; m1 += w * yv; m2 += w * (xv * xv); m3 += w * (yv * yv); m4 += w * (xv * yv);
+            }
+            s_h[0][r][c] = m0; s_h[1][r][c] = m1; s_h[2][r][c] = m2; s_h[3][r][c] = m3; s_h[4][r][c] = m4;
+        }
+        __syncthreads();
         const int px = x0 + lx, py = y0 + ly;
         if (px < W && py < H) {
-            // 121 taps with the reference's own float32 2-D window.  (A separable 11+11 evaluation is NOT equivalent here: the
-            // rounded outer product sums to 1 - 7e-8 instead of (sum w)^2 = 1 + 9e-8, and SSIM's sigma = E[xx] - mu^2 turns that
-            // 1.6e-7 normalisation difference into a 1e-5 shift of the SSIM mean.)
             float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 11; ++i)
-#pragma unroll
-                for (int j = 0; j < 11; ++j) {
-                    const float w = win.w[i * 11 + j];
-                    const float xv = s_x[ly + i][lx + j], yv = s_y[ly + i][lx + j];
-                    mu1 += w * xv; mu2 += w * yv; e11 += w * (xv * xv); e22 += w * (yv * yv); e12 += w * (xv * yv);
-                }
+            for (int k = 0; k < 11; ++k) {
+                const float w = win.w[k];
+                mu1 += w * s_h[0][ly + k][lx]; mu2 += w * s_h[1][ly + k][lx]; e11 += w * s_h[2][ly + k][lx];
+                e22 += w * s_h[3][ly + k][lx]; e12 += w * s_h[4][ly + k][lx];
+            }
             const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
             const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
             const float a = 2.f * mu12 + C1, b = 2.f * (e12 - mu12) + C2;
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
                                                          float depth_scale /* w_d / (HW d_max) */, const float* __restrict__ abc,
                                                          float* __restrict__ dL_dimage, float* __restrict__ dL_ddepth) {
     __shared__ float s_in[3][LW][LW + 1];
+    __shared__ float s_h[3][LW][LT + 1];
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
     const size_t HW = (size_t)W * H;
@@ -165,15 +177,24 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
         s_in[0][r][c] = a; s_in[1][r][c] = b; s_in[2][r][c] = cc;
     }
     __syncthreads();
+    for (int i = tid; i < LW * LT; i += 256) {
+        const int r = i / LT, c = i % LT;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = win.w[k];
+            m0 += w * s_in[0][r][c + k]; m1 += w * s_in[1][r][c + k]; m2 += w * s_in[2][r][c + k];
+        }
+        s_h[0][r][c] = m0; s_h[1][r][c] = m1; s_h[2][r][c] = m2;
+    }
+    __syncthreads();
     if (px < W && py < H) {
         float cA = 0.f, cB = 0.f, cC = 0.f;
 #pragma unroll
-        for (int i = 0; i < 11; ++i)
-#pragma unroll
-            for (int j = 0; j < 11; ++j) {
-                const float w = win.w[i * 11 + j];   // symmetric window: correlation == convolution
-                cA += w * s_in[0][ly + i][lx + j]; cB += w * s_in[1][ly + i][lx + j]; cC += w * s_in[2][ly + i][lx + j];
-            }
+        for (int k = 0; k < 11; ++k) {
+            const float w = win.w[k];   // symmetric window: correlation == convolution
+            cA += w * s_h[0][ly + k][lx]; cB += w * s_h[1][ly + k][lx]; cC += w * s_h[2][ly + k][lx];
+        }
         const size_t pix = (size_t)py * W + px;
         const float yv = gt_depth[pix] > 0.f ? gt_image[ch * HW + pix] : 0.f;
         float gr = 0.f;
@@ -248,9 +269,7 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
         // ulp lower, and that 6e-8 is visible in SSIM); tests/test_oracle_loss.py checks the construction bit-for-bit
         for (int i = 0; i < 11; ++i) sum_d += (double)g1[i];
         const float sum = (float)sum_d;
-        for (int i = 0; i < 11; ++i) g1[i] = g1[i] / sum;
-        for (int i = 0; i < 11; ++i)
-            for (int j = 0; j < 11; ++j) win.w[i * 11 + j] = g1[i] * g1[j];
+        for (int i = 0; i < 11; ++i) win.w[i] = g1[i] / sum;
     }
     const size_t HW = (size_t)width * height;
     const dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, 4);
