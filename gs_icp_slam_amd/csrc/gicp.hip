@@ -236,8 +236,8 @@ __device__ inline bool lex_less(float d, int i, float d2, int i2) { return d < d
 __device__ inline float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ inline int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }  // lane l <- lane l-1
 
-__global__ __launch_bounds__(256) void knn_cov_kernel(int n, int k, int batch_stride, const float4* __restrict__ pts, float max_d2, int reg_method,
-                                                      double* __restrict__ cov, float* __restrict__ rotq, float* __restrict__ scales) {
+__global__ __launch_bounds__(256) void knn_cov_kernel(int n, int k, int batch_stride, const float4* __restrict__ pts,
+                                                      int* __restrict__ nbr_idx, float* __restrict__ nbr_d2) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= n) return;                       // wave-uniform
@@ -284,36 +284,49 @@ __global__ __launch_bounds__(256) void knn_cov_kernel(int n, int k, int batch_st
             tau_i = __builtin_amdgcn_readlane(my_i, kk - 1);
         }
     }
-    // neighbours now sit in lanes 0..kk-1, ascending.  Mean / covariance in fp64, summed in rank order (as the oracle).
-    float4 np = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < kk) np = pts[my_i];
+    // neighbours now sit in lanes 0..kk-1, ascending: park (index, d2) for the per-thread covariance kernel.  (Doing the fp64
+    // mean / covariance / Jacobi here would execute it once per WAVE with all 64 lanes computing the same numbers.)
+    if (lane < kk) {
+        nbr_idx[(size_t)q * 64 + lane] = my_i;
+        nbr_d2[(size_t)q * 64 + lane] = my_d;
+    }
+}
+
+// One THREAD per point: mean / covariance of its neighbours in fp64 (summed in rank order, as the oracle does), cyclic
+// Jacobi, quaternion (x,y,z,w), scales = sqrt(eigenvalues of the RAW covariance), regularised covariance for the cost.
+__global__ __launch_bounds__(64) void cov_eig_kernel(int n, int k, const float4* __restrict__ pts, const int* __restrict__ nbr_idx,
+                                                     const float* __restrict__ nbr_d2, float max_d2, int reg_method,
+                                                     double* __restrict__ cov, float* __restrict__ rotq, float* __restrict__ scales) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= n) return;
+    const int kk = k < n ? k : n;
     double mu[3] = {0, 0, 0};
     int cnt = 0;
     for (int j = 0; j < kk; ++j) {
-        if (readlane_f(my_d, j) > max_d2) break;
-        mu[0] += (double)readlane_f(np.x, j); mu[1] += (double)readlane_f(np.y, j); mu[2] += (double)readlane_f(np.z, j);
+        if (nbr_d2[(size_t)q * 64 + j] > max_d2) break;
+        const float4 p = pts[nbr_idx[(size_t)q * 64 + j]];
+        mu[0] += (double)p.x; mu[1] += (double)p.y; mu[2] += (double)p.z;
         ++cnt;
     }
     mu[0] /= cnt; mu[1] /= cnt; mu[2] /= cnt;
     double raw[6] = {0, 0, 0, 0, 0, 0};
     for (int j = 0; j < cnt; ++j) {
-        const double dx = (double)readlane_f(np.x, j) - mu[0], dy = (double)readlane_f(np.y, j) - mu[1], dz = (double)readlane_f(np.z, j) - mu[2];
+        const float4 p = pts[nbr_idx[(size_t)q * 64 + j]];
+        const double dx = (double)p.x - mu[0], dy = (double)p.y - mu[1], dz = (double)p.z - mu[2];
         raw[0] += dx * dx; raw[1] += dx * dy; raw[2] += dx * dz; raw[3] += dy * dy; raw[4] += dy * dz; raw[5] += dz * dz;
     }
 #pragma unroll
     for (int d = 0; d < 6; ++d) raw[d] /= cnt;
     double ev[3], V[9], qd[4], out6[6];
-    eig_sym3(raw, ev, V);          // wave-uniform values: executed once per wave, stored by lane 0
+    eig_sym3(raw, ev, V);
     rot_to_quat(V, qd);
     regularise(reg_method, ev, V, raw, out6);
-    if (lane == 0) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) rotq[4 * (size_t)q + d] = (float)qd[d];
+    for (int d = 0; d < 4; ++d) rotq[4 * (size_t)q + d] = (float)qd[d];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) scales[3 * (size_t)q + d] = (float)sqrt(fmax(ev[d], 0.0));
+    for (int d = 0; d < 3; ++d) scales[3 * (size_t)q + d] = (float)sqrt(fmax(ev[d], 0.0));
 #pragma unroll
-        for (int d = 0; d < 6; ++d) cov[6 * (size_t)q + d] = out6[d];
-    }
+    for (int d = 0; d < 6; ++d) cov[6 * (size_t)q + d] = out6[d];
 }
 
 __global__ __launch_bounds__(256) void cov_fromqs_kernel(int n, int reg_method, const float* __restrict__ rots,
@@ -850,7 +863,8 @@ struct gsicp_gicp {
     DevBuf<float4> sorted;
     DevBuf<char> sort_temp;
     // per-source-point outputs
-    DevBuf<int> corr, miss, counters;
+    DevBuf<int> corr, miss, counters, nbr_idx;
+    DevBuf<float> nbr_d2;
     DevBuf<float> sqd;
     DevBuf<double> maha;
     DevBuf<AlignResult> result;
@@ -912,8 +926,10 @@ int calc_cov(gsicp_gicp* g, Cloud& c) {
         int stride = 1;
         for (int p : {37, 41, 43, 47, 53, 59, 61, 67, 71, 73})
             if (p < nb && nb % p != 0) { stride = p; break; }
-        hipLaunchKernelGGL(knn_cov_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, n, g->k, stride, c.pts.p, maxd2, g->reg, c.cov.p,
-                           c.rotq.p, c.scales.p);
+        if (g->nbr_idx.ensure((size_t)n * 64) || g->nbr_d2.ensure((size_t)n * 64)) { g_last_error = "hipMalloc failed"; return -1; }
+        hipLaunchKernelGGL(knn_cov_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, n, g->k, stride, c.pts.p, g->nbr_idx.p, g->nbr_d2.p);
+        hipLaunchKernelGGL(cov_eig_kernel, dim3((n + 63) / 64), dim3(64), 0, g->stream, n, g->k, c.pts.p, g->nbr_idx.p, g->nbr_d2.p, maxd2,
+                           g->reg, c.cov.p, c.rotq.p, c.scales.p);
         GC(hipGetLastError());
     }
     c.cov_valid = true; c.qs_valid = true;
