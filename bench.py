@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--serial", action="store_true", help="run tracker and mapper back-to-back on one thread (default: concurrently, as the\n                    reference runs them in two processes)")
+    ap.add_argument("--no-graph", action="store_true", help="drive the mapper iteration eagerly from Python instead of replaying the captured\n                    HIP graph (N > 1 always runs eagerly)")
     ap.add_argument("--pyprofile", default=None, help="write a cProfile of the timed region to this file (diagnostics)")
     args = ap.parse_args()
 
@@ -71,7 +72,8 @@ def main():
     from gs_icp_slam_amd.loss import mapper_loss
     from gs_icp_slam_amd.optim import FusedAdam
     lrs = {"means3D": 1.6e-6 * 2.5, "shs": 2.5e-3, "opacities": 0.05, "scales": 5e-3, "rotations": 1e-3}   # REF arguments/__init__.py:141-148
-    optimizer = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in lrs.items()], lr=0.0, eps=1e-15)
+    use_graph = (world == 1) and not args.no_graph
+    optimizer = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in lrs.items()], lr=0.0, eps=1e-15, capturable=use_graph)
     rs = GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev), scale_modifier=1.0,
         viewmatrix=torch.from_numpy(cam["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(cam["projmatrix"]).to(dev), sh_degree=0,
@@ -147,6 +149,33 @@ def main():
         optimizer.zero_grad(set_to_none=True)
         return loss, radii
 
+    mg = None
+    if use_graph:
+        # Single GPU: the whole iteration is one hipGraph launch (gs_icp_slam_amd/graph.py).  The duplicate-list capacity comes
+        # from one synchronous forward (x1.5); the keyframe (camera + targets) is re-selected before every replay, as the
+        # reference's mapper does [REF mp_Mapper.py:205-217].
+        from gs_icp_slam_amd.graph import MapperIterationGraph
+        with torch.no_grad():
+            a0 = activated()
+            rast(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"],
+                 scales=a0["scales"], rotations=a0["rotations"])
+        from gs_icp_slam_amd.rasterizer import GaussianRasterizer as _GR
+        probe = _GR(rs._replace(capacity=1 << 27))
+        with torch.no_grad():
+            probe(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"],
+                  scales=a0["scales"], rotations=a0["rotations"])
+        capacity = int(1.5 * int(probe.num_rendered.item())) + 4096
+        del probe
+        mg = MapperIterationGraph(params, optimizer, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=capacity,
+                                  lambda_dssim=0.2, warmup=2)
+        mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_color, gt_depth)
+        mg.capture()
+        eager_iteration = mapper_iteration
+
+        def mapper_iteration():   # noqa: F811
+            mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_color, gt_depth)
+            return mg.step(), mg.radii
+
     def step():
         if worker is not None:
             jobs.put(1)
@@ -183,6 +212,23 @@ def main():
         with open(args.pyprofile, "w") as fh:
             pstats.Stats(prof_py, stream=fh).sort_stats("cumulative").print_stats(45)
     prof = _lib.profile_read()
+    n_prof = {k: args.steps for k in prof}
+    if mg is not None:
+        # kernels inside a replayed graph carry no HIP events: time the SAME kernels on the same inputs in eager iterations
+        # right after the timed region (rocprofv3's kernel trace of this command sees both and agrees — profiles/README.md)
+        if mg.overflowed():
+            raise RuntimeError("duplicate-list capacity overflowed during the timed region")
+        n_e = max(5, min(args.steps, 20))
+        eager_iteration()
+        torch.cuda.synchronize()
+        _lib.profile_read()
+        for _ in range(n_e):
+            eager_iteration()
+        torch.cuda.synchronize()
+        for k, v in _lib.profile_read().items():
+            if v[1] > 0 and not k.startswith("gicp"):
+                prof[k] = v
+                n_prof[k] = n_e
     _lib.profile_enable(False)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -190,7 +236,7 @@ def main():
         dt = float(tmax.item())
 
     # ---------------- roofline of the dominant kernel ----------------
-    per_launch_us = {k: (1e3 * ms / args.steps) for k, (ms, c) in prof.items() if c > 0}   # us per step (a stage may be several launches)
+    per_launch_us = {k: (1e3 * ms / n_prof[k]) for k, (ms, c) in prof.items() if c > 0}   # us per step (a stage may be several launches)
     raster_stages = ["preprocess", "tile_scan_lpt", "scatter", "tile_sort", "blend_forward", "blend_backward", "entry_grad_sum",
                      "preprocess_backward"]
     dominant = max((k for k in raster_stages if k in per_launch_us), key=lambda k: per_launch_us[k])
@@ -269,6 +315,7 @@ def main():
                                    f"S-map mapper iteration (P={P}, {W}x{H}, sh_degree 0)", "gaussians": P, "width": W, "height": H,
                        "duplicates_per_rank": D_local, "visible_gaussians": P_vis,
                        "tracker_mapper_overlap": not args.serial,
+                       "mapper_iteration": "one hipGraph replay per iteration" if mg is not None else "eager launches from Python",
                        "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-reduce image + grads), tracker replicated"},
             "render_bwd_ms_per_iter": round(sum(per_launch_us.get(k, 0.0) for k in raster_stages) / 1e3, 4),
             "tracker_align_kernel_us": stage_us.get("gicp_align"),

@@ -26,6 +26,10 @@ SIGNATURES = {
                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_void_p]),
+    "gsicp_raster_forward_async": (c_int, [RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, c_int, c_int, c_int, c_void_p,
+                                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gsicp_raster_backward_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gsicp_raster_backward": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p,
@@ -39,6 +43,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p]),
     "gsicp_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int,
                                 c_void_p]),
+    "gsicp_adam_step_capturable": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
+                                           c_void_p, c_void_p]),
     "gsicp_gicp_create": (c_void_p, []),
     "gsicp_gicp_destroy": (None, [c_void_p]),
     "gsicp_gicp_set_max_correspondence_distance": (c_int, [c_void_p, c_double]),

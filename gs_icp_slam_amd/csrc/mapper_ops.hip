@@ -216,6 +216,7 @@ struct AdamTable {
     float* v[ADAM_MAX_GROUPS];
     long long end[ADAM_MAX_GROUPS];    // exclusive prefix end of each group in the flattened index space
     float step_size[ADAM_MAX_GROUPS];  // lr / (1 - beta1^t)
+    int src[ADAM_MAX_GROUPS];          // index of the group in the caller's arrays (empty tensors are squeezed out)
     int n;
 };
 
@@ -238,6 +239,32 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float beta1, flo
         t.p[gidx][j] = t.p[gidx][j] - t.step_size[gidx] * (m / denom);
     }
 }
+
+// Same update with the step count and the learning rates in DEVICE memory, so that one captured HIP graph can be replayed
+// for every iteration (torch.optim.Adam(capturable=True) keeps its step on the device for the same reason).
+__global__ __launch_bounds__(256) void adam_capturable_kernel(AdamTable t, const float* __restrict__ lr_dev, const int* __restrict__ step_dev,
+                                                              float beta1, float beta2, float eps, long long total) {
+    const int step = *step_dev + 1;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        int gidx = 0;
+        long long base = 0;
+#pragma unroll
+        for (int k = 0; k < ADAM_MAX_GROUPS - 1; ++k)
+            if (k < t.n - 1 && i >= t.end[k]) { gidx = k + 1; base = t.end[k]; }
+        const long long j = i - base;
+        const float step_size = (float)((double)lr_dev[t.src[gidx]] / bc1);
+        const float g = t.g[gidx][j];
+        float m = t.m[gidx][j], v = t.v[gidx][j];
+        m = m + (1.f - beta1) * (g - m);
+        v = beta2 * v + (1.f - beta2) * g * g;
+        t.m[gidx][j] = m; t.v[gidx][j] = v;
+        const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+        t.p[gidx][j] = t.p[gidx][j] - step_size * (m / denom);
+    }
+}
+__global__ void adam_bump_step_kernel(int* step_dev) { *step_dev += 1; }
 
 }  // namespace
 }  // namespace gsicp
@@ -288,28 +315,56 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
     return 0;
 }
 
-int gsicp_adam_step(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                    const long long* numel, const float* lr, float beta1, float beta2, float eps, int step, void* stream_v) {
-    hipStream_t stream = (hipStream_t)stream_v;
-    if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || step < 1) { g_last_error = "gsicp_adam_step: 1..8 tensors, step >= 1"; return -2; }
-    AdamTable t;
+static long long adam_table(AdamTable& t, int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const long long* numel, const float* lr, double bc1) {
     long long total = 0;
-    const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
     t.n = 0;
     for (int k = 0; k < n_groups; ++k) {
         if (numel[k] <= 0) continue;
         t.p[t.n] = params[k]; t.g[t.n] = grads[k]; t.m[t.n] = exp_avg[k]; t.v[t.n] = exp_avg_sq[k];
         total += numel[k];
         t.end[t.n] = total;
-        t.step_size[t.n] = (float)((double)lr[k] / bc1);
+        t.step_size[t.n] = lr ? (float)((double)lr[k] / bc1) : 0.f;
+        t.src[t.n] = k;
         ++t.n;
     }
-    for (int k = t.n; k < ADAM_MAX_GROUPS; ++k) { t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.end[k] = total; t.step_size[k] = 0.f; }
+    for (int k = t.n; k < ADAM_MAX_GROUPS; ++k) {
+        t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.end[k] = total; t.step_size[k] = 0.f; t.src[k] = 0;
+    }
+    return total;
+}
+
+int gsicp_adam_step(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const long long* numel, const float* lr, float beta1, float beta2, float eps, int step, void* stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || step < 1) { g_last_error = "gsicp_adam_step: 1..8 tensors, step >= 1"; return -2; }
+    AdamTable t;
+    const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+    const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, bc1);
     if (total == 0) return 0;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, beta1, beta2, eps, (float)(1.0 / std::sqrt(bc2)), total);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step: kernel launch failed"; return -1; }
+    return 0;
+}
+
+int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const long long* numel, const float* lr_dev, float beta1, float beta2,
+                               float eps, int* step_dev, void* stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || !lr_dev || !step_dev) {
+        g_last_error = "gsicp_adam_step_capturable: 1..8 tensors, device lr array and device step counter"; return -2;
+    }
+    AdamTable t;
+    const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, nullptr, 1.0);
+    if (total > 0) {
+        long long blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(adam_capturable_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, lr_dev, step_dev, beta1, beta2, eps, total);
+    }
+    hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, stream, step_dev);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step_capturable: kernel launch failed"; return -1; }
     return 0;
 }
 

@@ -82,6 +82,15 @@ void profile_end(int stage, hipStream_t s) {
 
 namespace {
 
+// The number of (Gaussian, tile) duplicates R lives in device memory (preprocess counts it).  Every binning kernel
+// reads it there, so the forward can run without a host round trip when the caller provides the list capacity
+// (gsicp_raster_forward_async).  R above the capacity degrades to "nothing rendered" — memory-safe, and flagged to the
+// caller through num_rendered_dev.
+__device__ inline int device_R(const uint32_t* __restrict__ total, uint32_t cap) {
+    const uint32_t r = *total;
+    return r > cap ? 0 : (int)r;
+}
+
 // ------------------------------------------------------------------------------------------------ binning
 // Single workgroup: exclusive scan of the per-tile duplicate counts -> list ranges, and an LPT dispatch order by a
 // counting sort over 64 length buckets (exact ordering is not needed for load balance).  Any T; one launch.
@@ -143,14 +152,15 @@ __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int tile_mod
 
 // One thread per Gaussian (id order): fill its contiguous run of emission slots — tile id, depth bits, list word
 // (slot | strip bits), slot -> Gaussian map.  Coalesced-ish plain stores, no atomics.
-__global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ slot_base,
+__global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __restrict__ total, uint32_t cap,
+                                                   const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ slot_base,
                                                    const SplatRec* __restrict__ rec, const int* __restrict__ radii, int gx, int gy,
                                                    int tile_mod, int tile_rem, uint32_t* __restrict__ emit_tile,
                                                    uint32_t* __restrict__ emit_depth, uint32_t* __restrict__ entry_gauss,
                                                    uint32_t* __restrict__ entry_bits) {
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= P) return;
-    if (tiles_touched[id] == 0) return;
+    if (tiles_touched[id] == 0 || *total > cap) return;
     uint32_t u = slot_base[id];
     const SplatRec r = rec[id];
     const uint32_t dbits = __float_as_uint(r.depth);
@@ -179,9 +189,10 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __rest
 
 // Tile multi-split, pass 1: each workgroup histograms its contiguous chunk of emission slots over all T tiles in LDS
 // (LDS atomics; no global atomics) and writes its row of the (split block, tile) count table.
-__global__ __launch_bounds__(1024) void split_hist_kernel(int R, int T, int chunk, const uint32_t* __restrict__ emit_tile,
-                                                          uint32_t* __restrict__ block_hist) {
+__global__ __launch_bounds__(1024) void split_hist_kernel(const uint32_t* __restrict__ total, uint32_t cap, int T,
+                                                          const uint32_t* __restrict__ emit_tile, uint32_t* __restrict__ block_hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist_dyn[];
+    const int R = device_R(total, cap), chunk = (R + (int)gridDim.x - 1) / (int)gridDim.x;
     for (int t = threadIdx.x; t < T; t += 1024) s_hist_dyn[t] = 0;
     __syncthreads();
     const int lo = blockIdx.x * chunk, hi = (lo + chunk) < R ? (lo + chunk) : R;
@@ -211,11 +222,12 @@ __global__ __launch_bounds__(256) void split_colscan_kernel(int T, int nb, uint3
 }
 // pass 3: scatter every emission slot into its tile's range; the rank inside the (block, tile) cell comes from an LDS
 // cursor.  Order inside a tile is arbitrary here — the per-tile sort that follows makes it unique.
-__global__ __launch_bounds__(1024) void split_scatter_kernel(int R, int T, int chunk, const uint32_t* __restrict__ emit_tile,
+__global__ __launch_bounds__(1024) void split_scatter_kernel(const uint32_t* __restrict__ total, uint32_t cap, int T, const uint32_t* __restrict__ emit_tile,
                                                              const uint32_t* __restrict__ emit_depth, const uint32_t* __restrict__ entry_bits,
                                                              const uint32_t* __restrict__ block_hist, const uint2* __restrict__ ranges,
                                                              uint32_t* __restrict__ sc_keys, uint32_t* __restrict__ sc_vals) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist_dyn[];
+    const int R = device_R(total, cap), chunk = (R + (int)gridDim.x - 1) / (int)gridDim.x;
     for (int t = threadIdx.x; t < T; t += 1024) s_hist_dyn[t] = 0;
     __syncthreads();
     const int lo = blockIdx.x * chunk, hi = (lo + chunk) < R ? (lo + chunk) : R;
@@ -565,10 +577,10 @@ __global__ __launch_bounds__(64) void blend_backward_strip_kernel(BlendArgs a) {
 
 // Entry-parallel: add up each emission slot's (up to four) strip slots into one 12-float record, so that the
 // per-Gaussian pass (preprocess_backward) only streams a contiguous array.  Fully parallel, no dependent chains.
-__global__ __launch_bounds__(256) void entry_sum_kernel(int R, const uint32_t* __restrict__ entry_bits, const float* __restrict__ slots,
-                                                        float* __restrict__ entry_sum) {
+__global__ __launch_bounds__(256) void entry_sum_kernel(const uint32_t* __restrict__ total, uint32_t cap, const uint32_t* __restrict__ entry_bits,
+                                                        const float* __restrict__ slots, float* __restrict__ entry_sum) {
     const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= R) return;
+    if (u >= device_R(total, cap)) return;
     const uint32_t bits = entry_bits[u];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
 #pragma unroll
@@ -627,14 +639,17 @@ int gsicp_raster_layout(int P, int num_rendered, int width, int height, size_t o
     return 0;
 }
 
-int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
+static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
                          gsicp_resize_fn img_alloc, void* img_user, int P, int D, int M, const float* background, int width,
                          int height, const float* means3D, const float* shs, const float* colors_precomp,
                          const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                          float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
-                         int* is_used, int tile_mod, int tile_rem, int debug, void* stream_v) {
+                         int* is_used, int tile_mod, int tile_rem, int debug, int capacity, unsigned int* num_rendered_dev,
+                         void* stream_v) {
     (void)prefiltered; (void)debug;
+    const bool async = capacity > 0 && P > 0;   // capacity given: no host round trip, R stays on the device
+    if (capacity > (int)ID_MASK) { g_last_error = "capacity above 2^28 duplicates is not supported"; return -2; }
     hipStream_t stream = (hipStream_t)stream_v;
     if (width <= 0 || height <= 0 || P < 0) { g_last_error = "gsicp_raster_forward: bad sizes"; return -2; }
     if (P > (int)ID_MASK) { g_last_error = "more than 2^28 Gaussians are not supported"; return -2; }
@@ -680,14 +695,21 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
         pa.tiles_touched = tiles_touched; pa.slot_base = slot_base; pa.total_counter = total_counter;
         pa.radii = radii;
         { ProfileScope ps(ST_PREPROCESS, stream); launch_preprocess(pa, stream); }
-        uint32_t total = 0;
-        GS_CHECK(hipMemcpyAsync(&total, total_counter, 4, hipMemcpyDeviceToHost, stream));
-        GS_CHECK(hipStreamSynchronize(stream));   // the one host sync of the forward: the binning buffer is sized by it
-        if (total > ID_MASK) { g_last_error = "more than 2^28 (Gaussian, tile) duplicates are not supported"; return -2; }
-        num_rendered = (int)total;
+        if (async) {
+            num_rendered = capacity;   // buffer layouts and launch grids are sized by the capacity; kernels read the true R
+        } else {
+            uint32_t total = 0;
+            GS_CHECK(hipMemcpyAsync(&total, total_counter, 4, hipMemcpyDeviceToHost, stream));
+            GS_CHECK(hipStreamSynchronize(stream));   // the one host sync of the forward: the binning buffer is sized by it
+            if (total > ID_MASK) { g_last_error = "more than 2^28 (Gaussian, tile) duplicates are not supported"; return -2; }
+            num_rendered = (int)total;
+        }
+        if (num_rendered_dev) GS_CHECK(hipMemcpyAsync(num_rendered_dev, total_counter, 4, hipMemcpyDeviceToDevice, stream));
     } else {
         GS_CHECK(hipStreamSynchronize(stream));
+        if (num_rendered_dev) GS_CHECK(hipMemsetAsync(num_rendered_dev, 0, 4, stream));
     }
+    const uint32_t cap = (uint32_t)num_rendered;
 
     const BinLayout BL = bin_layout((size_t)num_rendered, (size_t)T);
     char* bin = binning_alloc(binning_user, BL.total);
@@ -698,7 +720,6 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     int nb = (num_rendered + 4095) / 4096;            // split blocks: >= 4096 slots each, at most SPLIT_BLOCKS_MAX
     if (nb < 1) nb = 1;
     if (nb > SPLIT_BLOCKS_MAX) nb = SPLIT_BLOCKS_MAX;
-    const int chunk = (num_rendered + nb - 1) / nb;
     const size_t lds_bytes = (size_t)T * 4;
     if (lds_bytes > 160 * 1024) { g_last_error = "image has too many tiles for the LDS tile histogram (> 40 960)"; return -2; }
     if (lds_bytes > 48 * 1024) {   // gfx950 has 160 KiB of LDS per CU, but more than the default dynamic quota must be requested
@@ -714,9 +735,9 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     uint32_t* block_hist = (uint32_t*)(bin + BL.block_hist);
     if (num_rendered > 0) {
         ProfileScope ps(ST_DUPLICATE, stream);
-        hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, tiles_touched, slot_base, rec, radii, gx, gy,
+        hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, total_counter, cap, tiles_touched, slot_base, rec, radii, gx, gy,
                            tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits);
-        hipLaunchKernelGGL(split_hist_kernel, dim3(nb), dim3(1024), lds_bytes, stream, num_rendered, T, chunk, emit_tile, block_hist);
+        hipLaunchKernelGGL(split_hist_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, block_hist);
         hipLaunchKernelGGL(split_colscan_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, nb, block_hist, tile_count);
     }
     {
@@ -726,7 +747,7 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     if (num_rendered > 0) {
         {
             ProfileScope ps(ST_DUPLICATE, stream);
-            hipLaunchKernelGGL(split_scatter_kernel, dim3(nb), dim3(1024), lds_bytes, stream, num_rendered, T, chunk, emit_tile, emit_depth,
+            hipLaunchKernelGGL(split_scatter_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, emit_depth,
                                entry_bits, block_hist, ranges, (uint32_t*)(bin + BL.scatter_keys), (uint32_t*)(bin + BL.scatter_vals));
         }
         const int n_local = (T - tile_rem + tile_mod - 1) / tile_mod;
@@ -758,6 +779,34 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     return num_rendered;
 }
 
+int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
+                         gsicp_resize_fn img_alloc, void* img_user, int P, int D, int M, const float* background, int width,
+                         int height, const float* means3D, const float* shs, const float* colors_precomp,
+                         const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                         float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
+                         int* is_used, int tile_mod, int tile_rem, int debug, void* stream) {
+    return raster_forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width, height,
+                               means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                               projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, radii, is_used, tile_mod,
+                               tile_rem, debug, 0, nullptr, stream);
+}
+
+int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
+                               gsicp_resize_fn img_alloc, void* img_user, int P, int D, int M, const float* background, int width,
+                               int height, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                               float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
+                               int* is_used, int tile_mod, int tile_rem, int debug, int capacity, unsigned int* num_rendered_dev,
+                               void* stream) {
+    if (capacity <= 0) { g_last_error = "gsicp_raster_forward_async: capacity must be positive"; return -2; }
+    return raster_forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width, height,
+                               means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                               projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, radii, is_used, tile_mod,
+                               tile_rem, debug, capacity, num_rendered_dev, stream);
+}
+
 size_t gsicp_raster_backward_scratch_bytes(int num_rendered, int width, int height) {
     (void)width; (void)height;
     const size_t R = num_rendered > 0 ? (size_t)num_rendered : 1;
@@ -781,6 +830,8 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     const GeomLayout GL = geom_layout(P);
     const BinLayout BL = bin_layout((size_t)num_rendered, (size_t)T);
     const ImgLayout IL = img_layout(width, height);
+    // num_rendered is the list capacity the forward ran with (== R on the synchronous path); the true R is on the device
+    const uint32_t* total_counter = (const uint32_t*)(img_buffer + IL.tile_count) + 2 * (size_t)T;
     float* slots = (float*)scratch;
     float* entry_sum = (float*)(scratch + align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * 4 * SLOT_F * sizeof(float)));
 
@@ -804,7 +855,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     }
     if (num_rendered > 0) {
         ProfileScope ps(ST_ENTRY_SUM, stream);
-        hipLaunchKernelGGL(entry_sum_kernel, dim3((num_rendered + 255) / 256), dim3(256), 0, stream, num_rendered,
+        hipLaunchKernelGGL(entry_sum_kernel, dim3((num_rendered + 255) / 256), dim3(256), 0, stream, total_counter, (uint32_t)num_rendered,
                            (const uint32_t*)(binning_buffer + BL.entry_bits), slots, entry_sum);
     }
 
@@ -817,6 +868,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     pb.entry_sum = entry_sum;
     pb.slot_base = (const uint32_t*)(geom_buffer + GL.slot_base);
     pb.tiles_touched = (const uint32_t*)(geom_buffer + GL.tiles_touched);
+    pb.total_counter = total_counter; pb.capacity = (uint32_t)(num_rendered > 0 ? num_rendered : 0);
     pb.dL_dmean2D = dL_dmeans2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
     pb.dL_ddepths = dL_ddepths;
     pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = dL_dsh; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;

@@ -100,6 +100,8 @@ struct PreprocessBwdArgs {
     const unsigned char* clamped;
     const float* entry_sum;        // (R, SLOT_F) per-emission-slot gradient sums (strips already added)
     const uint32_t *slot_base, *tiles_touched;
+    const uint32_t* total_counter;  // device R; above `capacity` the forward rendered nothing (async path overflow)
+    uint32_t capacity;
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolors, *dL_ddepths;   // (P,3) (P,4) (P) (P,3) (P): written here
     float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
 };

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
 #pragma unroll
     for (int c = 0; c < NGRAD; ++c) gs[c] = 0.f;
     {
-        const uint32_t n_slots = a.tiles_touched[i];
+        const uint32_t n_slots = (*a.total_counter > a.capacity) ? 0u : a.tiles_touched[i];
         const float4* es = (const float4*)a.entry_sum + 3 * (size_t)a.slot_base[i];
         for (uint32_t u = 0; u < n_slots; ++u) {
             const float4 p0 = es[3 * u], p1 = es[3 * u + 1], p2 = es[3 * u + 2];

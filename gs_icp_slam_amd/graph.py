@@ -1,0 +1,114 @@
+"""One mapper iteration as a replayable HIP graph.
+
+The reference's mapping loop [REF mp_Mapper.py:219-248] launches ~60 small kernels per iteration from Python (activations,
+rasteriser forward with a host round trip, loss chain, backward, Adam); at P = 300 k the GPU work is ~0.55 ms and the
+Python/launch path around it costs as much again.  With the sync-free forward (`GaussianRasterizationSettings.capacity`),
+the fused loss and the capturable fused Adam, nothing in the iteration needs the host, so the whole iteration is captured
+once (`torch.cuda.CUDAGraph`, i.e. hipGraph) and replayed with one launch per iteration.
+
+What changes from iteration to iteration in the reference — the keyframe: camera matrices and the two target images —
+lives in static device buffers that `set_view()` overwrites before `step()`.  Everything with a fixed address (parameters,
+Adam state, learning rates, step count) is updated in place by the replay.  The graph is valid while the parameter tensors
+are the ones captured: after the map grows or is pruned (new parameter tensors, [REF scene/gaussian_model.py:409-492]) build
+a new MapperIterationGraph — capture costs about three eager iterations.
+"""
+import torch
+
+from .loss import mapper_loss_parts
+from .optim import FusedAdam
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def default_activations(p):
+    """GaussianModel's property getters [REF scene/gaussian_model.py:105-125] on the raw parameter tensors."""
+    return dict(means3D=p["means3D"], shs=p["shs"], opacities=torch.sigmoid(p["opacities"]), scales=torch.exp(p["scales"]),
+                rotations=torch.nn.functional.normalize(p["rotations"]))
+
+
+class MapperIterationGraph:
+    """params: dict of raw leaf tensors (means3D, shs, opacities, scales, rotations) with requires_grad;
+    optimizer: FusedAdam(capturable=True) over them;  capacity: upper bound for the number of (Gaussian, tile) duplicates
+    (e.g. 1.5x the count of an eager forward; `overflowed()` tells when it was too small)."""
+
+    def __init__(self, params, optimizer, image_height, image_width, tanfovx, tanfovy, sh_degree, capacity, bg=None, lambda_dssim=0.2,
+                 depth_weight=0.1, d_max=10.0, activations=default_activations, rasterizer_factory=None, warmup=2):
+        if not isinstance(optimizer, FusedAdam) or not optimizer.capturable:
+            raise RuntimeError("MapperIterationGraph needs FusedAdam(capturable=True): a host-side step count cannot be replayed")
+        if capacity <= 0:
+            raise RuntimeError("MapperIterationGraph needs a positive duplicate-list capacity")
+        dev = params["means3D"].device
+        self.params, self.optimizer, self.activations = params, optimizer, activations
+        self.capacity = int(capacity)
+        self.lambda_dssim, self.depth_weight, self.d_max = float(lambda_dssim), float(depth_weight), float(d_max)
+        H, W = int(image_height), int(image_width)
+        f32 = dict(dtype=torch.float32, device=dev)
+        # static inputs of the captured iteration
+        self.viewmatrix = torch.eye(4, **f32)
+        self.projmatrix = torch.eye(4, **f32)
+        self.campos = torch.zeros(3, **f32)
+        self.gt_image = torch.zeros((3, H, W), **f32)
+        self.gt_depth = torch.zeros((1, H, W), **f32)
+        self.bg = torch.zeros(3, **f32) if bg is None else bg.to(**f32)
+        rs = GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=float(tanfovx), tanfovy=float(tanfovy), bg=self.bg, scale_modifier=1.0,
+            viewmatrix=self.viewmatrix, projmatrix=self.projmatrix, sh_degree=int(sh_degree), campos=self.campos, prefiltered=False,
+            debug=False, capacity=self.capacity)
+        self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
+        self._warmup = int(warmup)
+        self.graph = None
+        # static outputs
+        self.loss_parts = None      # tensor([loss, L1, SSIM mean, depth L1]) of the last replay
+        self.radii = None
+        self.is_used = None
+        self.num_rendered = None    # int32[1]: true duplicate count of the last replay
+
+    # ------------------------------------------------------------------------------------------------------------
+    def set_view(self, viewmatrix, projmatrix, campos, gt_image, gt_depth):
+        """Select the keyframe of the next step(): asynchronous device copies into the graph's static inputs."""
+        self.viewmatrix.copy_(viewmatrix, non_blocking=True)
+        self.projmatrix.copy_(projmatrix, non_blocking=True)
+        self.campos.copy_(campos.reshape(3), non_blocking=True)
+        self.gt_image.copy_(gt_image.reshape(self.gt_image.shape), non_blocking=True)
+        self.gt_depth.copy_(gt_depth.reshape(self.gt_depth.shape), non_blocking=True)
+
+    def _iteration(self):
+        a = self.activations(self.params)
+        means2D = torch.zeros_like(a["means3D"], requires_grad=True)
+        depth, color, radii, used = self.rasterizer(means3D=a["means3D"], means2D=means2D, shs=a["shs"], opacities=a["opacities"],
+                                                    scales=a["scales"], rotations=a["rotations"])
+        loss, parts = mapper_loss_parts(color, depth, self.gt_image, self.gt_depth, lambda_dssim=self.lambda_dssim,
+                                        depth_weight=self.depth_weight, d_max=self.d_max)
+        loss.backward()
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        return parts, radii, used
+
+    def capture(self):
+        dev = self.params["means3D"].device
+        self.optimizer.zero_grad(set_to_none=True)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):          # eager warm-up on a side stream (allocator pools, lr array, Adam state)
+            for _ in range(max(self._warmup, 1)):
+                self._iteration()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            parts, radii, used = self._iteration()
+        self.loss_parts, self.radii, self.is_used = parts, radii, used
+        self.num_rendered = self.rasterizer.num_rendered if hasattr(self.rasterizer, "num_rendered") else None
+        if self.num_rendered is None and hasattr(self.rasterizer, "inner"):
+            self.num_rendered = self.rasterizer.inner.num_rendered
+        return self
+
+    def step(self):
+        """Replay one iteration (one graph launch).  Returns the static loss tensor (0-dim view; read it when needed)."""
+        if self.graph is None:
+            self.capture()
+        self.graph.replay()
+        return self.loss_parts[0]
+
+    def overflowed(self):
+        """True when the last replay produced more duplicates than the capacity (it then rendered nothing).  Synchronises."""
+        return self.num_rendered is not None and int(self.num_rendered.item()) > self.capacity

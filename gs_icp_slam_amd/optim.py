@@ -4,6 +4,11 @@ that GaussianModel builds [REF scene/gaussian_model.py:222-231] and the mapper s
 State layout is torch's (`state[p] = {"step", "exp_avg", "exp_avg_sq"}`), because GaussianModel edits the optimiser state
 in place when it appends or prunes Gaussians [REF scene/gaussian_model.py:409-492].  amsgrad / weight decay / maximize are
 not supported (the reference does not use them).
+
+``capturable=True`` (same meaning as torch.optim.Adam's flag) keeps the step count and the learning rates in device
+memory, so that ``step()`` can be captured in a HIP graph and replayed (gs_icp_slam_amd/graph.py).  ``state[p]["step"]``
+is then an int32 device tensor shared by the parameters that were first stepped together; after changing a group's
+``lr`` call ``sync_lr()`` (outside capture) to push the new values to the device.
 """
 import ctypes
 
@@ -15,8 +20,66 @@ _MAX = 8
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.capturable = bool(capturable)
+        self._lr_dev = {}       # bucket key -> (device float tensor, list of host lr values it holds)
+
+    def sync_lr(self):
+        """Push the param groups' current learning rates to the device arrays of the capturable path."""
+        lr_of = {id(p): float(g["lr"]) for g in self.param_groups for p in g["params"]}
+        for key, (t, plist, vals) in list(self._lr_dev.items()):
+            new = [lr_of.get(i, v) for i, v in zip(plist, vals)]
+            if new != vals:
+                t.copy_(torch.tensor(new, dtype=torch.float32))
+                self._lr_dev[key] = (t, plist, new)
+
+    def _step_capturable(self, lib):
+        buckets = {}   # (beta1, beta2, eps, id(step tensor)) -> list of (p, g, m, v, lr)
+        fresh = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("FusedAdam(capturable): parameters and gradients must be contiguous float32 on the HIP device")
+                st = self.state[p]
+                if len(st) == 0:
+                    if p.device not in fresh:
+                        fresh[p.device] = torch.zeros((), dtype=torch.int32, device=p.device)
+                    st["step"] = fresh[p.device]
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                elif not torch.is_tensor(st["step"]):
+                    st["step"] = torch.full((), int(st["step"]), dtype=torch.int32, device=p.device)
+                buckets.setdefault((float(b1), float(b2), float(group["eps"]), st["step"].data_ptr()), []).append(
+                    (p, p.grad, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), st["step"]))
+        capturing = torch.cuda.is_current_stream_capturing()
+        for (b1, b2, eps, _sp), items in buckets.items():
+            if len(items) > _MAX:
+                raise RuntimeError("FusedAdam(capturable): more than 8 tensors share one step counter")
+            dev = items[0][0].device
+            key = (b1, b2, eps, _sp, tuple(id(t[0]) for t in items))
+            lrs = [t[4] for t in items]
+            if key not in self._lr_dev:
+                if capturing:
+                    raise RuntimeError("FusedAdam(capturable): run one step() outside graph capture first (allocates the device lr array)")
+                self._lr_dev[key] = (torch.tensor(lrs, dtype=torch.float32).to(dev), [id(t[0]) for t in items], lrs)
+            elif not capturing and self._lr_dev[key][2] != lrs:
+                self._lr_dev[key][0].copy_(torch.tensor(lrs, dtype=torch.float32))
+                self._lr_dev[key] = (self._lr_dev[key][0], self._lr_dev[key][1], lrs)
+            lr_dev = self._lr_dev[key][0]
+            with torch.cuda.device(dev):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                n = len(items)
+                P = (ctypes.c_void_p * n)(*[t[0].data_ptr() for t in items])
+                G = (ctypes.c_void_p * n)(*[t[1].data_ptr() for t in items])
+                M = (ctypes.c_void_p * n)(*[t[2].data_ptr() for t in items])
+                V = (ctypes.c_void_p * n)(*[t[3].data_ptr() for t in items])
+                N = (ctypes.c_longlong * n)(*[t[0].numel() for t in items])
+                _lib.check(lib.gsicp_adam_step_capturable(n, P, G, M, V, N, ctypes.c_void_p(lr_dev.data_ptr()), b1, b2, eps,
+                                                          ctypes.c_void_p(items[0][5].data_ptr()), stream), "gsicp_adam_step_capturable")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -25,6 +88,9 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        if self.capturable:
+            self._step_capturable(lib)
+            return loss
         buckets = {}   # (beta1, beta2, eps, step, device) -> list of (p, g, m, v, lr)
         for group in self.param_groups:
             b1, b2 = group["betas"]

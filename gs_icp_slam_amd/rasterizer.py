@@ -35,6 +35,10 @@ class GaussianRasterizationSettings(NamedTuple):
     # Extension (not in the reference): blend only tiles with tile_id % tile_mod == tile_rem (multi-GPU sharding).
     tile_mod: int = 1
     tile_rem: int = 0
+    # Extension: duplicate-list capacity.  0 = size the lists by reading the count back (one host sync, the reference's
+    # behaviour); > 0 = sync-free forward (HIP-graph capturable); GaussianRasterizer.num_rendered then holds the true
+    # count on the device, and a count above the capacity renders nothing (see include/gsicp_hip.h).
+    capacity: int = 0
 
 
 def _ptr(t):
@@ -62,14 +66,15 @@ class _Scratch:
         return self.tensor.data_ptr()
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        count_out=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+                                     raster_settings, count_out)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, count_out=None):
         lib = _lib.load()
         if not means3D.is_cuda:
             raise RuntimeError("diff_gaussian_rasterization (gfx950): tensors must live on the HIP device; there is no CPU path")
@@ -97,11 +102,17 @@ class _RasterizeGaussians(torch.autograd.Function):
             is_used = torch.empty((P,), dtype=torch.int32, device=dev)
             geom, binning, img = _Scratch(dev), _Scratch(dev), _Scratch(dev)
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            n = lib.gsicp_raster_forward(
-                geom.cb, None, binning.cb, None, img.cb, None, P, int(rs.sh_degree), int(M), _ptr(bg), W, H, _ptr(means3D),
-                _ptr(sh_c), _ptr(col_c), _ptr(op_c), _ptr(sc_c), float(rs.scale_modifier), _ptr(rot_c), _ptr(cov_c), _ptr(view),
-                _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)), _ptr(color),
-                _ptr(depth), _ptr(radii), _ptr(is_used), int(rs.tile_mod), int(rs.tile_rem), int(bool(rs.debug)), stream)
+            args = (geom.cb, None, binning.cb, None, img.cb, None, P, int(rs.sh_degree), int(M), _ptr(bg), W, H, _ptr(means3D),
+                    _ptr(sh_c), _ptr(col_c), _ptr(op_c), _ptr(sc_c), float(rs.scale_modifier), _ptr(rot_c), _ptr(cov_c), _ptr(view),
+                    _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)), _ptr(color),
+                    _ptr(depth), _ptr(radii), _ptr(is_used), int(rs.tile_mod), int(rs.tile_rem), int(bool(rs.debug)))
+            capacity = int(getattr(rs, "capacity", 0) or 0)
+            if capacity > 0 and P > 0:
+                n = lib.gsicp_raster_forward_async(*args, capacity, _ptr(count_out), stream)
+            else:
+                n = lib.gsicp_raster_forward(*args, stream)
+                if count_out is not None:
+                    count_out.fill_(max(int(n), 0))
             _lib.check(n, "gsicp_raster_forward")
         ctx.rs = rs
         ctx.num_rendered = n
@@ -146,13 +157,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                 int(bool(rs.debug)), stream)
             _lib.check(rc, "gsicp_raster_backward")
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors if col_c is not None else None, dL_dopacity, dL_dscales, dL_drots,
-                dL_dcov3D if cov_c is not None else None, None)
+                dL_dcov3D if cov_c is not None else None, None, None)
 
 
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
         self.raster_settings = raster_settings
+        self.num_rendered = None   # int32[1] device tensor: (Gaussian, tile) duplicates of the last forward (extension)
 
     def markVisible(self, positions):
         lib = _lib.load()
@@ -175,4 +187,7 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+        if getattr(rs, "capacity", 0) and (self.num_rendered is None or self.num_rendered.device != means3D.device):
+            self.num_rendered = torch.zeros(1, dtype=torch.int32, device=means3D.device)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs,
+                                   self.num_rendered if getattr(rs, "capacity", 0) else None)

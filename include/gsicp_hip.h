@@ -67,6 +67,24 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
                          const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                          float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug, void* stream);
 
+/* Same forward without the host round trip (extension; no reference counterpart — the reference always reads
+ * num_rendered back, [REF submodules/diff-gaussian-rasterization: rasterizer_impl forward] behind
+ * gaussian_renderer/__init__.py:294): the caller states the duplicate-list `capacity`, every buffer and launch is
+ * sized by it and the kernels read the true count R from device memory.  Nothing in the call synchronises, allocates
+ * outside the callbacks or copies to the host, so it can be captured in a HIP graph together with the backward.
+ *   num_rendered_dev: DEVICE uint32 that receives R (may be NULL).  If R > capacity the call renders nothing
+ *   (background colour, zero depth, zero gradients) — the caller detects it by reading num_rendered_dev later and
+ *   repeats with a larger capacity.
+ * Returns `capacity`; pass that value as `num_rendered` to gsicp_raster_backward_scratch_bytes / gsicp_raster_backward. */
+int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
+                               gsicp_resize_fn img_alloc, void* img_user, int P, int D, int M, const float* background,
+                               int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                               const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                               float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug,
+                               int capacity, unsigned int* num_rendered_dev, void* stream);
+
 /* Bytes of DEVICE scratch gsicp_raster_backward needs (per-(list entry, strip) gradient slots; contents need no
  * initialisation and are dead after the call). */
 size_t gsicp_raster_backward_scratch_bytes(int num_rendered, int width, int height);
@@ -180,6 +198,14 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
  * after the increment (bias corrections 1 - beta^step). */
 int gsicp_adam_step(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                     const long long* numel, const float* lr, float beta1, float beta2, float eps, int step, void* stream);
+
+/* The same step with the step count and the learning rates in DEVICE memory (the counterpart of
+ * torch.optim.Adam(capturable=True)): `lr_dev` is a DEVICE float array of n_groups learning rates, `step_dev` a DEVICE
+ * int holding the number of steps taken so far; the call applies step *step_dev + 1 and then increments it.  No host
+ * value other than the pointers is baked into the launches, so a captured HIP graph replays correctly. */
+int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const long long* numel, const float* lr_dev, float beta1, float beta2,
+                               float eps, int* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

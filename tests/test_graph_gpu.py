@@ -1,0 +1,163 @@
+"""GPU tests of the sync-free forward (capacity mode), the capturable Adam and the captured mapper iteration: each must
+reproduce the synchronous / eager path, which the other test files pin against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gs_icp_slam_amd import synth
+from tests.util import make_settings, torch_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(P=20000, W=320, H=200, seed=5):
+    cfg = dict(synth.REPLICA)
+    cam = synth.make_camera(W, H, cfg["fx"] * W / cfg["W"], cfg["fy"] * H / cfg["H"], synth.DEFAULT_POSE_A)
+    cam["fx"], cam["fy"] = cfg["fx"] * W / cfg["W"], cfg["fy"] * H / cfg["H"]
+    g = synth.s_map(P, seed=seed)
+    return g, cam
+
+
+def _render(rs, t, seed=0):
+    from diff_gaussian_rasterization import GaussianRasterizer
+    rast = GaussianRasterizer(rs)
+    means2D = torch.zeros_like(t["means3D"], requires_grad=True)
+    depth, color, radii, used = rast(means3D=t["means3D"], means2D=means2D, shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
+                                     rotations=t["rotations"])
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    wc = torch.rand(color.shape, device="cuda", generator=gen)
+    wd = torch.rand(depth.shape, device="cuda", generator=gen)
+    ((color * wc).sum() + (depth * wd).sum()).backward()
+    grads = {k: v.grad.clone() for k, v in t.items() if v.grad is not None}
+    grads["means2D"] = means2D.grad.clone()
+    for v in t.values():
+        v.grad = None
+    return depth.detach(), color.detach(), radii, used, grads, rast
+
+
+def test_async_forward_backward_equals_synchronous_path():
+    g, cam = _scene()
+    t = torch_inputs(g, requires_grad=True)
+    rs = make_settings(cam, [0.1, 0.2, 0.3])
+    d0, c0, r0, u0, g0, rast0 = _render(rs, t)
+    node_R = int((r0 > 0).sum())
+    assert node_R > 0
+    for capacity in (4_000_000, 1_000_003):    # different capacities -> different split-block counts, same result
+        d1, c1, r1, u1, g1, rast1 = _render(rs._replace(capacity=capacity), t)
+        R = int(rast1.num_rendered.item())
+        assert 0 < R <= capacity
+        assert torch.equal(d0, d1) and torch.equal(c0, c1) and torch.equal(r0, r1) and torch.equal(u0, u1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+
+
+def test_async_overflow_renders_nothing_and_reports_the_count():
+    g, cam = _scene()
+    t = torch_inputs(g, requires_grad=True)
+    rs = make_settings(cam, [0.1, 0.2, 0.3])
+    *_, rast_big = _render(rs._replace(capacity=4_000_000), t)
+    R = int(rast_big.num_rendered.item())
+    d, c, r, u, grads, rast = _render(rs._replace(capacity=R - 1), t)
+    assert int(rast.num_rendered.item()) == R                  # the caller sees the true count and can retry
+    assert torch.all(d == 0) and torch.all(u == 0)
+    assert torch.allclose(c, torch.tensor([0.1, 0.2, 0.3], device="cuda").view(3, 1, 1).expand_as(c))
+    for k, v in grads.items():
+        assert torch.all(v == 0), k
+    # exactly at capacity is fine
+    d2, c2, *_ = _render(rs._replace(capacity=R), t)
+    d0, c0, *_ = _render(rs, t)
+    assert torch.equal(d0, d2) and torch.equal(c0, c2)
+
+
+def test_capturable_adam_equals_host_step_adam():
+    from gs_icp_slam_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(1000, 3), (1000, 1, 3), (1000, 1), (1000, 4)]
+    lrs = [1e-3, 2.5e-3, 0.05, 1e-3]
+    p_a = [torch.randn(s, device="cuda", requires_grad=True) for s in shapes]
+    p_b = [p.detach().clone().requires_grad_(True) for p in p_a]
+    oa = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(p_a, lrs)], lr=0.0, eps=1e-15)
+    ob = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(p_b, lrs)], lr=0.0, eps=1e-15, capturable=True)
+    for it in range(12):
+        if it == 6:                       # learning-rate change is picked up by both
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 5e-3
+            ob.sync_lr()
+        for pa, pb in zip(p_a, p_b):
+            gr = torch.randn_like(pa)
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    assert int(ob.state[p_b[0]]["step"].item()) == 12
+    for pa, pb in zip(p_a, p_b):
+        torch.testing.assert_close(pa, pb, rtol=2e-6, atol=1e-8)
+
+
+def _mapper_setup(P, W, H, capturable):
+    from gs_icp_slam_amd.optim import FusedAdam
+    g, cam = _scene(P, W, H)
+    raw = {"means3D": torch.from_numpy(g["means3D"]), "scales": torch.log(torch.from_numpy(g["scales"])),
+           "rotations": torch.from_numpy(g["rotations"]), "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-4, 1 - 1e-4)),
+           "shs": torch.from_numpy(g["shs"])}
+    params = {k: v.cuda().contiguous().requires_grad_(True) for k, v in raw.items()}
+    lrs = {"means3D": 4e-6, "shs": 2.5e-3, "opacities": 0.05, "scales": 5e-3, "rotations": 1e-3}
+    opt = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in lrs.items()], lr=0.0, eps=1e-15, capturable=capturable)
+    return g, cam, params, opt
+
+
+def test_captured_iteration_equals_eager_iterations():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gs_icp_slam_amd.graph import MapperIterationGraph, default_activations
+    from gs_icp_slam_amd.loss import mapper_loss_parts
+    P, W, H = 20000, 320, 200
+    g, cam, params_e, opt_e = _mapper_setup(P, W, H, capturable=False)
+    _, _, params_g, opt_g = _mapper_setup(P, W, H, capturable=True)
+    rs = make_settings(cam, [0.0, 0.0, 0.0])
+    # two keyframes (views + targets): targets rendered from a perturbed map
+    views = []
+    for pose_seed in (0, 1):
+        pose = synth.DEFAULT_POSE_A if pose_seed == 0 else synth.se3((12.5, 27.0, 0.5), (-0.88, -0.22, -1.08))
+        cam_k = synth.make_camera(W, H, cam["fx"], cam["fy"], pose)
+        rs_k = make_settings(cam_k, [0.0, 0.0, 0.0])
+        g2 = synth.s_map(P, seed=5, perturb_seed=7)
+        t2 = torch_inputs(g2)
+        with torch.no_grad():
+            d, c, _, _ = GaussianRasterizer(rs_k)(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"],
+                                                  opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
+        views.append((rs_k, c.clone(), d.clone()))
+    schedule = [0, 0, 1, 0, 1, 1]    # first two = the graph's eager warm-up iterations (real optimiser steps)
+
+    losses_e = []
+    for k in schedule:
+        rs_k, gt_c, gt_d = views[k]
+        a = default_activations(params_e)
+        m2 = torch.zeros_like(a["means3D"], requires_grad=True)
+        depth, color, _, _ = GaussianRasterizer(rs_k)(means3D=a["means3D"], means2D=m2, shs=a["shs"], opacities=a["opacities"],
+                                                      scales=a["scales"], rotations=a["rotations"])
+        loss, parts = mapper_loss_parts(color, depth, gt_c, gt_d)
+        loss.backward()
+        opt_e.step()
+        opt_e.zero_grad(set_to_none=True)
+        losses_e.append(float(loss))
+
+    mg = MapperIterationGraph(params_g, opt_g, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=2_000_000, warmup=2)
+    rs0, c0, d0 = views[0]
+    mg.set_view(rs0.viewmatrix, rs0.projmatrix, rs0.campos, c0, d0)
+    mg.capture()                      # 2 warm-up iterations on view 0, then capture (capture itself executes nothing)
+    losses_g = []
+    for k in schedule[2:]:
+        rs_k, gt_c, gt_d = views[k]
+        mg.set_view(rs_k.viewmatrix, rs_k.projmatrix, rs_k.campos, gt_c, gt_d)
+        losses_g.append(float(mg.step()))
+        assert not mg.overflowed()
+    np.testing.assert_allclose(losses_g, losses_e[2:], rtol=1e-5)
+    assert int(opt_g.state[params_g["means3D"]]["step"].item()) == len(schedule)
+    for k in params_e:
+        torch.testing.assert_close(params_g[k], params_e[k], rtol=1e-4, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_graph_rejects_host_step_optimizer():
+    from gs_icp_slam_amd.graph import MapperIterationGraph
+    g, cam, params, opt = _mapper_setup(1000, 64, 48, capturable=False)
+    with pytest.raises(RuntimeError):
+        MapperIterationGraph(params, opt, 48, 64, cam["tanfovx"], cam["tanfovy"], 0, capacity=1000)
