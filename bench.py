@@ -185,6 +185,8 @@ def main():
             T, idx, d2 = tracker_step(reg)
             loss, radii = mapper_iteration()
         last.update(T=T, loss=loss, radii=radii)
+        if mg is not None and os.environ.get("GSICP_DEBUG_R"):
+            print("R", int(mg.num_rendered.item()), "cap", mg.capacity, "loss", float(loss), file=sys.stderr)
 
     def barrier():
         if world > 1:
@@ -193,7 +195,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    _lib.profile_enable(True)
+    _lib.profile_enable(not os.environ.get("GSICP_DEBUG_NOPROF"))
     _lib.profile_read()
     barrier()
     prof_py = None
@@ -217,7 +219,7 @@ def main():
         # kernels inside a replayed graph carry no HIP events: time the SAME kernels on the same inputs in eager iterations
         # right after the timed region (rocprofv3's kernel trace of this command sees both and agrees — profiles/README.md)
         if mg.overflowed():
-            raise RuntimeError("duplicate-list capacity overflowed during the timed region")
+            raise RuntimeError(f"duplicate-list capacity overflowed during the timed region: R = {int(mg.num_rendered.item())} > {mg.capacity}")
         n_e = max(5, min(args.steps, 20))
         eager_iteration()
         torch.cuda.synchronize()

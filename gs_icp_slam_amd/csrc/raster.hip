@@ -91,6 +91,16 @@ __device__ inline int device_R(const uint32_t* __restrict__ total, uint32_t cap)
     return r > cap ? 0 : (int)r;
 }
 
+// Zero fill of the per-call counters and of is_used, as a kernel: memset / memcpy NODES inside a replayed hipGraph proved
+// unreliable on this stack (the counter region came back holding a constant garbage value after a device synchronise),
+// so the capturable path contains kernel nodes only.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t* __restrict__ a, size_t na, uint32_t* __restrict__ b, size_t nb) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na; i += stride) a[i] = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += stride) b[i] = 0u;
+}
+__global__ void publish_count_kernel(const uint32_t* __restrict__ total, uint32_t* __restrict__ out) { *out = total ? *total : 0u; }
+
 // ------------------------------------------------------------------------------------------------ binning
 // Single workgroup: exclusive scan of the per-tile duplicate counts -> list ranges, and an LPT dispatch order by a
 // counting sort over 64 length buckets (exact ordering is not needed for load balance).  Any T; one launch.
@@ -680,8 +690,12 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     uint32_t* tiles_touched = (uint32_t*)(geom + GL.tiles_touched);
     uint32_t* slot_base = (uint32_t*)(geom + GL.slot_base);
 
-    GS_CHECK(hipMemsetAsync(tile_count, 0, ((size_t)2 * T + 64) * 4, stream));
-    if (is_used && P > 0) GS_CHECK(hipMemsetAsync(is_used, 0, (size_t)P * 4, stream));
+    {
+        const size_t n_used = (is_used && P > 0) ? (size_t)P : 0;
+        size_t blocks = (n_used + (size_t)2 * T + 64 + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tile_count, (size_t)2 * T + 64, (uint32_t*)is_used, n_used);
+    }
 
     int num_rendered = 0;
     if (P > 0) {
@@ -704,10 +718,10 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
             if (total > ID_MASK) { g_last_error = "more than 2^28 (Gaussian, tile) duplicates are not supported"; return -2; }
             num_rendered = (int)total;
         }
-        if (num_rendered_dev) GS_CHECK(hipMemcpyAsync(num_rendered_dev, total_counter, 4, hipMemcpyDeviceToDevice, stream));
+        if (num_rendered_dev) hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(1), 0, stream, total_counter, num_rendered_dev);
     } else {
         GS_CHECK(hipStreamSynchronize(stream));
-        if (num_rendered_dev) GS_CHECK(hipMemsetAsync(num_rendered_dev, 0, 4, stream));
+        if (num_rendered_dev) hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)nullptr, num_rendered_dev);
     }
     const uint32_t cap = (uint32_t)num_rendered;
 

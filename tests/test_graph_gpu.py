@@ -154,6 +154,13 @@ def test_captured_iteration_equals_eager_iterations():
     assert int(opt_g.state[params_g["means3D"]]["step"].item()) == len(schedule)
     for k in params_e:
         torch.testing.assert_close(params_g[k], params_e[k], rtol=1e-4, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+    # regression: replays after a full device synchronise (memset nodes in the graph once came back with garbage here)
+    torch.cuda.synchronize()
+    for _ in range(8):
+        loss = mg.step()
+    torch.cuda.synchronize()
+    assert not mg.overflowed() and 0 < int(mg.num_rendered.item()) < 2_000_000
+    assert float(loss) < losses_g[-1]
 
 
 def test_graph_rejects_host_step_optimizer():

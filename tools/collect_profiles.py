@@ -1,0 +1,117 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/<tag>/ (written by tools/capture_profiles.sh on the GPU box) into the tracked files profiles/<tag>_*.
+
+  <tag>_bench.json, _bench_tum.json, _bench_eager.json, _bench_under_rocprof.json   the bench lines
+  <tag>_rocprofv3_kernel_stats.csv    rocprofv3 --kernel-trace --stats, kernel names shortened
+  <tag>_rocprofv3_pmc_hbm_traffic.csv, <tag>_pmc_traffic.json   FETCH_SIZE / WRITE_SIZE (KiB -> bytes) per launch
+  <tag>_rocprofv3_pmc_sq.csv          SQ_* counters per launch (mean)
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STAGE_OF = {"blend_backward_strip_kernel": "blend_backward", "blend_forward_strip_kernel": "blend_forward",
+            "entry_sum_kernel": "entry_grad_sum", "preprocess_backward_kernel": "preprocess_backward",
+            "preprocess_kernel": "preprocess", "tile_scan_lpt_kernel": "tile_scan_lpt"}
+
+
+def short(name):
+    name = name.strip().strip('"').replace("(anonymous namespace)::", "").replace("gsicp::", "")
+    name = re.sub(r"^void\s+", "", name)
+    depth, cut = 0, len(name)
+    for i, ch in enumerate(name):          # drop the argument list: first "(" outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    name = name[:cut].strip()
+    if "<" in name and not name.startswith("tile_sort_kernel"):
+        head, tail = name.split("<", 1)
+        if head.startswith("at::") or head.startswith("rocprim"):
+            m = re.search(r"(\w+Functor|\w+_functor|\w+Op)\b", tail)
+            name = head + ("<" + m.group(1) + ">" if m else "")
+        else:
+            name = head
+    return name.replace(",", ";")
+
+
+def find(d, pattern):
+    hits = sorted(glob.glob(os.path.join(d, "**", pattern), recursive=True))
+    return hits[0] if hits else None
+
+
+def last_json_line(path):
+    if not os.path.exists(path):
+        return None
+    for line in reversed(open(path).read().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    return None
+
+
+def pmc_means(d):
+    """kernel -> counter -> mean value per launch"""
+    f = find(d, "*counter_collection.csv")
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    if not f:
+        return {}
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            a = acc[short(row["Kernel_Name"])][row["Counter_Name"]]
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
+    return {k: {c: s / n for c, (s, n) in v.items()} for k, v in acc.items()}
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    for name in ("bench", "bench_tum", "bench_eager", "bench_under_rocprof"):
+        j = last_json_line(os.path.join(src, name + ".json"))
+        if j is not None:
+            json.dump(j, open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
+            print(name, j["value"], j["unit"], j["ms_per_step"], "ms/step")
+    ks = find(os.path.join(src, "kt"), "*kernel_stats.csv")
+    if ks:
+        rows = list(csv.DictReader(open(ks)))
+        with open(os.path.join(dst, f"{tag}_rocprofv3_kernel_stats.csv"), "w") as fh:
+            fh.write("kernel,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+            for r in rows:
+                fh.write(",".join([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
+                                   r["MaxNs"], r["StdDev"]]) + "\n")
+        print("kernel stats:", len(rows), "kernels")
+    fetch, write = pmc_means(os.path.join(src, "fetch")), pmc_means(os.path.join(src, "write"))
+    if fetch or write:
+        traffic = {}
+        with open(os.path.join(dst, f"{tag}_rocprofv3_pmc_hbm_traffic.csv"), "w") as fh:
+            fh.write("kernel,fetch_bytes_per_launch,write_bytes_per_launch\n")
+            for k in sorted(set(fetch) | set(write)):
+                fb = int(fetch.get(k, {}).get("FETCH_SIZE", 0.0) * 1024)
+                wb = int(write.get(k, {}).get("WRITE_SIZE", 0.0) * 1024)
+                fh.write(f"{k},{fb},{wb}\n")
+                if k in STAGE_OF:
+                    traffic[STAGE_OF[k]] = {"fetch_bytes": fb, "write_bytes": wb, "kernel": k}
+        json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+        print("traffic:", {k: (v["fetch_bytes"] + v["write_bytes"]) // 1000000 for k, v in traffic.items()}, "MB")
+    sq = pmc_means(os.path.join(src, "sq"))
+    if sq:
+        cols = sorted({c for v in sq.values() for c in v})
+        with open(os.path.join(dst, f"{tag}_rocprofv3_pmc_sq.csv"), "w") as fh:
+            fh.write("kernel," + ",".join(cols) + "\n")
+            for k in sorted(sq):
+                fh.write(k + "," + ",".join(f"{sq[k].get(c, 0.0):.1f}" for c in cols) + "\n")
+        print("sq counters:", len(sq), "kernels")
+
+
+if __name__ == "__main__":
+    main()
