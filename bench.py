@@ -6,7 +6,7 @@ One "step" = one SLAM frame's worth of the hot path on synthetic Replica-shaped 
             on S-pair (8 280 points/frame, max_correspondence_distance 0.02)          [REF mp_Tracker.py:191-231]
   mapper  : one full optimisation iteration — activations, GaussianRasterizer forward, the mapping loss
             0.8 L1 + 0.2 (1-SSIM) + 0.1 L1(depth/10) (fused HIP kernel), backward, Adam step over the parameter groups
-            (fused HIP kernel), zero_grad; P = 300 000 surfels, 1200x680                 [REF mp_Mapper.py:219-248]
+            (fused HIP kernel), zero_grad; activations fused; P = 300 000 surfels, 1200x680                 [REF mp_Mapper.py:219-248]
 With N > 1 GPUs the mapper's tiles are sharded across ranks (strong scaling; gs_icp_slam_amd/sharded.py) and the
 tracker runs as a replica on every rank (it does not shard — DESIGN.md).
 
@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--serial", action="store_true", help="run tracker and mapper back-to-back on one thread (default: concurrently, as the\n                    reference runs them in two processes)")
     ap.add_argument("--no-graph", action="store_true", help="drive the mapper iteration eagerly from Python instead of replaying the captured\n                    HIP graph (N > 1 always runs eagerly)")
+    ap.add_argument("--only", choices=["tracker", "mapper"], default=None, help="diagnostics: run only one half of the step (the JSON line is then\n                    NOT the contract metric)")
     ap.add_argument("--pyprofile", default=None, help="write a cProfile of the timed region to this file (diagnostics)")
     args = ap.parse_args()
 
@@ -133,9 +134,11 @@ def main():
         worker = threading.Thread(target=tracker_worker, daemon=True)
         worker.start()
 
-    def activated():
-        return dict(means3D=params["means3D"], shs=params["shs"], opacities=torch.sigmoid(params["opacities"]),
-                    scales=torch.exp(params["scales"]), rotations=torch.nn.functional.normalize(params["rotations"]))
+    from gs_icp_slam_amd.activations import activate
+
+    def activated():   # GaussianModel.get_opacity / get_scaling / get_rotation [REF scene/gaussian_model.py:105-125], one fused launch
+        o, s_, q = activate(params["opacities"], params["scales"], params["rotations"])
+        return dict(means3D=params["means3D"], shs=params["shs"], opacities=o, scales=s_, rotations=q)
 
     def mapper_iteration():
         """One iteration of Mapper.mapping [REF mp_Mapper.py:219-248]: render_3 -> loss -> backward -> Adam step -> zero_grad."""
@@ -177,6 +180,14 @@ def main():
             return mg.step(), mg.radii
 
     def step():
+        if args.only == "tracker":
+            T, idx, d2 = tracker_step(reg)
+            last.update(T=T)
+            return
+        if args.only == "mapper":
+            loss, radii = mapper_iteration()
+            last.update(loss=loss, radii=radii)
+            return
         if worker is not None:
             jobs.put(1)
             loss, radii = mapper_iteration()
@@ -309,7 +320,8 @@ def main():
         ms = 1e3 * dt / args.steps
         stage_us = {k: round(v, 2) for k, v in per_launch_us.items()}
         out = {
-            "metric": "SLAM hot-path FPS (GICP tracker frame + one full mapper iteration: render, loss, backward, Adam), Replica room0-shaped synthetic",
+            "metric": ("SLAM hot-path FPS (GICP tracker frame + one full mapper iteration: render, loss, backward, Adam), Replica room0-shaped synthetic"
+                       if args.only is None else f"DIAGNOSTIC: {args.only} half only"),
             "value": round(args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",

@@ -41,6 +41,9 @@ SIGNATURES = {
     "gsicp_mapper_loss_scratch_bytes": (c_size_t, [c_int, c_int]),
     "gsicp_mapper_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
+    "gsicp_mapper_activations_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsicp_mapper_activations_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p]),
     "gsicp_adam_step": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_int,
                                 c_void_p]),
     "gsicp_adam_step_capturable": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
@@ -68,6 +71,7 @@ SIGNATURES = {
     "gsicp_gicp_set_target_covariances_fromqs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "gsicp_gicp_align": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gsicp_gicp_get_source_correspondence": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "gsicp_gicp_knn_stats": (c_int, [c_void_p, c_void_p]),
     "gsicp_gicp_num_source": (c_int, [c_void_p]),
     "gsicp_gicp_num_target": (c_int, [c_void_p]),
     "gsicp_gicp_last_align_stats": (c_int, [c_void_p, c_void_p]),

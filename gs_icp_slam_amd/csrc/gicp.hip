@@ -24,6 +24,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -236,60 +238,283 @@ __device__ inline bool lex_less(float d, int i, float d2, int i2) { return d < d
 __device__ inline float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ inline int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xF, 0xF, false); }  // lane l <- lane l-1
 
-__global__ __launch_bounds__(256) void knn_cov_kernel(int n, int k, int batch_stride, const float4* __restrict__ pts,
-                                                      int* __restrict__ nbr_idx, float* __restrict__ nbr_d2) {
+// ---- exact k-NN over a uniform grid -----------------------------------------------------------------------------
+// The brute-force scan above costs n/64 batches per query (130 at n = 8 280).  A counting sort of the cloud into grid
+// cells (dense cell_start table, all on the device) lets a query look only at the (2r+1)^3 cells around it: each (y,z) row
+// of that cube is ONE contiguous range of the sorted array.  The answer stays exact: after ring r the k-th distance must be
+// below the distance to the nearest face of the scanned cube, otherwise the ring grows (r <= KNN_RMAX), and past that the
+// query falls back to scanning every point.  The result does not depend on the visiting order (total order on (d2, index)).
+constexpr int KNN_MAX_CELLS = 1 << 18;
+#ifndef KNN_H_AREA
+#define KNN_H_AREA 2.5f                     // cell edge in units of the estimated point spacing (surface / volume model)
+#define KNN_H_VOL 1.4f
+#endif
+struct KnnGrid {
+    float ox, oy, oz, h, inv_h;
+    int nx, ny, nz, ncells;
+    unsigned ring_hist[5];   // diagnostics: queries settled by whole-grid coverage [0], after ring 1 / 2 [1], [2], by the full scan [4]
+};
+
+// single workgroup: bounding box -> grid parameters, and clears the cell counters
+__global__ __launch_bounds__(1024) void knn_grid_params_kernel(int n, const float4* __restrict__ pts, float h_area, float h_vol,
+                                                               KnnGrid* __restrict__ gp, unsigned* __restrict__ cell_count) {
+    __shared__ float s_lo[3][16], s_hi[3][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = pts[i];
+        lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+        if (lane == 0) { s_lo[d][wave] = lo[d]; s_hi[d][wave] = hi[d]; }
+    }
+    __syncthreads();
+    __shared__ int s_ncells;
+    if (tid == 0) {
+        float L[3], E[3];
+        for (int d = 0; d < 3; ++d) {
+            float l = s_lo[d][0], u = s_hi[d][0];
+            for (int w = 1; w < 16; ++w) { l = fminf(l, s_lo[d][w]); u = fmaxf(u, s_hi[d][w]); }
+            L[d] = l; E[d] = fmaxf(u - l, 0.f);
+        }
+        const float emax = fmaxf(fmaxf(E[0], E[1]), fmaxf(E[2], 1e-6f));
+        // depth-camera clouds are surfaces: spacing ~ sqrt(area / n); 20 neighbours sit within ~2.5 spacings, and a
+        // cell edge of 4 leaves room for the density to vary across the cloud before a second ring is needed.  The volume term covers
+        // genuinely volumetric clouds.  Either way the search below is exact; h only decides how much it scans.
+        const float area = E[0] * E[1] + E[1] * E[2] + E[0] * E[2];
+        const float vol = fmaxf(E[0], 1e-3f * emax) * fmaxf(E[1], 1e-3f * emax) * fmaxf(E[2], 1e-3f * emax);
+        float h = fmaxf(h_area * sqrtf(area / (float)n), h_vol * cbrtf(vol / (float)n));
+        h = fmaxf(h, emax * (1.f / 1024.f));
+        int nx, ny, nz;
+        for (;;) {
+            nx = (int)(E[0] / h) + 1; ny = (int)(E[1] / h) + 1; nz = (int)(E[2] / h) + 1;
+            if ((long long)nx * ny * nz <= KNN_MAX_CELLS) break;
+            h *= 1.25f;
+        }
+        gp->ox = L[0]; gp->oy = L[1]; gp->oz = L[2]; gp->h = h; gp->inv_h = 1.f / h;
+        gp->nx = nx; gp->ny = ny; gp->nz = nz; gp->ncells = nx * ny * nz;
+        for (int i = 0; i < 5; ++i) gp->ring_hist[i] = 0u;
+        s_ncells = nx * ny * nz;
+    }
+    __syncthreads();
+    for (int c = tid; c <= s_ncells; c += 1024) cell_count[c] = 0u;
+}
+__device__ inline void knn_cell_of(const KnnGrid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+    cx = (int)((x - g.ox) * g.inv_h); cy = (int)((y - g.oy) * g.inv_h); cz = (int)((z - g.oz) * g.inv_h);
+    cx = cx < 0 ? 0 : (cx >= g.nx ? g.nx - 1 : cx);
+    cy = cy < 0 ? 0 : (cy >= g.ny ? g.ny - 1 : cy);
+    cz = cz < 0 ? 0 : (cz >= g.nz ? g.nz - 1 : cz);
+}
+__global__ __launch_bounds__(256) void knn_count_kernel(int n, const float4* __restrict__ pts, const KnnGrid* __restrict__ gp,
+                                                        int* __restrict__ cell_of, unsigned* __restrict__ cell_count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const KnnGrid g = *gp;
+    const float4 p = pts[i];
+    int cx, cy, cz;
+    knn_cell_of(g, p.x, p.y, p.z, cx, cy, cz);
+    const int c = (cz * g.ny + cy) * g.nx + cx;
+    cell_of[i] = c;
+    atomicAdd(&cell_count[c], 1u);
+}
+// single workgroup: exclusive scan of the cell counts -> cell_start[0..ncells]; cell_fill (cursor) = copy of cell_start
+__global__ __launch_bounds__(1024) void knn_scan_kernel(const KnnGrid* __restrict__ gp, const unsigned* __restrict__ cell_count,
+                                                        unsigned* __restrict__ cell_start, unsigned* __restrict__ cell_fill) {
+    __shared__ unsigned s_part[1024];
+    const int tid = threadIdx.x;
+    const int ncells = gp->ncells;
+    const int per = (ncells + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per) < ncells ? (lo + per) : ncells;
+    unsigned sum = 0;
+    for (int c = lo; c < hi; ++c) sum += cell_count[c];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
+        const unsigned v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = s_part[tid] - sum;
+    for (int c = lo; c < hi; ++c) {
+        const unsigned cnt = cell_count[c];
+        cell_start[c] = run; cell_fill[c] = run;
+        run += cnt;
+    }
+    if (tid == 1023) cell_start[ncells] = s_part[1023];
+}
+__global__ __launch_bounds__(256) void knn_fill_kernel(int n, const float4* __restrict__ pts, const int* __restrict__ cell_of,
+                                                       unsigned* __restrict__ cell_fill, float4* __restrict__ sorted) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pts[i];
+    p.w = __int_as_float(i);
+    sorted[atomicAdd(&cell_fill[cell_of[i]], 1u)] = p;
+}
+
+struct TopK { float my_d; int my_i; float tau_d; int tau_i; };
+// Offer one candidate per lane (d = FLT_MAX / id = INT_MAX for idle lanes) to the cross-lane sorted list.
+__device__ inline void topk_offer(TopK& t, float d, int id, int kk, unsigned long long kmask, int lane) {
+    unsigned long long m = __ballot(lex_less(d, id, t.tau_d, t.tau_i));
+    while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float cd = readlane_f(d, b);
+        const int ci = __builtin_amdgcn_readlane(id, b);
+        if (!lex_less(cd, ci, t.tau_d, t.tau_i)) continue;   // the list moved on since the ballot
+        const unsigned long long le = __ballot(!lex_less(cd, ci, t.my_d, t.my_i)) & kmask;   // entries ranked before the candidate
+        const int pos = __popcll(le);
+        const float up_d = __int_as_float(wave_shr1(__float_as_int(t.my_d)));
+        const int up_i = wave_shr1(t.my_i);
+        if (lane > pos) { t.my_d = up_d; t.my_i = up_i; }
+        else if (lane == pos) { t.my_d = cd; t.my_i = ci; }
+        t.tau_d = readlane_f(t.my_d, kk - 1);
+        t.tau_i = __builtin_amdgcn_readlane(t.my_i, kk - 1);
+    }
+}
+
+__device__ inline float wave_min_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+// scan one contiguous range of the cell-sorted array
+__device__ inline void knn_scan_range(TopK& t, const float4& Q, const float4* __restrict__ sorted, unsigned s0, unsigned e0, int kk,
+                                      unsigned long long kmask, int lane) {
+    for (unsigned jb = s0; jb < e0; jb += 64) {
+        const unsigned j = jb + lane;
+        float d = FLT_MAX;
+        int id = 0x7fffffff;
+        if (j < e0) {
+            const float4 p = sorted[j];
+            d = dist2(Q.x, Q.y, Q.z, p.x, p.y, p.z);
+            id = __float_as_int(p.w);
+        }
+        topk_offer(t, d, id, kk, kmask, lane);
+    }
+}
+// conservative distance from coordinate q to the slab of cells [c0, c1] along one axis (0 inside); `slack` absorbs the
+// rounding of the cell assignment, so a pruned range can never hold a point closer than the bound
+__device__ inline float knn_gap(float q, float o, float h, int c0, int c1, float slack) {
+    const float lo = o + (float)c0 * h, hi = o + (float)(c1 + 1) * h;
+    const float g = q < lo ? lo - q : (q > hi ? q - hi : 0.f);
+    return fmaxf(g - slack, 0.f);
+}
+
+// One WAVE per query.  Ring 1: the 27 cells around the query, one per lane, visited nearest-first and pruned against the
+// running k-th distance (dense regions settle after one or two cells).  Ring 2: the 5x5x5 shell as 34 row segments, pruned the
+// same way, keeping the list.  After each ring the k-th distance is tested against the distance to the faces of the scanned
+// cube; a query that is still open after ring 2 scans the whole cloud.  Exact for any cell size.
+__global__ __launch_bounds__(256) void knn_grid_kernel(int n, int k, const float4* __restrict__ pts, const KnnGrid* __restrict__ gp,
+                                                       const unsigned* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                                       int* __restrict__ nbr_idx, float* __restrict__ nbr_d2, unsigned* __restrict__ ring_hist) {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= n) return;                       // wave-uniform
     const int kk = k < n ? k : n;             // <= 64
     const unsigned long long kmask = kk >= 64 ? ~0ull : ((1ull << kk) - 1ull);
+    const KnnGrid g = *gp;
     const float4 Q = pts[q];
-    float my_d = FLT_MAX;
-    int my_i = 0x7fffffff;
-    float tau_d = FLT_MAX;
-    int tau_i = 0x7fffffff;
-    // Batches are visited in a multiplicative-permutation order: depth-image clouds arrive in raster order, and a
-    // monotone approach towards the query would make almost every candidate an insertion.  The final sorted list
-    // does not depend on the visiting order (the order is a total one).
-    const int nb = (n + 63) / 64;
-    // software pipeline: the load of the next batch is in flight while this one is tested / inserted
-    float4 pnext = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < n) pnext = pts[lane];
-    for (int b = 0, pb = 0; b < nb; ++b) {
-        const int j = pb * 64 + lane;
-        const float4 p = pnext;
-        pb += batch_stride;
-        if (pb >= nb) pb -= nb;
-        if (b + 1 < nb && pb * 64 + lane < n) pnext = pts[pb * 64 + lane];
-        float d = FLT_MAX;
-        int id = 0x7fffffff;
-        if (j < n) {
-            d = dist2(Q.x, Q.y, Q.z, p.x, p.y, p.z);
-            id = j;
+    const float slack = 2e-3f * g.h;
+    int cx, cy, cz;
+    knn_cell_of(g, Q.x, Q.y, Q.z, cx, cy, cz);
+    TopK t;
+    t.my_d = FLT_MAX; t.my_i = 0x7fffffff; t.tau_d = FLT_MAX; t.tau_i = 0x7fffffff;
+    int how = 4;
+    bool done = false;
+
+    // ---------------- ring 1: 27 cells, nearest first
+    {
+        float key = FLT_MAX;                  // lower bound of the squared distance to this lane's cell; FLT_MAX = nothing (left) to visit
+        unsigned cs = 0, ce = 0;
+        if (lane < 27) {
+            const int x = cx + lane % 3 - 1, y = cy + (lane / 3) % 3 - 1, z = cz + lane / 9 - 1;
+            if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                const int c = (z * g.ny + y) * g.nx + x;
+                cs = cell_start[c]; ce = cell_start[c + 1];
+                if (ce > cs) {
+                    const float gx_ = knn_gap(Q.x, g.ox, g.h, x, x, slack), gy_ = knn_gap(Q.y, g.oy, g.h, y, y, slack),
+                                gz_ = knn_gap(Q.z, g.oz, g.h, z, z, slack);
+                    key = gx_ * gx_ + gy_ * gy_ + gz_ * gz_;
+                }
+            }
         }
-        unsigned long long m = __ballot(lex_less(d, id, tau_d, tau_i));
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const float cd = readlane_f(d, b);
-            const int ci = __builtin_amdgcn_readlane(id, b);
-            if (!lex_less(cd, ci, tau_d, tau_i)) continue;   // the list moved on since the ballot
-            const unsigned long long le = __ballot(!lex_less(cd, ci, my_d, my_i)) & kmask;   // entries ranked before the candidate
-            const int pos = __popcll(le);
-            const float up_d = __int_as_float(wave_shr1(__float_as_int(my_d)));
-            const int up_i = wave_shr1(my_i);
-            if (lane > pos) { my_d = up_d; my_i = up_i; }
-            else if (lane == pos) { my_d = cd; my_i = ci; }
-            tau_d = readlane_f(my_d, kk - 1);
-            tau_i = __builtin_amdgcn_readlane(my_i, kk - 1);
+        for (;;) {
+            const float m = wave_min_f(key);
+            if (m == FLT_MAX || m > t.tau_d) break;      // every remaining cell is farther than the current k-th neighbour
+            const int sel = __ffsll((long long)__ballot(key == m)) - 1;
+            const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)cs, sel), e0 = (unsigned)__builtin_amdgcn_readlane((int)ce, sel);
+            knn_scan_range(t, Q, sorted, s0, e0, kk, kmask, lane);
+            if (lane == sel) key = FLT_MAX;
         }
     }
-    // neighbours now sit in lanes 0..kk-1, ascending: park (index, d2) for the per-thread covariance kernel.  (Doing the fp64
-    // mean / covariance / Jacobi here would execute it once per WAVE with all 64 lanes computing the same numbers.)
+    for (int r = 1; r <= 2 && !done; ++r) {
+        const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r >= g.nx ? g.nx - 1 : cx + r;
+        const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r >= g.ny ? g.ny - 1 : cy + r;
+        const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r >= g.nz ? g.nz - 1 : cz + r;
+        if (r == 2) {
+            // ---------------- ring 2: rows of the 5x5 (y,z) window.  Rows inside the 3x3 window contribute only their two end cells
+            // (lanes 0..24: left / whole segment, lanes 25..49: right end cell of an inner row); the list from ring 1 is kept.
+            float key = FLT_MAX;
+            unsigned cs = 0, ce = 0;
+            if (lane < 50) {
+                const int rr = lane % 25, y = cy + rr % 5 - 2, z = cz + rr / 5 - 2;
+                const bool inner = (rr % 5 >= 1 && rr % 5 <= 3 && rr / 5 >= 1 && rr / 5 <= 3);
+                if (y >= 0 && y < g.ny && z >= 0 && z < g.nz && (lane < 25 || inner)) {
+                    int xa, xb;
+                    if (!inner) { xa = x0; xb = x1; }
+                    else if (lane < 25) { xa = cx - 2; xb = cx - 2; }
+                    else { xa = cx + 2; xb = cx + 2; }
+                    if (xa >= 0 && xb < g.nx) {
+                        const int base = (z * g.ny + y) * g.nx;
+                        cs = cell_start[base + xa]; ce = cell_start[base + xb + 1];
+                        if (ce > cs) {
+                            const float gx_ = knn_gap(Q.x, g.ox, g.h, xa, xb, slack), gy_ = knn_gap(Q.y, g.oy, g.h, y, y, slack),
+                                        gz_ = knn_gap(Q.z, g.oz, g.h, z, z, slack);
+                            key = gx_ * gx_ + gy_ * gy_ + gz_ * gz_;
+                        }
+                    }
+                }
+            }
+            for (;;) {
+                const float m = wave_min_f(key);
+                if (m == FLT_MAX || m > t.tau_d) break;
+                const int sel = __ffsll((long long)__ballot(key == m)) - 1;
+                const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)cs, sel), e0 = (unsigned)__builtin_amdgcn_readlane((int)ce, sel);
+                knn_scan_range(t, Q, sorted, s0, e0, kk, kmask, lane);
+                if (lane == sel) key = FLT_MAX;
+            }
+        }
+        // every point outside the scanned cube is at least `gr` away (faces clipped by the grid boundary do not count: nothing lies beyond)
+        float gr = FLT_MAX;
+        if (x0 > 0) gr = fminf(gr, Q.x - (g.ox + (float)x0 * g.h));
+        if (x1 < g.nx - 1) gr = fminf(gr, (g.ox + (float)(x1 + 1) * g.h) - Q.x);
+        if (y0 > 0) gr = fminf(gr, Q.y - (g.oy + (float)y0 * g.h));
+        if (y1 < g.ny - 1) gr = fminf(gr, (g.oy + (float)(y1 + 1) * g.h) - Q.y);
+        if (z0 > 0) gr = fminf(gr, Q.z - (g.oz + (float)z0 * g.h));
+        if (z1 < g.nz - 1) gr = fminf(gr, (g.oz + (float)(z1 + 1) * g.h) - Q.z);
+        if (gr == FLT_MAX) { done = true; how = 0; }                      // the cube already covers the whole grid
+        else {
+            gr -= slack;                                                  // cell assignment is a rounded float multiply: stay conservative
+            if (gr > 0.f && t.tau_d < gr * gr * 0.9999f) { done = true; how = r; }   // strict: an equal-distance outsider could win the index tie-break
+        }
+    }
+    if (!done) {   // sparse neighbourhood: scan everything
+        t.my_d = FLT_MAX; t.my_i = 0x7fffffff; t.tau_d = FLT_MAX; t.tau_i = 0x7fffffff;
+        knn_scan_range(t, Q, sorted, 0u, (unsigned)n, kk, kmask, lane);
+    }
     if (lane < kk) {
-        nbr_idx[(size_t)q * 64 + lane] = my_i;
-        nbr_d2[(size_t)q * 64 + lane] = my_d;
+        nbr_idx[(size_t)q * 64 + lane] = t.my_i;
+        nbr_d2[(size_t)q * 64 + lane] = t.my_d;
     }
+    if (lane == 0 && ring_hist) atomicAdd(&ring_hist[how], 1u);
 }
 
 // One THREAD per point: mean / covariance of its neighbours in fp64 (summed in rank order, as the oracle does), cyclic
@@ -418,13 +643,22 @@ struct AlignResult {
     int iterations, lm_trials, converged, failed;
 };
 
+// Page-locked, device-visible host memory the kernels write their small results into directly: the host polls the sequence
+// numbers instead of paying for a D2H copy plus a stream synchronise (each 15-60 us of fixed cost against ~100 us kernels).
+struct HostMailbox {
+    AlignResult result;
+    unsigned align_seq;          // written (system scope) after `result`
+    unsigned export_seq;         // written after the correspondence export below
+};
+
 constexpr int AL_T = 256;        // threads per workgroup
 constexpr int AL_MAX_WG = 240;   // <= one workgroup per CU, so every workgroup is resident and the grid barrier is safe
 
-struct AlignSync {               // zeroed by a hipMemsetAsync before every launch
+struct AlignSync {               // zeroed once at creation; every launch leaves it zeroed again (the last workgroup out resets it)
     unsigned counter;
     unsigned abort;
-    unsigned pad[30];
+    unsigned exit_count;
+    unsigned pad[29];
     double partials[2][AL_MAX_WG][NRED];
 };
 
@@ -445,6 +679,9 @@ struct AlignArgs {
     double* maha;              // 6 per trackable source point
     AlignResult* result;
     AlignSync* sync;
+    int* miss_counter;         // zeroed here for the exact-distance pass that follows (saves a memset launch per frame)
+    HostMailbox* mailbox;      // pinned host memory
+    unsigned seq;              // this launch's sequence number
 };
 
 __device__ inline double wave_sum_d(double v) {
@@ -586,6 +823,7 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
     unsigned epoch = 0;
     if (tid < 12) sh.x0[tid] = a.init[tid];
     if (tid == 0) { sh.lambda = -1.0; sh.converged = 0; sh.abort = 0; }
+    if (leader && a.miss_counter) *a.miss_counter = 0;
     __syncthreads();
 
     int iterations = 0, lm_trials = 0, failed = 0;
@@ -770,6 +1008,24 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
             r->final_pose[4 * i + 3] = (double)(float)sh.x0[9 + i];
         }
         r->iterations = iterations; r->lm_trials = lm_trials; r->converged = sh.converged; r->failed = failed;
+        // hand the result to the host: plain stores into pinned memory, system-scope fence, then the sequence number
+        HostMailbox* mb = a.mailbox;
+        const double* src = (const double*)r;
+        double* dst = (double*)&mb->result;
+        for (unsigned i = 0; i < sizeof(AlignResult) / sizeof(double); ++i) dst[i] = src[i];
+        __threadfence_system();
+        __hip_atomic_store(&mb->align_seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // check-out: a workgroup leaves only after its last barrier, so when the last one leaves nobody reads the barrier
+    // state any more and it can be reset for the next launch (no host-side memset between frames)
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned gone = __hip_atomic_fetch_add(&a.sync->exit_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == gridDim.x - 1) {
+            __hip_atomic_store(&a.sync->counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.sync->abort, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.sync->exit_count, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -822,6 +1078,35 @@ __global__ __launch_bounds__(256) void brute_nn_kernel(const int* __restrict__ m
     if (lane == 0) sqd[s] = bd;
 }
 
+// Correspondence export straight into pinned host memory (two coalesced streams over PCIe); the last workgroup to finish
+// publishes the sequence number the host is polling.
+__global__ __launch_bounds__(256) void export_corr_kernel(int n, const int* __restrict__ corr, const float* __restrict__ sqd, int* __restrict__ h_corr,
+                                                          float* __restrict__ h_sqd, int* __restrict__ blocks_done, HostMailbox* mb, unsigned seq) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { h_corr[i] = corr[i]; h_sqd[i] = sqd[i]; }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(blocks_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            __hip_atomic_store(blocks_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(&mb->export_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// set_input_* / set_*_filter ingest: the kernels read the page-locked staging directly (one launch instead of a copy engine
+// transfer plus a launch; 132 KB over PCIe is ~5 us).
+__global__ __launch_bounds__(256) void ingest_points_kernel(int n, const float4* __restrict__ h_pts, float4* __restrict__ pts, int* __restrict__ track) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { pts[i] = h_pts[i]; track[i] = i; }   // every point trackable until a filter says otherwise
+}
+__global__ __launch_bounds__(256) void ingest_track_kernel(int n, const int* __restrict__ h_track, int* __restrict__ track) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) track[i] = h_track[i];
+}
+
 // ---------------------------------------------------------------------------------------------- host object
 template <class T>
 struct DevBuf {
@@ -839,10 +1124,31 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+template <class T>
+struct PinnedBuf {                // page-locked host staging: async copies without the runtime's own bounce buffer
+    T* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        size_t want = n + n / 4 + 64;
+        if (hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { cap = 0; return -1; }
+        cap = want;
+        return 0;
+    }
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+};
+
 struct Cloud {
     int n = 0, n_track = 0;
     DevBuf<float4> pts;
     DevBuf<int> track;
+    PinnedBuf<float4> h_pts;      // staging for set_input_*; reused only after `staged` has completed
+    PinnedBuf<int> h_track;
+    hipEvent_t staged[2] = {nullptr, nullptr};   // [0] h_pts copy, [1] h_track copy
+    bool staged_pending[2] = {false, false};
+    ~Cloud() { for (hipEvent_t e : staged) if (e) (void)hipEventDestroy(e); }
     DevBuf<double> cov;
     DevBuf<float> rotq, scales;
     bool cov_valid = false, qs_valid = false;
@@ -863,12 +1169,21 @@ struct gsicp_gicp {
     DevBuf<float4> sorted;
     DevBuf<char> sort_temp;
     // per-source-point outputs
-    DevBuf<int> corr, miss, counters, nbr_idx;
+    DevBuf<int> corr, miss, counters, nbr_idx, knn_cell_of;
+    DevBuf<KnnGrid> knn_params;
+    DevBuf<unsigned> knn_count, knn_start, knn_fill;
+    DevBuf<float4> knn_sorted;
     DevBuf<float> nbr_d2;
     DevBuf<float> sqd;
     DevBuf<double> maha;
     DevBuf<AlignResult> result;
     DevBuf<AlignSync> sync;
+    HostMailbox* mailbox = nullptr;        // pinned
+    unsigned seq = 0;
+    bool stats_pending = false;            // device_us of the last align not read from the events yet
+    PinnedBuf<int> h_corr;
+    PinnedBuf<float> h_sqd;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
     AlignResult host_result{};
     bool aligned = false, dist_exact = false;
     std::vector<float> h_stage;
@@ -877,38 +1192,81 @@ struct gsicp_gicp {
 
 namespace {
 
+// Wait for the tracker stream by polling an event: the runtime's hipStreamSynchronize parks the thread and its wake-up costs
+// 50-150 us, several times the kernels being waited for.  Falls back to the blocking wait after ~2 ms of polling.
+int drain(gsicp_gicp* g) {
+    if (!g->ev_done) GC(hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming));
+    GC(hipEventRecord(g->ev_done, g->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(g->ev_done);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { g_last_error = std::string("hipEventQuery failed: ") + hipGetErrorString(q); return -1; }
+        if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    GC(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+// Poll a sequence number a kernel publishes in the pinned mailbox; after ~2 ms fall back to draining the stream (and fail if
+// the number still is not there — the launch itself must have failed).
+int wait_mailbox(gsicp_gicp* g, const volatile unsigned* slot, unsigned seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == seq) return 0;
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    if (int rc = drain(g)) return rc;
+    if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == seq) return 0;
+    g_last_error = "tracker kernel finished without publishing its result";
+    return -1;
+}
+
+int wait_staging(Cloud& c, int which) {
+    if (c.staged_pending[which]) { GC(hipEventSynchronize(c.staged[which])); c.staged_pending[which] = false; }
+    return 0;
+}
+int mark_staging(gsicp_gicp* g, Cloud& c, int which) {
+    if (!c.staged[which]) GC(hipEventCreateWithFlags(&c.staged[which], hipEventDisableTiming));
+    GC(hipEventRecord(c.staged[which], g->stream));
+    c.staged_pending[which] = true;
+    return 0;
+}
+
+// The caller's array is converted into page-locked staging and copied asynchronously; the call returns without waiting for
+// the device (the caller's buffer is already consumed), and the staging is reused only once its copy has completed.
 int upload_points(gsicp_gicp* g, Cloud& c, const void* pts, int n, int is_f64) {
     if (n < 0 || (n > 0 && !pts)) { g_last_error = "bad point array"; return -2; }
     c.n = n; c.n_track = n; c.cov_valid = false; c.qs_valid = false;
-    if (c.pts.ensure((size_t)n) || c.track.ensure((size_t)n)) { g_last_error = "hipMalloc failed"; return -1; }
-    std::vector<float4> h((size_t)n);
-    std::vector<int> tr((size_t)n);
-    for (int i = 0; i < n; ++i) {
-        if (is_f64) { const double* p = (const double*)pts + 3 * (size_t)i; h[i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f); }
-        else { const float* p = (const float*)pts + 3 * (size_t)i; h[i] = make_float4(p[0], p[1], p[2], 0.f); }
-        tr[i] = i;
-    }
+    if (c.pts.ensure((size_t)n) || c.track.ensure((size_t)n) || c.h_pts.ensure((size_t)n)) { g_last_error = "hipMalloc failed"; return -1; }
     if (n > 0) {
-        GC(hipMemcpyAsync(c.pts.p, h.data(), sizeof(float4) * n, hipMemcpyHostToDevice, g->stream));
-        GC(hipMemcpyAsync(c.track.p, tr.data(), sizeof(int) * n, hipMemcpyHostToDevice, g->stream));
-        GC(hipStreamSynchronize(g->stream));
+        if (int rc = wait_staging(c, 0)) return rc;
+        float4* h = c.h_pts.p;
+        if (is_f64) { const double* p = (const double*)pts; for (int i = 0; i < n; ++i, p += 3) h[i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f); }
+        else { const float* p = (const float*)pts; for (int i = 0; i < n; ++i, p += 3) h[i] = make_float4(p[0], p[1], p[2], 0.f); }
+        hipLaunchKernelGGL(ingest_points_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, (const float4*)h, c.pts.p, c.track.p);
+        if (int rc = mark_staging(g, c, 0)) return rc;
     }
     return 0;
 }
 
 int upload_filter(gsicp_gicp* g, Cloud& c, int n_track, const int32_t* f, int n) {
     if (n != c.n) { g_last_error = "filter length does not match the point cloud"; return -2; }
-    std::vector<int> tr((size_t)(n_track > 0 ? n_track : 0), -1);
+    const size_t nt = (size_t)(n_track > 0 ? n_track : 0);
+    if (c.h_track.ensure(nt ? nt : 1)) { g_last_error = "hipHostMalloc failed"; return -1; }
+    if (int rc = wait_staging(c, 1)) return rc;
+    int* tr = c.h_track.p;
+    for (size_t i = 0; i < nt; ++i) tr[i] = -1;
     for (int i = 0; i < n; ++i)
         if (f[i] > 0 && f[i] <= n_track) tr[f[i] - 1] = i;
     size_t w = 0;
-    for (size_t i = 0; i < tr.size(); ++i)
+    for (size_t i = 0; i < nt; ++i)
         if (tr[i] >= 0) tr[w++] = tr[i];
     c.n_track = (int)w;
     if (c.track.ensure(w ? w : 1)) { g_last_error = "hipMalloc failed"; return -1; }
     if (w) {
-        GC(hipMemcpyAsync(c.track.p, tr.data(), sizeof(int) * w, hipMemcpyHostToDevice, g->stream));
-        GC(hipStreamSynchronize(g->stream));
+        hipLaunchKernelGGL(ingest_track_kernel, dim3(((int)w + 255) / 256), dim3(256), 0, g->stream, (int)w, (const int*)tr, c.track.p);
+        if (int rc = mark_staging(g, c, 1)) return rc;
     }
     return 0;
 }
@@ -922,12 +1280,21 @@ int calc_cov(gsicp_gicp* g, Cloud& c) {
         if (g->k > 64) { g_last_error = "correspondence randomness (k) > 64 is not supported"; return -2; }
         const float maxd2 = g->max_knn >= (double)FLT_MAX ? FLT_MAX : (float)(g->max_knn * g->max_knn);
         gsicp::ProfileScope ps(gsicp::ST_GICP_COV, g->stream);
-        const int nb = (n + 63) / 64;
-        int stride = 1;
-        for (int p : {37, 41, 43, 47, 53, 59, 61, 67, 71, 73})
-            if (p < nb && nb % p != 0) { stride = p; break; }
-        if (g->nbr_idx.ensure((size_t)n * 64) || g->nbr_d2.ensure((size_t)n * 64)) { g_last_error = "hipMalloc failed"; return -1; }
-        hipLaunchKernelGGL(knn_cov_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, n, g->k, stride, c.pts.p, g->nbr_idx.p, g->nbr_d2.p);
+        if (g->nbr_idx.ensure((size_t)n * 64) || g->nbr_d2.ensure((size_t)n * 64) || g->knn_params.ensure(1) ||
+            g->knn_cell_of.ensure((size_t)n) || g->knn_count.ensure(KNN_MAX_CELLS + 1) || g->knn_start.ensure(KNN_MAX_CELLS + 1) ||
+            g->knn_fill.ensure(KNN_MAX_CELLS + 1) || g->knn_sorted.ensure((size_t)n)) { g_last_error = "hipMalloc failed"; return -1; }
+        static const bool knn_stats_on = std::getenv("GSICP_KNN_STATS") != nullptr;
+        static const float h_area = [] { const char* e = std::getenv("GSICP_KNN_H"); const float v = e ? (float)std::atof(e) : 0.f; return v > 0.f ? v : KNN_H_AREA; }();
+        hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, g->stream, n, c.pts.p, h_area, h_area * (KNN_H_VOL / KNN_H_AREA),
+                           g->knn_params.p, g->knn_count.p);
+        hipLaunchKernelGGL(knn_count_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, c.pts.p, g->knn_params.p, g->knn_cell_of.p,
+                           g->knn_count.p);
+        hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, g->stream, g->knn_params.p, g->knn_count.p, g->knn_start.p, g->knn_fill.p);
+        hipLaunchKernelGGL(knn_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, c.pts.p, g->knn_cell_of.p, g->knn_fill.p,
+                           g->knn_sorted.p);
+        hipLaunchKernelGGL(knn_grid_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, n, g->k, c.pts.p, g->knn_params.p, g->knn_start.p,
+                           g->knn_sorted.p, g->nbr_idx.p, g->nbr_d2.p,
+                           knn_stats_on ? g->knn_params.p->ring_hist : (unsigned*)nullptr);   // same-address atomics: diagnostics only
         hipLaunchKernelGGL(cov_eig_kernel, dim3((n + 63) / 64), dim3(64), 0, g->stream, n, g->k, c.pts.p, g->nbr_idx.p, g->nbr_d2.p, maxd2,
                            g->reg, c.cov.p, c.rotq.p, c.scales.p);
         GC(hipGetLastError());
@@ -978,7 +1345,7 @@ int fetch_floats(gsicp_gicp* g, const float* dev, int n_pts, int width, float* o
     const int n = n_pts < cap_pts ? n_pts : cap_pts;
     if (n > 0) {
         GC(hipMemcpyAsync(out, dev, sizeof(float) * (size_t)n * width, hipMemcpyDeviceToHost, g->stream));
-        GC(hipStreamSynchronize(g->stream));
+        if (int rc_ = drain(g)) return rc_;
     }
     return n;
 }
@@ -989,17 +1356,33 @@ extern "C" {
 
 gsicp_gicp* gsicp_gicp_create(void) {
     gsicp_gicp* g = new gsicp_gicp();
-    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
+    // The tracker is the latency-critical half (one frame = a short dependent chain of small kernels); the mapper it shares the GPU
+    // with is throughput work.  Highest stream priority lets the tracker's waves go ahead of queued mapper workgroups.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char* pe = std::getenv("GSICP_TRACKER_PRIORITY");   // "0" = default priority (A/B switch for measurements)
+    if (pe && pe[0] == '0') prio_hi = prio_lo = 0;
+    if (hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
         g_last_error = "hipStreamCreate failed (no HIP device?)";
         delete g;
         return nullptr;
     }
-    if (g->result.ensure(1) || g->counters.ensure(4) || g->sync.ensure(1)) { g_last_error = "hipMalloc failed"; delete g; return nullptr; }
+    if (g->result.ensure(1) || g->counters.ensure(4) || g->sync.ensure(1) ||
+        hipHostMalloc((void**)&g->mailbox, sizeof(HostMailbox), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess ||
+        hipMemset(g->sync.p, 0, 128) != hipSuccess || hipMemset(g->counters.p, 0, sizeof(int) * 4) != hipSuccess) {
+        g_last_error = "device / pinned allocation failed"; gsicp_gicp_destroy(g); return nullptr;
+    }
+    std::memset(g->mailbox, 0, sizeof(HostMailbox));
     return g;
 }
 void gsicp_gicp_destroy(gsicp_gicp* g) {
     if (!g) return;
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
+    if (g->mailbox) (void)hipHostFree(g->mailbox);
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->ev_done) (void)hipEventDestroy(g->ev_done);
     delete g;
 }
 int gsicp_gicp_set_max_correspondence_distance(gsicp_gicp* g, double d) { g->max_corr = d; g->grid_valid = false; return 0; }
@@ -1032,12 +1415,12 @@ int gsicp_gicp_set_target_filter(gsicp_gicp* g, int n_track, const int32_t* f, i
 int gsicp_gicp_set_source_filter(gsicp_gicp* g, int n_track, const int32_t* f, int n) { return upload_filter(g, g->src, n_track, f, n); }
 int gsicp_gicp_calculate_target_covariance_with_filter(gsicp_gicp* g) {
     const int rc = calc_cov(g, g->tgt);
-    if (rc == 0) GC(hipStreamSynchronize(g->stream));
+    if (rc == 0) if (int rc_ = drain(g)) return rc_;
     return rc;
 }
 int gsicp_gicp_calculate_source_covariance(gsicp_gicp* g) {
     const int rc = calc_cov(g, g->src);
-    if (rc == 0) GC(hipStreamSynchronize(g->stream));
+    if (rc == 0) if (int rc_ = drain(g)) return rc_;
     return rc;
 }
 int gsicp_gicp_get_target_rotationsq(gsicp_gicp* g, float* out, int cap) {
@@ -1066,7 +1449,7 @@ int gsicp_gicp_set_target_covariances_fromqs(gsicp_gicp* g, const float* rots, i
         GC(hipMemcpyAsync(t.scales.p, scales, sizeof(float) * 3 * t.n, hipMemcpyHostToDevice, g->stream));
         hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, t.rotq.p, t.scales.p, t.cov.p);
         GC(hipGetLastError());
-        GC(hipStreamSynchronize(g->stream));
+        if (int rc_ = drain(g)) return rc_;
     }
     t.cov_valid = true; t.qs_valid = true;
     return 0;
@@ -1075,8 +1458,7 @@ int gsicp_gicp_set_target_covariances_fromqs(gsicp_gicp* g, const float* rots, i
 int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     Cloud &s = g->src, &t = g->tgt;
     if (s.n == 0 || t.n == 0) { g_last_error = "align: source and target must be set"; return -2; }
-    hipEvent_t e0, e1;
-    GC(hipEventCreate(&e0)); GC(hipEventCreate(&e1));
+    hipEvent_t e0 = g->ev0, e1 = g->ev1;
     GC(hipEventRecord(e0, g->stream));
     int launches = 0;
     if (!s.cov_valid) { if (int rc = calc_cov(g, s)) return rc; ++launches; }
@@ -1097,20 +1479,22 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     }
     a.max_iter = g->max_iter; a.lm_max_iter = g->lm_max_iter; a.rot_eps = g->rot_eps; a.trans_eps = g->trans_eps; a.lm_init = g->lm_init;
     a.corr = g->corr.p; a.sqd = g->sqd.p; a.maha = g->maha.p; a.result = g->result.p; a.sync = g->sync.p;
+    a.miss_counter = g->counters.p;
+    a.mailbox = g->mailbox; a.seq = ++g->seq;
     int nwg = (s.n_track + AL_T - 1) / AL_T;
     if (nwg < 1) nwg = 1;
     if (nwg > AL_MAX_WG) nwg = AL_MAX_WG;
-    GC(hipMemsetAsync(g->sync.p, 0, 128, g->stream));   // barrier counter + abort flag
     { gsicp::ProfileScope ps(gsicp::ST_GICP_ALIGN, g->stream);
       hipLaunchKernelGGL(gicp_align_kernel, dim3(nwg), dim3(AL_T), 0, g->stream, a); }
     ++launches;
     GC(hipGetLastError());
     GC(hipEventRecord(e1, g->stream));
-    GC(hipMemcpyAsync(&g->host_result, g->result.p, sizeof(AlignResult), hipMemcpyDeviceToHost, g->stream));
-    GC(hipStreamSynchronize(g->stream));
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (int rc_ = wait_mailbox(g, &g->mailbox->align_seq, a.seq)) return rc_;
+    g->host_result = g->mailbox->result;
+    for (int w = 0; w < 2; ++w) { g->src.staged_pending[w] = false; g->tgt.staged_pending[w] = false; }   // everything before the kernel has completed
+    g->stats_pending = true;   // the events are read lazily (gsicp_gicp_last_align_stats): e1 completes a few us after the mailbox write
+    const float ms = 0.f;
+    if (g->host_result.failed) { (void)hipStreamSynchronize(g->stream); (void)hipMemset(g->sync.p, 0, 128); }   // an aborted launch may leave barrier state behind
     std::memcpy(out, g->host_result.final_pose, sizeof(double) * 16);
     g->aligned = true; g->dist_exact = false;
     g->stats[0] = launches; g->stats[1] = g->host_result.lm_trials; g->stats[2] = g->host_result.cost;
@@ -1125,7 +1509,6 @@ int gsicp_gicp_get_source_correspondence(gsicp_gicp* g, int32_t* idx, float* d2,
     if (!g->dist_exact && g->grid.use_grid && n > 0 && t.n_track > 0) {
         const float gate = (float)g->max_corr * (float)g->max_corr;
         gsicp::ProfileScope ps(gsicp::ST_GICP_MISS, g->stream);
-        GC(hipMemsetAsync(g->counters.p, 0, sizeof(int) * 4, g->stream));
         hipLaunchKernelGGL(miss_list_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, g->sqd.p, g->corr.p, gate, g->miss.p,
                            g->counters.p);
         hipLaunchKernelGGL(brute_nn_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
@@ -1134,16 +1517,39 @@ int gsicp_gicp_get_source_correspondence(gsicp_gicp* g, int32_t* idx, float* d2,
         g->dist_exact = true;
     }
     const int m = n < cap ? n : cap;
-    if (m > 0) {
-        GC(hipMemcpyAsync(idx, g->corr.p, sizeof(int) * m, hipMemcpyDeviceToHost, g->stream));
-        GC(hipMemcpyAsync(d2, g->sqd.p, sizeof(float) * m, hipMemcpyDeviceToHost, g->stream));
+    if (m > 0) {   // page-locked staging, then a plain memcpy into the caller's arrays once the stream has drained
+        if (g->h_corr.ensure((size_t)m) || g->h_sqd.ensure((size_t)m)) { g_last_error = "hipHostMalloc failed"; return -1; }
+        const unsigned seq = ++g->seq;
+        hipLaunchKernelGGL(export_corr_kernel, dim3((m + 255) / 256), dim3(256), 0, g->stream, m, g->corr.p, g->sqd.p, g->h_corr.p, g->h_sqd.p,
+                           g->counters.p + 1, g->mailbox, seq);
+        GC(hipGetLastError());
+        if (int rc_ = wait_mailbox(g, &g->mailbox->export_seq, seq)) return rc_;
+        std::memcpy(idx, g->h_corr.p, sizeof(int) * m);
+        std::memcpy(d2, g->h_sqd.p, sizeof(float) * m);
     }
-    GC(hipStreamSynchronize(g->stream));
     return m;
+}
+int gsicp_gicp_knn_stats(gsicp_gicp* g, double out[12]) {
+    KnnGrid h;
+    if (!g->knn_params.p) { g_last_error = "no covariance has been computed yet"; return -2; }
+    GC(hipStreamSynchronize(g->stream));
+    GC(hipMemcpy(&h, g->knn_params.p, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h.h; out[1] = h.nx; out[2] = h.ny; out[3] = h.nz; out[4] = h.ncells;
+    for (int i = 0; i < 5; ++i) out[5 + i] = h.ring_hist[i];
+    out[10] = out[11] = 0;
+    return 0;
 }
 int gsicp_gicp_num_source(gsicp_gicp* g) { return g->src.n; }
 int gsicp_gicp_num_target(gsicp_gicp* g) { return g->tgt.n; }
-int gsicp_gicp_last_align_stats(gsicp_gicp* g, double out[6]) { std::memcpy(out, g->stats, sizeof(double) * 6); return 0; }
+int gsicp_gicp_last_align_stats(gsicp_gicp* g, double out[6]) {
+    if (g->stats_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g->ev1) == hipSuccess && hipEventElapsedTime(&ms, g->ev0, g->ev1) == hipSuccess) g->stats[4] = ms * 1000.0;
+        g->stats_pending = false;
+    }
+    std::memcpy(out, g->stats, sizeof(double) * 6);
+    return 0;
+}
 int gsicp_gicp_get_final_hessian(gsicp_gicp* g, double out[36]) { std::memcpy(out, g->host_result.H_final, sizeof(double) * 36); return 0; }
 
 }  // extern "C"

@@ -244,9 +244,16 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float beta1, flo
 // for every iteration (torch.optim.Adam(capturable=True) keeps its step on the device for the same reason).
 __global__ __launch_bounds__(256) void adam_capturable_kernel(AdamTable t, const float* __restrict__ lr_dev, const int* __restrict__ step_dev,
                                                               float beta1, float beta2, float eps, long long total) {
-    const int step = *step_dev + 1;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    __shared__ double s_bc1;
+    __shared__ float s_inv_bc2_sqrt;
+    if (threadIdx.x == 0) {   // two double pow() per BLOCK, not per thread
+        const int step = *step_dev + 1;
+        s_bc1 = 1.0 - pow((double)beta1, (double)step);
+        s_inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    }
+    __syncthreads();
+    const double bc1 = s_bc1;
+    const float inv_bc2_sqrt = s_inv_bc2_sqrt;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         int gidx = 0;
         long long base = 0;
@@ -265,6 +272,53 @@ __global__ __launch_bounds__(256) void adam_capturable_kernel(AdamTable t, const
     }
 }
 __global__ void adam_bump_step_kernel(int* step_dev) { *step_dev += 1; }
+
+// ------------------------------------------------------------------------------------------------ activations
+// GaussianModel's getters [REF scene/gaussian_model.py:105-125, 44-56]: opacity = sigmoid(_opacity), scaling = exp(_scaling),
+// rotation = normalize(_rotation) (torch.nn.functional.normalize: x / max(||x||, 1e-12)).  One thread per Gaussian, one
+// launch for the three of them (the torch chain is ~8 launches forward and ~12 backward at ~5 us each).
+__global__ __launch_bounds__(256) void activations_forward_kernel(int P, const float* __restrict__ o_raw, const float* __restrict__ s_raw,
+                                                                  const float4* __restrict__ q_raw, float* __restrict__ o,
+                                                                  float* __restrict__ s, float4* __restrict__ q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    o[i] = 1.f / (1.f + expf(-o_raw[i]));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) s[3 * (size_t)i + d] = expf(s_raw[3 * (size_t)i + d]);
+    const float4 r = q_raw[i];
+    const float n = fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);
+    q[i] = make_float4(r.x / n, r.y / n, r.z / n, r.w / n);
+}
+// d/d_raw: sigmoid' = o (1 - o);  exp' = s;  normalize: (g - y (y . g)) / n  with y = x / n  (n above the clamp; at the clamp g / 1e-12)
+__global__ __launch_bounds__(256) void activations_backward_kernel(int P, const float* __restrict__ o, const float* __restrict__ s,
+                                                                   const float4* __restrict__ q_raw, const float* __restrict__ g_o,
+                                                                   const float* __restrict__ g_s, const float4* __restrict__ g_q,
+                                                                   float* __restrict__ d_o_raw, float* __restrict__ d_s_raw,
+                                                                   float4* __restrict__ d_q_raw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    if (d_o_raw) { const float ov = o[i]; d_o_raw[i] = g_o ? g_o[i] * ov * (1.f - ov) : 0.f; }
+    if (d_s_raw) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) d_s_raw[3 * (size_t)i + d] = g_s ? g_s[3 * (size_t)i + d] * s[3 * (size_t)i + d] : 0.f;
+    }
+    if (d_q_raw) {
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_q) {
+            const float4 r = q_raw[i], g = g_q[i];
+            const float nn = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+            if (nn > 1e-12f) {
+                const float inv = 1.f / nn;
+                const float yx = r.x * inv, yy = r.y * inv, yz = r.z * inv, yw = r.w * inv;
+                const float dot = yx * g.x + yy * g.y + yz * g.z + yw * g.w;
+                out = make_float4((g.x - yx * dot) * inv, (g.y - yy * dot) * inv, (g.z - yz * dot) * inv, (g.w - yw * dot) * inv);
+            } else {
+                out = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+            }
+        }
+        d_q_raw[i] = out;
+    }
+}
 
 }  // namespace
 }  // namespace gsicp
@@ -312,6 +366,30 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
         hipLaunchKernelGGL(loss_pass2_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                            (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss: kernel launch failed"; return -1; }
+    return 0;
+}
+
+int gsicp_mapper_activations_forward(int P, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* opacity,
+                                     float* scaling, float* rotation, void* stream) {
+    if (P < 0 || (P > 0 && (!opacity_raw || !scaling_raw || !rotation_raw || !opacity || !scaling || !rotation))) {
+        g_last_error = "gsicp_mapper_activations_forward: bad arguments"; return -2;
+    }
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(activations_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, opacity_raw, scaling_raw,
+                       (const float4*)rotation_raw, opacity, scaling, (float4*)rotation);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_activations_forward: kernel launch failed"; return -1; }
+    return 0;
+}
+
+int gsicp_mapper_activations_backward(int P, const float* opacity, const float* scaling, const float* rotation_raw, const float* dL_dopacity,
+                                      const float* dL_dscaling, const float* dL_drotation, float* dL_dopacity_raw, float* dL_dscaling_raw,
+                                      float* dL_drotation_raw, void* stream) {
+    if (P < 0 || (P > 0 && (!opacity || !scaling || !rotation_raw))) { g_last_error = "gsicp_mapper_activations_backward: bad arguments"; return -2; }
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(activations_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, opacity, scaling,
+                       (const float4*)rotation_raw, dL_dopacity, dL_dscaling, (const float4*)dL_drotation, dL_dopacity_raw, dL_dscaling_raw,
+                       (float4*)dL_drotation_raw);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_activations_backward: kernel launch failed"; return -1; }
     return 0;
 }
 

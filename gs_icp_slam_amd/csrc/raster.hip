@@ -167,9 +167,10 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __rest
                                                    const SplatRec* __restrict__ rec, const int* __restrict__ radii, int gx, int gy,
                                                    int tile_mod, int tile_rem, uint32_t* __restrict__ emit_tile,
                                                    uint32_t* __restrict__ emit_depth, uint32_t* __restrict__ entry_gauss,
-                                                   uint32_t* __restrict__ entry_bits) {
+                                                   uint32_t* __restrict__ entry_bits, uint32_t* __restrict__ num_rendered_dev) {
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= P) return;
+    if (id == 0 && num_rendered_dev) *num_rendered_dev = *total;   // the caller's copy of R (async path)
     if (tiles_touched[id] == 0 || *total > cap) return;
     uint32_t u = slot_base[id];
     const SplatRec r = rec[id];
@@ -718,7 +719,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
             if (total > ID_MASK) { g_last_error = "more than 2^28 (Gaussian, tile) duplicates are not supported"; return -2; }
             num_rendered = (int)total;
         }
-        if (num_rendered_dev) hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(1), 0, stream, total_counter, num_rendered_dev);
+        if (num_rendered_dev && !async) hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(1), 0, stream, total_counter, num_rendered_dev);
     } else {
         GS_CHECK(hipStreamSynchronize(stream));
         if (num_rendered_dev) hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(1), 0, stream, (const uint32_t*)nullptr, num_rendered_dev);
@@ -750,7 +751,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     if (num_rendered > 0) {
         ProfileScope ps(ST_DUPLICATE, stream);
         hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, total_counter, cap, tiles_touched, slot_base, rec, radii, gx, gy,
-                           tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits);
+                           tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits, num_rendered_dev);
         hipLaunchKernelGGL(split_hist_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, block_hist);
         hipLaunchKernelGGL(split_colscan_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, nb, block_hist, tile_count);
     }

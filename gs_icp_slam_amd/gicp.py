@@ -140,6 +140,12 @@ class FastGICP:
         self._ck(self._lib.gsicp_gicp_get_final_hessian(self._h, _vp(out)), "get_final_hessian")
         return out
 
+    def knn_stats(self):
+        out = np.empty(12, np.float64)
+        self._ck(self._lib.gsicp_gicp_knn_stats(self._h, _vp(out)), "knn_stats")
+        return dict(cell=float(out[0]), dims=(int(out[1]), int(out[2]), int(out[3])), whole_grid=int(out[5]), ring1=int(out[6]),
+                    ring2=int(out[7]), ring3=int(out[8]), full_scan=int(out[9]))
+
     def last_align_stats(self):
         out = np.empty(6, np.float64)
         self._lib.gsicp_gicp_last_align_stats(self._h, _vp(out))

@@ -14,13 +14,20 @@ a new MapperIterationGraph — capture costs about three eager iterations.
 """
 import torch
 
-from .loss import mapper_loss_parts
+from .activations import activate
+from .loss import mapper_loss_and_grads
 from .optim import FusedAdam
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
 def default_activations(p):
-    """GaussianModel's property getters [REF scene/gaussian_model.py:105-125] on the raw parameter tensors."""
+    """GaussianModel's property getters [REF scene/gaussian_model.py:105-125] on the raw parameter tensors (one fused launch)."""
+    opacities, scales, rotations = activate(p["opacities"], p["scales"], p["rotations"])
+    return dict(means3D=p["means3D"], shs=p["shs"], opacities=opacities, scales=scales, rotations=rotations)
+
+
+def torch_activations(p):
+    """The same with the reference's torch ops (sigmoid / exp / normalize)."""
     return dict(means3D=p["means3D"], shs=p["shs"], opacities=torch.sigmoid(p["opacities"]), scales=torch.exp(p["scales"]),
                 rotations=torch.nn.functional.normalize(p["rotations"]))
 
@@ -55,11 +62,15 @@ class MapperIterationGraph:
             debug=False, capacity=self.capacity)
         self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
         self._warmup = int(warmup)
+        # screen-space gradient holder [REF gaussian_renderer/__init__.py:227]: the reference makes a fresh zero tensor per call;
+        # its VALUE is never read by the rasteriser, so one static tensor serves every replay
+        self._means2D = torch.zeros_like(params["means3D"], requires_grad=True)
         self.graph = None
         # static outputs
         self.loss_parts = None      # tensor([loss, L1, SSIM mean, depth L1]) of the last replay
         self.radii = None
         self.is_used = None
+        self.screenspace_grad = None
         self.num_rendered = None    # int32[1]: true duplicate count of the last replay
 
     # ------------------------------------------------------------------------------------------------------------
@@ -73,12 +84,14 @@ class MapperIterationGraph:
 
     def _iteration(self):
         a = self.activations(self.params)
-        means2D = torch.zeros_like(a["means3D"], requires_grad=True)
-        depth, color, radii, used = self.rasterizer(means3D=a["means3D"], means2D=means2D, shs=a["shs"], opacities=a["opacities"],
+        depth, color, radii, used = self.rasterizer(means3D=a["means3D"], means2D=self._means2D, shs=a["shs"], opacities=a["opacities"],
                                                     scales=a["scales"], rotations=a["rotations"])
-        loss, parts = mapper_loss_parts(color, depth, self.gt_image, self.gt_depth, lambda_dssim=self.lambda_dssim,
-                                        depth_weight=self.depth_weight, d_max=self.d_max)
-        loss.backward()
+        # the loss kernels produce dL/dimage and dL/ddepth directly: no autograd node, no ones_like / multiply launches
+        parts, g_color, g_depth = mapper_loss_and_grads(color, depth, self.gt_image, self.gt_depth, lambda_dssim=self.lambda_dssim,
+                                                        depth_weight=self.depth_weight, d_max=self.d_max)
+        torch.autograd.backward((color, depth), (g_color, g_depth))
+        self.screenspace_grad = self._means2D.grad     # (P,3) viewspace gradient of this iteration (densification statistics)
+        self._means2D.grad = None
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return parts, radii, used

@@ -167,6 +167,9 @@ int gsicp_gicp_align(gsicp_gicp*, const double* initial_pose, double* final_pose
  * the squared distance to the nearest target point, as of the last linearisation  [REF mp_Tracker.py:231].
  * Returns the number of entries. */
 int gsicp_gicp_get_source_correspondence(gsicp_gicp*, int32_t* target_index, float* sq_distance, int capacity);
+/* Diagnostics of the last k-NN covariance pass: out = {cell edge, nx, ny, nz, cells, queries settled by whole-grid coverage,
+ * after ring 1, ring 2, ring 3, by the exhaustive scan, 0, 0}.  Synchronises. */
+int gsicp_gicp_knn_stats(gsicp_gicp* g, double out[12]);
 int gsicp_gicp_num_source(gsicp_gicp*);
 int gsicp_gicp_num_target(gsicp_gicp*);
 /* out[0..5]: kernel launches of the last align, LM trials, final cost, converged flag, device microseconds, reserved */
@@ -191,6 +194,17 @@ size_t gsicp_mapper_loss_scratch_bytes(int width, int height);
 int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
                       float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
                       char* scratch, void* stream);
+
+/* GaussianModel's activation getters in one launch each way [REF scene/gaussian_model.py:44-56, 105-125], reached from
+ * render_3 at [REF gaussian_renderer/__init__.py:263, 273-274]: opacity = sigmoid(opacity_raw) (P), scaling =
+ * exp(scaling_raw) (P,3), rotation = rotation_raw / max(||rotation_raw||, 1e-12) (P,4).  All DEVICE float arrays. */
+int gsicp_mapper_activations_forward(int P, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* opacity,
+                                     float* scaling, float* rotation, void* stream);
+/* Chain rule of the above.  `opacity` / `scaling` are the forward OUTPUTS, rotation_raw the forward input; any dL_d*
+ * input may be NULL (treated as zero) and any dL_d*_raw output may be NULL (skipped). */
+int gsicp_mapper_activations_backward(int P, const float* opacity, const float* scaling, const float* rotation_raw, const float* dL_dopacity,
+                                      const float* dL_dscaling, const float* dL_drotation, float* dL_dopacity_raw, float* dL_dscaling_raw,
+                                      float* dL_drotation_raw, void* stream);
 
 /* One torch.optim.Adam step (amsgrad off, weight decay 0) over up to 8 tensors in one launch — the six parameter
  * groups of GaussianModel [REF scene/gaussian_model.py:222-231], stepped at [REF mp_Mapper.py:247].  Arrays are HOST

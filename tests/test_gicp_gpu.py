@@ -148,3 +148,37 @@ def test_distances_beyond_gate_are_exact():
         out.append(r)
     assert (out[0]["idx"] < 0).mean() > 0.2
     assert np.array_equal(out[0]["d2"], out[1]["d2"]) and np.array_equal(out[0]["idx"], out[1]["idx"])
+
+
+def _clouds():
+    rng = np.random.default_rng(11)
+    plane = np.c_[rng.uniform(-2, 2, (4000, 2)), 0.002 * rng.standard_normal(4000)]
+    volume = rng.uniform(-1, 1, (3000, 3))
+    clusters = np.r_[rng.normal(0, 0.05, (600, 3)), rng.normal(0, 0.05, (15, 3)) + [40.0, 0, 0], rng.normal(0, 0.3, (300, 3)) + [0, 9.0, 0]]
+    line = np.c_[np.linspace(0, 5, 700), np.zeros(700), np.zeros(700)] + 1e-4 * rng.standard_normal((700, 3))
+    lattice = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(12)), -1).reshape(-1, 3) * 0.1   # many exactly tied distances
+    dup = np.r_[volume[:500], volume[:500], volume[:40]]                                                      # exact duplicates
+    tiny = rng.uniform(-1, 1, (10, 3))                                                                       # fewer points than k
+    return dict(plane=plane, volume=volume, clusters=clusters, line=line, lattice=lattice, dup=dup, tiny=tiny)
+
+
+@pytest.mark.parametrize("name", ["plane", "volume", "clusters", "line", "lattice", "dup", "tiny"])
+def test_knn_covariances_match_oracle_on_awkward_clouds(name):
+    """The grid k-NN (ring growth, whole-grid and scan-everything fallbacks, distance ties broken by index) must select the
+    same neighbours as the oracle's exhaustive search: scales and covariances agree to fp64 summation-order tolerance."""
+    import oracle
+    import pygicp
+    pts = _clouds()[name].astype(np.float32)
+    out = []
+    for reg in (pygicp.FastGICP(), oracle.OracleGICP()):
+        reg.set_max_knn_distance(99999.0)
+        reg.set_input_source(pts)
+        reg.calculate_source_covariance()
+        q = np.reshape(np.array(reg.get_source_rotationsq()), (-1, 4))
+        s = np.reshape(np.array(reg.get_source_scales()), (-1, 3))
+        out.append((q, s))
+    (qg, sg), (qo, so) = out
+    assert sg.shape == so.shape == (len(pts), 3)
+    np.testing.assert_allclose(sg, so, rtol=2e-5, atol=1e-7)
+    cg, co = quat_cov(qg.astype(np.float64), sg.astype(np.float64)), quat_cov(qo.astype(np.float64), so.astype(np.float64))
+    np.testing.assert_allclose(cg, co, atol=2e-6 * max(1.0, float(np.abs(co).max())))

@@ -90,3 +90,31 @@ def test_fused_adam_matches_torch_adam():
     st = fused.state[gpu_p[0]]
     assert set(st) >= {"step", "exp_avg", "exp_avg_sq"} and int(st["step"]) == 25
     np.testing.assert_allclose(st["exp_avg"].cpu().numpy(), ref.state[ref_p[0]]["exp_avg"].numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_fused_activations_match_torch_ops():
+    from gs_icp_slam_amd.activations import activate
+    torch.manual_seed(3)
+    P = 5000
+    raw = [torch.randn(P, 1, device="cuda") * 3, torch.randn(P, 3, device="cuda") - 4, torch.randn(P, 4, device="cuda")]
+    raw[2][7] = 0.0                                    # zero quaternion: normalize clamps the norm at 1e-12
+    a = [r.clone().requires_grad_(True) for r in raw]
+    b = [r.clone().requires_grad_(True) for r in raw]
+    oa, sa, qa = activate(*a)
+    ob, sb, qb = torch.sigmoid(b[0]), torch.exp(b[1]), torch.nn.functional.normalize(b[2])
+    torch.testing.assert_close(oa, ob, rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(sa, sb, rtol=2e-6, atol=0)
+    torch.testing.assert_close(qa, qb, rtol=2e-6, atol=1e-7)
+    w = [torch.randn_like(oa), torch.randn_like(sa), torch.randn_like(qa)]
+    (oa * w[0]).sum().add((sa * w[1]).sum()).add((qa * w[2]).sum()).backward()
+    (ob * w[0]).sum().add((sb * w[1]).sum()).add((qb * w[2]).sum()).backward()
+    for x, y in zip(a, b):
+        torch.testing.assert_close(x.grad, y.grad, rtol=2e-5, atol=1e-6)
+    # partial gradients: only the opacity branch is used downstream
+    c = [r.clone().requires_grad_(True) for r in raw]
+    oc, _, _ = activate(*c)
+    oc.sum().backward()
+    torch.testing.assert_close(c[0].grad, (ob * (1 - ob)).detach(), rtol=2e-5, atol=1e-7)
+    assert torch.all(c[1].grad == 0) and torch.all(c[2].grad == 0)
+    with pytest.raises(RuntimeError):
+        activate(*[r.cpu() for r in raw])

@@ -72,8 +72,9 @@ def pmc_means(d):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    src = os.path.join(ROOT, "gpurun_out", tag)
+    src_tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[2] if len(sys.argv) > 2 else src_tag          # collect_profiles.py <gpurun_out subdir> [<profiles prefix>]
+    src = os.path.join(ROOT, "gpurun_out", src_tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     for name in ("bench", "bench_tum", "bench_eager", "bench_under_rocprof"):

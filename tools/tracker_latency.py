@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Wall-clock breakdown of one tracker frame (the four pygicp calls of mp_Tracker.py:191-231) with the GPU otherwise idle."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401,E402
+import pygicp  # noqa: E402
+from gs_icp_slam_amd import _lib, synth  # noqa: E402
+
+cfg = synth.REPLICA if "--tum" not in sys.argv else synth.TUM
+sp = synth.s_pair(cfg, noise=("--tum" in sys.argv))
+pw = sp["points_a"].astype(np.float64) @ sp["pose_a"][:3, :3].T + sp["pose_a"][:3, 3]
+
+
+def filt(n, tr):
+    f = np.zeros(n, np.int32)
+    f[tr] = np.arange(1, len(tr) + 1)
+    return f
+
+
+reg = pygicp.FastGICP()
+reg.set_max_correspondence_distance(cfg["max_corr"])
+reg.set_max_knn_distance(99999.0)
+reg.set_input_target(pw)
+reg.set_target_filter(len(sp["trackable_a"]), filt(len(pw), sp["trackable_a"]))
+reg.calculate_target_covariance_with_filter()
+f_src = filt(len(sp["points_b"]), sp["trackable_b"])
+names = ["set_input_source", "set_source_filter", "align", "get_source_correspondence"]
+acc = np.zeros(4)
+N = 300
+_lib.profile_enable(True)
+for it in range(N + 20):
+    if it == 20:
+        acc[:] = 0
+        _lib.profile_read()
+        t_all = time.perf_counter()
+    t0 = time.perf_counter()
+    reg.set_input_source(sp["points_b"])
+    t1 = time.perf_counter()
+    reg.set_source_filter(len(sp["trackable_b"]), f_src)
+    t2 = time.perf_counter()
+    T = reg.align(sp["pose_a"])
+    t3 = time.perf_counter()
+    idx, d2 = reg.get_source_correspondence()
+    t4 = time.perf_counter()
+    acc += [t1 - t0, t2 - t1, t3 - t2, t4 - t3]
+wall = (time.perf_counter() - t_all) / N
+prof = _lib.profile_read()
+print("frame wall %.1f us" % (wall * 1e6))
+for n, a in zip(names, acc):
+    print("  %-28s %.1f us" % (n, a / N * 1e6))
+print("  kernels:", {k: round(1e3 * ms / N, 1) for k, (ms, c) in prof.items() if c > 0})
+print("  align stats:", reg.last_align_stats())
+print("  knn grid:", reg.knn_stats())
