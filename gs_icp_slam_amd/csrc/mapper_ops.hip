@@ -11,6 +11,7 @@
 // pixel-channel, pass 2 reads 5 and writes 1.  Sums are reduced per workgroup and finished by a tiny second kernel in
 // a fixed order (no float atomics: results are bit-reproducible).
 #include <cmath>
+#include <cstdint>
 #include <string>
 
 #include <hip/hip_runtime.h>
@@ -23,9 +24,12 @@ extern thread_local std::string g_last_error;
 
 namespace {
 
-constexpr int LT = 16;            // output tile
+constexpr int LT = 32;            // output tile (32 x 32 pixels per 256-thread workgroup, 4 pixels per thread)
 constexpr int HALO = 5;           // 11x11 window
-constexpr int LW = LT + 2 * HALO; // 26
+constexpr int LW = LT + 2 * HALO; // 42
+constexpr int LWS = 44;           // staged row stride (floats): 16-byte aligned rows for ds_read_b128
+constexpr int LHS = 36;           // row stride of the horizontally filtered maps (16-byte aligned float4 stores)
+constexpr int HSEG = LT / 4;      // 4-column segments per row in the horizontal pass
 
 struct Win { float w[11]; };   // the reference's normalised 11-tap Gaussian (its 2-D window is the float32 outer product of this)
 
@@ -34,84 +38,135 @@ __device__ inline float wave_sum_f(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
+// 16 consecutive staged values -> registers (four 128-bit LDS reads)
+__device__ inline void lds_load16(const float* __restrict__ row, float v[16]) {
+    const float4* p = (const float4*)row;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float4 t = p[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+}
+// four adjacent outputs of the 11-tap filter from 14 inputs held in registers (same tap order as a scalar loop: k = 0..10)
+__device__ inline float4 conv4(const float v[16], const Win& win) {
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float w = win.w[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += w * v[j + k];
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
 
 // Pass 1.  grid = (tiles_x, tiles_y, 4): z = 0..2 colour channels, z = 3 the depth L1 term (no SSIM).
 // partial[(z * n_tiles + tile) * 2 + {0,1}] = {sum of masked |diff|, sum of SSIM map} of this workgroup.
+// Register tiling: the horizontal pass makes 4 adjacent outputs from 14 staged values (4 x ds_read_b128 per array), the vertical
+// pass 4 stacked outputs from 14 rows — a quarter of the LDS traffic of one-output-per-thread, and a 1.7x halo instead of 2.6x.
 __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict__ image, const float* __restrict__ depth,
                                                          const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
                                                          Win win, float d_max, float dS_scale /* = -lambda / (3HW) */,
                                                          float* __restrict__ abc /* (3, 3, H, W): A, B, C per channel */,
                                                          float* __restrict__ partial) {
-    __shared__ float s_x[LW][LW + 1], s_y[LW][LW + 1];
-    __shared__ float s_h[5][LW][LT + 1];
+    __shared__ __attribute__((aligned(16))) float s_x[LW][LWS];
+    __shared__ __attribute__((aligned(16))) float s_y[LW][LWS];
+    __shared__ __attribute__((aligned(16))) float s_h[5][LW][LHS];
     __shared__ float s_red[4][2];
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int tid = threadIdx.x;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
     const size_t HW = (size_t)W * H;
     const int n_tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    const int lx = tid & 31, ry = tid >> 5;      // this thread's output column and its group of four rows
     float l1 = 0.f, ssum = 0.f;
     if (ch == 3) {   // depth term: L1(depth / d_max, gt_depth / d_max), masked where gt == 0
-        const int px = x0 + lx, py = y0 + ly;
-        if (px < W && py < H) {
-            const float g = gt_depth[(size_t)py * W + px] / d_max;
-            const float d = depth[(size_t)py * W + px] / d_max;
-            if (g != 0.f) l1 = fabsf(d - g);
+        const int px = x0 + lx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int py = y0 + 4 * ry + j;
+            if (px < W && py < H) {
+                const float g = gt_depth[(size_t)py * W + px] / d_max;
+                const float d = depth[(size_t)py * W + px] / d_max;
+                if (g != 0.f) l1 += fabsf(d - g);
+            }
         }
     } else {
-        // stage the halo tile: y = gt * (gt_depth > 0), x = where(y != 0, image, 0); zero outside the image
-        for (int i = tid; i < LW * LW; i += 256) {
-            const int r = i / LW, c = i % LW;
+        // stage the halo tile: y = gt * (gt_depth > 0), x = where(y != 0, image, 0); zero outside the image.  All loads of the
+        // (unrolled) loop are unconditional on clamped addresses and issued before the first use: this phase is pure latency.
+        constexpr int NST = (LW * LWS + 255) / 256;
+        float gd[NST], gi[NST], im[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + u * 256, r = i / LWS, c = i % LWS;
+            int px = x0 + c - HALO, py = y0 + r - HALO;
+            px = px < 0 ? 0 : (px >= W ? W - 1 : px);
+            py = py < 0 ? 0 : (py >= H ? H - 1 : py);
+            const size_t pix = (size_t)py * W + px;
+            gd[u] = gt_depth[pix]; gi[u] = gt_image[ch * HW + pix]; im[u] = image[ch * HW + pix];
+        }
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + u * 256, r = i / LWS, c = i % LWS;
             const int px = x0 + c - HALO, py = y0 + r - HALO;
-            float xv = 0.f, yv = 0.f;
-            if (px >= 0 && px < W && py >= 0 && py < H) {
-                const size_t pix = (size_t)py * W + px;
-                yv = gt_depth[pix] > 0.f ? gt_image[ch * HW + pix] : 0.f;
-                xv = yv != 0.f ? image[ch * HW + pix] : 0.f;
+            if (i < LW * LWS) {
+                const bool in = c < LW && px >= 0 && px < W && py >= 0 && py < H;
+                const float yv = (in && gd[u] > 0.f) ? gi[u] : 0.f;
+                s_x[r][c] = yv != 0.f ? im[u] : 0.f;
+                s_y[r][c] = yv;
             }
-            s_x[r][c] = xv; s_y[r][c] = yv;
         }
         __syncthreads();
         // Separable evaluation (11 + 11 taps instead of 121).  The reference convolves with the float32 outer product g g^T; the
         // separable form differs from it only by the rounding of the 121 products (relative 6e-8, zero-mean) PROVIDED the 1-D
         // weights are bit-identical to the reference's (an early version normalised them with a sequentially rounded sum, one ulp
         // off, and that 6e-8 scale error alone moved the SSIM mean by 1e-5 through sigma = E[xx] - mu^2).
-        for (int i = tid; i < LW * LT; i += 256) {
-            const int r = i / LT, c = i % LT;
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+        for (int it = tid; it < LW * HSEG; it += 256) {
+            const int r = it / HSEG, c0 = 4 * (it % HSEG);
+            float xv[16], yv[16], pr[16];
+            lds_load16(&s_x[r][c0], xv);
+            lds_load16(&s_y[r][c0], yv);
+            *(float4*)&s_h[0][r][c0] = conv4(xv, win);
+            *(float4*)&s_h[1][r][c0] = conv4(yv, win);
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float xv = s_x[r][c + k], yv = s_y[r][c + k], w = win.w[k];
-                m0 += w * xv; m1 += w * yv; m2 += w * (xv * xv); m3 += w * (yv * yv); m4 += w * (xv * yv);
-            }
-            s_h[0][r][c] = m0; s_h[1][r][c] = m1; s_h[2][r][c] = m2; s_h[3][r][c] = m3; s_h[4][r][c] = m4;
+            for (int i = 0; i < 14; ++i) pr[i] = xv[i] * xv[i];
+            *(float4*)&s_h[2][r][c0] = conv4(pr, win);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) pr[i] = yv[i] * yv[i];
+            *(float4*)&s_h[3][r][c0] = conv4(pr, win);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) pr[i] = xv[i] * yv[i];
+            *(float4*)&s_h[4][r][c0] = conv4(pr, win);
         }
         __syncthreads();
-        const int px = x0 + lx, py = y0 + ly;
-        if (px < W && py < H) {
-            float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+        float mom[5][4];
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float w = win.w[k];
-                mu1 += w * s_h[0][ly + k][lx]; mu2 += w * s_h[1][ly + k][lx]; e11 += w * s_h[2][ly + k][lx];
-                e22 += w * s_h[3][ly + k][lx]; e12 += w * s_h[4][ly + k][lx];
+        for (int m = 0; m < 5; ++m) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) v[i] = s_h[m][4 * ry + i][lx];
+            const float4 o = conv4(v, win);
+            mom[m][0] = o.x; mom[m][1] = o.y; mom[m][2] = o.z; mom[m][3] = o.w;
+        }
+        const int px = x0 + lx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int py = y0 + 4 * ry + j;
+            if (px < W && py < H) {
+                const float mu1 = mom[0][j], mu2 = mom[1][j], e11 = mom[2][j], e22 = mom[3][j], e12 = mom[4][j];
+                const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+                const float a = 2.f * mu12 + C1, b = 2.f * (e12 - mu12) + C2;
+                const float c = mu1_sq + mu2_sq + C1, d = (e11 - mu1_sq) + (e22 - mu2_sq) + C2;
+                const float inv_cd = 1.f / (c * d);
+                const float S = a * b * inv_cd;
+                ssum += S;
+                // dS/d(mu1), dS/d(E[xx]), dS/d(E[xy]) with mu2, E[yy] fixed (the target image carries no gradient)
+                const float dS_dmu1 = 2.f * mu2 * (b - a) * inv_cd - 2.f * mu1 * S * (d - c) * inv_cd;
+                const float dS_de11 = -S / d;
+                const float dS_de12 = 2.f * a * inv_cd;
+                const size_t pix = (size_t)py * W + px;
+                abc[(ch * 3 + 0) * HW + pix] = dS_scale * dS_dmu1;
+                abc[(ch * 3 + 1) * HW + pix] = dS_scale * dS_de11;
+                abc[(ch * 3 + 2) * HW + pix] = dS_scale * dS_de12;
+                const float xc = s_x[4 * ry + j + HALO][lx + HALO], yc = s_y[4 * ry + j + HALO][lx + HALO];
+                if (yc != 0.f) l1 += fabsf(xc - yc);
             }
-            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float a = 2.f * mu12 + C1, b = 2.f * (e12 - mu12) + C2;
-            const float c = mu1_sq + mu2_sq + C1, d = (e11 - mu1_sq) + (e22 - mu2_sq) + C2;
-            const float inv_cd = 1.f / (c * d);
-            const float S = a * b * inv_cd;
-            ssum = S;
-            // dS/d(mu1), dS/d(E[xx]), dS/d(E[xy]) with mu2, E[yy] fixed (the target image carries no gradient)
-            const float dS_dmu1 = 2.f * mu2 * (b - a) * inv_cd - 2.f * mu1 * S * (d - c) * inv_cd;
-            const float dS_de11 = -S / d;
-            const float dS_de12 = 2.f * a * inv_cd;
-            const size_t pix = (size_t)py * W + px;
-            abc[(ch * 3 + 0) * HW + pix] = dS_scale * dS_dmu1;
-            abc[(ch * 3 + 1) * HW + pix] = dS_scale * dS_de11;
-            abc[(ch * 3 + 2) * HW + pix] = dS_scale * dS_de12;
-            const float xv = s_x[ly + HALO][lx + HALO], yv = s_y[ly + HALO][lx + HALO];
-            if (yv != 0.f) l1 = fabsf(xv - yv);
         }
     }
     l1 = wave_sum_f(l1); ssum = wave_sum_f(ssum);
@@ -124,87 +179,140 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
 }
 
 // Finish the sums in a fixed order and form the loss.  out = {loss, L1, SSIM mean, depth L1}.
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ partial, int n_tiles, float inv_n_img, float inv_n_depth,
-                                                          float lambda_dssim, float depth_weight, float* __restrict__ out) {
-    __shared__ double s_acc[3][256];
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float2* __restrict__ partial, int n_tiles, float inv_n_img, float inv_n_depth,
+                                                           float lambda_dssim, float depth_weight, float* __restrict__ out) {
+    __shared__ double s_acc[3][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double l1 = 0, ss = 0, ld = 0;
-    for (int i = tid; i < 3 * n_tiles; i += 256) { l1 += partial[(size_t)i * 2]; ss += partial[(size_t)i * 2 + 1]; }
-    for (int i = tid; i < n_tiles; i += 256) ld += partial[((size_t)3 * n_tiles + i) * 2];
-    s_acc[0][tid] = l1; s_acc[1][tid] = ss; s_acc[2][tid] = ld;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) { s_acc[0][tid] += s_acc[0][tid + s]; s_acc[1][tid] += s_acc[1][tid + s]; s_acc[2][tid] += s_acc[2][tid + s]; }
-        __syncthreads();
+    const int n_img = 3 * n_tiles, n_all = 4 * n_tiles;
+    for (int base = 0; base < n_all; base += 4 * 1024) {   // four independent loads in flight per thread (the loop is latency-bound)
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * 1024 + tid;
+            v[u] = i < n_all ? partial[i] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * 1024 + tid;
+            if (i < n_img) { l1 += (double)v[u].x; ss += (double)v[u].y; }
+            else if (i < n_all) ld += (double)v[u].x;
+        }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { l1 += __shfl_down(l1, off, 64); ss += __shfl_down(ss, off, 64); ld += __shfl_down(ld, off, 64); }
+    if (lane == 0) { s_acc[0][wave] = l1; s_acc[1][wave] = ss; s_acc[2][wave] = ld; }
+    __syncthreads();
     if (tid == 0) {
-        const float L1 = (float)(s_acc[0][0] * inv_n_img), SS = (float)(s_acc[1][0] * inv_n_img), LD = (float)(s_acc[2][0] * inv_n_depth);
+        double a = 0, b = 0, c = 0;
+        for (int w = 0; w < 16; ++w) { a += s_acc[0][w]; b += s_acc[1][w]; c += s_acc[2][w]; }
+        const float L1 = (float)(a * inv_n_img), SS = (float)(b * inv_n_img), LD = (float)(c * inv_n_depth);
         out[0] = (1.f - lambda_dssim) * L1 + lambda_dssim * (1.f - SS) + depth_weight * LD;
         out[1] = L1; out[2] = SS; out[3] = LD;
     }
 }
 
-// Pass 2.  dL/dx(p) = sum_q w(q - p) [A_q + 2 x_p B_q + y_p C_q]  (+ the L1 sign term), masked where y == 0.
+// Pass 2.  dL/dx(p) = sum_q w(q - p) [A_q + 2 x_p B_q + y_p C_q]  (+ the L1 sign term), masked where y == 0.  Same tiling as pass 1.
 __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict__ image, const float* __restrict__ depth,
                                                          const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
                                                          Win win, float d_max, float l1_scale /* (1 - lambda) / (3HW) */,
                                                          float depth_scale /* w_d / (HW d_max) */, const float* __restrict__ abc,
                                                          float* __restrict__ dL_dimage, float* __restrict__ dL_ddepth) {
-    __shared__ float s_in[3][LW][LW + 1];
-    __shared__ float s_h[3][LW][LT + 1];
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    __shared__ __attribute__((aligned(16))) float s_in[3][LW][LWS];
+    __shared__ __attribute__((aligned(16))) float s_h[3][LW][LHS];
+    const int tid = threadIdx.x, lx = tid & 31, ry = tid >> 5;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
     const size_t HW = (size_t)W * H;
-    const int px = x0 + lx, py = y0 + ly;
+    const int px = x0 + lx;
     if (ch == 3) {
-        if (px < W && py < H) {
-            const size_t pix = (size_t)py * W + px;
-            const float g = gt_depth[pix] / d_max, d = depth[pix] / d_max;
-            float gr = 0.f;
-            if (g != 0.f) gr = d > g ? depth_scale : (d < g ? -depth_scale : 0.f);
-            dL_ddepth[pix] = gr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int py = y0 + 4 * ry + j;
+            if (px < W && py < H) {
+                const size_t pix = (size_t)py * W + px;
+                const float g = gt_depth[pix] / d_max, d = depth[pix] / d_max;
+                float gr = 0.f;
+                if (g != 0.f) gr = d > g ? depth_scale : (d < g ? -depth_scale : 0.f);
+                dL_ddepth[pix] = gr;
+            }
         }
         return;
     }
-    for (int i = tid; i < LW * LW; i += 256) {
-        const int r = i / LW, c = i % LW;
-        const int qx = x0 + c - HALO, qy = y0 + r - HALO;
-        float a = 0.f, b = 0.f, cc = 0.f;
-        if (qx >= 0 && qx < W && qy >= 0 && qy < H) {
+    {
+        constexpr int NST = (LW * LWS + 255) / 256;
+        float va[NST], vb[NST], vc[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {   // unconditional loads on clamped addresses, all in flight together
+            const int i = tid + u * 256, r = i / LWS, c = i % LWS;
+            int qx = x0 + c - HALO, qy = y0 + r - HALO;
+            qx = qx < 0 ? 0 : (qx >= W ? W - 1 : qx);
+            qy = qy < 0 ? 0 : (qy >= H ? H - 1 : qy);
             const size_t q = (size_t)qy * W + qx;
-            a = abc[(ch * 3 + 0) * HW + q]; b = abc[(ch * 3 + 1) * HW + q]; cc = abc[(ch * 3 + 2) * HW + q];
+            va[u] = abc[(ch * 3 + 0) * HW + q]; vb[u] = abc[(ch * 3 + 1) * HW + q]; vc[u] = abc[(ch * 3 + 2) * HW + q];
         }
-        s_in[0][r][c] = a; s_in[1][r][c] = b; s_in[2][r][c] = cc;
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + u * 256, r = i / LWS, c = i % LWS;
+            const int qx = x0 + c - HALO, qy = y0 + r - HALO;
+            if (i < LW * LWS) {
+                const bool in = c < LW && qx >= 0 && qx < W && qy >= 0 && qy < H;
+                s_in[0][r][c] = in ? va[u] : 0.f; s_in[1][r][c] = in ? vb[u] : 0.f; s_in[2][r][c] = in ? vc[u] : 0.f;
+            }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < LW * LT; i += 256) {
-        const int r = i / LT, c = i % LT;
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (int it = tid; it < LW * HSEG; it += 256) {
+        const int r = it / HSEG, c0 = 4 * (it % HSEG);
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];
-            m0 += w * s_in[0][r][c + k]; m1 += w * s_in[1][r][c + k]; m2 += w * s_in[2][r][c + k];
+        for (int m = 0; m < 3; ++m) {
+            float v[16];
+            lds_load16(&s_in[m][r][c0], v);
+            *(float4*)&s_h[m][r][c0] = conv4(v, win);
         }
-        s_h[0][r][c] = m0; s_h[1][r][c] = m1; s_h[2][r][c] = m2;
     }
     __syncthreads();
-    if (px < W && py < H) {
-        float cA = 0.f, cB = 0.f, cC = 0.f;
+    float acc[3][4];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];   // symmetric window: correlation == convolution
-            cA += w * s_h[0][ly + k][lx]; cB += w * s_h[1][ly + k][lx]; cC += w * s_h[2][ly + k][lx];
-        }
-        const size_t pix = (size_t)py * W + px;
-        const float yv = gt_depth[pix] > 0.f ? gt_image[ch * HW + pix] : 0.f;
-        float gr = 0.f;
-        if (yv != 0.f) {
-            const float xv = image[ch * HW + pix];
-            gr = cA + 2.f * xv * cB + yv * cC;
-            gr += xv > yv ? l1_scale : (xv < yv ? -l1_scale : 0.f);
-        }
-        dL_dimage[ch * HW + pix] = gr;
+    for (int m = 0; m < 3; ++m) {   // symmetric window: correlation == convolution
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) v[i] = s_h[m][4 * ry + i][lx];
+        const float4 o = conv4(v, win);
+        acc[m][0] = o.x; acc[m][1] = o.y; acc[m][2] = o.z; acc[m][3] = o.w;
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int py = y0 + 4 * ry + j;
+        if (px < W && py < H) {
+            const size_t pix = (size_t)py * W + px;
+            const float yv = gt_depth[pix] > 0.f ? gt_image[ch * HW + pix] : 0.f;
+            float gr = 0.f;
+            if (yv != 0.f) {
+                const float xv = image[ch * HW + pix];
+                gr = acc[0][j] + 2.f * xv * acc[1][j] + yv * acc[2][j];
+                gr += xv > yv ? l1_scale : (xv < yv ? -l1_scale : 0.f);
+            }
+            dL_dimage[ch * HW + pix] = gr;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ keyframe selection
+// The captured mapper iteration reads its camera and target images from fixed device buffers; selecting the keyframe of the
+// next replay is ONE launch that refreshes all five (five separate runtime copies cost ~5 us each of fixed latency).
+__global__ __launch_bounds__(256) void set_view_kernel(const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+                                                       const float4* __restrict__ gt_image, const float4* __restrict__ gt_depth, size_t n4_image,
+                                                       size_t n4_depth, float* __restrict__ d_view, float* __restrict__ d_proj,
+                                                       float* __restrict__ d_campos, float4* __restrict__ d_gt_image, float4* __restrict__ d_gt_depth) {
+    if (blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t < 16) d_view[t] = view[t];
+        else if (t < 32) d_proj[t - 16] = proj[t - 16];
+        else if (t < 35) d_campos[t - 32] = campos[t - 32];
+    }
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4_image; i += stride) d_gt_image[i] = gt_image[i];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4_depth; i += stride) d_gt_depth[i] = gt_depth[i];
 }
 
 // ------------------------------------------------------------------------------------------------ Adam
@@ -360,12 +468,30 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
     const float n_img = 3.f * (float)HW;
     hipLaunchKernelGGL(loss_pass1_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                        -lambda_dssim / n_img, abc, partial);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim,
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, stream, (const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim,
                        depth_weight, loss_out);
     if (dL_dimage && dL_ddepth)
         hipLaunchKernelGGL(loss_pass2_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                            (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss: kernel launch failed"; return -1; }
+    return 0;
+}
+
+int gsicp_mapper_set_view(int width, int height, const float* viewmatrix, const float* projmatrix, const float* campos, const float* gt_image,
+                          const float* gt_depth, float* dst_viewmatrix, float* dst_projmatrix, float* dst_campos, float* dst_gt_image,
+                          float* dst_gt_depth, void* stream) {
+    const size_t HW = (size_t)width * height;
+    if (width <= 0 || height <= 0 || (HW & 3) || !viewmatrix || !projmatrix || !campos || !gt_image || !gt_depth || !dst_viewmatrix ||
+        !dst_projmatrix || !dst_campos || !dst_gt_image || !dst_gt_depth) {
+        g_last_error = "gsicp_mapper_set_view: bad arguments (width*height must be a multiple of 4)"; return -2;
+    }
+    if ((((uintptr_t)gt_image | (uintptr_t)gt_depth | (uintptr_t)dst_gt_image | (uintptr_t)dst_gt_depth) & 15) != 0) {
+        g_last_error = "gsicp_mapper_set_view: image buffers must be 16-byte aligned"; return -2;
+    }
+    hipLaunchKernelGGL(set_view_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, viewmatrix, projmatrix, campos, (const float4*)gt_image,
+                       (const float4*)gt_depth, 3 * HW / 4, HW / 4, dst_viewmatrix, dst_projmatrix, dst_campos, (float4*)dst_gt_image,
+                       (float4*)dst_gt_depth);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_set_view: kernel launch failed"; return -1; }
     return 0;
 }
 

@@ -12,8 +12,11 @@ Adam state, learning rates, step count) is updated in place by the replay.  The 
 are the ones captured: after the map grows or is pruned (new parameter tensors, [REF scene/gaussian_model.py:409-492]) build
 a new MapperIterationGraph — capture costs about three eager iterations.
 """
+import ctypes
+
 import torch
 
+from . import _lib
 from .activations import activate
 from .loss import mapper_loss_and_grads
 from .optim import FusedAdam
@@ -75,8 +78,21 @@ class MapperIterationGraph:
 
     # ------------------------------------------------------------------------------------------------------------
     def set_view(self, viewmatrix, projmatrix, campos, gt_image, gt_depth):
-        """Select the keyframe of the next step(): asynchronous device copies into the graph's static inputs."""
-        self.viewmatrix.copy_(viewmatrix, non_blocking=True)
+        """Select the keyframe of the next step(): one launch refreshes the graph's static inputs (device tensors in, float32)."""
+        ok = lambda t, n: t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n and t.data_ptr() % 16 == 0
+        HW = self.gt_depth.numel()
+        if HW % 4 == 0 and ok(viewmatrix, 16) and ok(projmatrix, 16) and campos.is_cuda and campos.dtype == torch.float32 and \
+                campos.numel() == 3 and campos.is_contiguous() and ok(gt_image, 3 * HW) and ok(gt_depth, HW):
+            lib = _lib.load()
+            dev = self.gt_depth.device
+            p = lambda t: ctypes.c_void_p(t.data_ptr())
+            with torch.cuda.device(dev):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                _lib.check(lib.gsicp_mapper_set_view(self.gt_depth.shape[-1], self.gt_depth.shape[-2], p(viewmatrix), p(projmatrix), p(campos),
+                                                     p(gt_image), p(gt_depth), p(self.viewmatrix), p(self.projmatrix), p(self.campos),
+                                                     p(self.gt_image), p(self.gt_depth), stream), "gsicp_mapper_set_view")
+            return
+        self.viewmatrix.copy_(viewmatrix, non_blocking=True)          # host tensors / other dtypes: plain copies
         self.projmatrix.copy_(projmatrix, non_blocking=True)
         self.campos.copy_(campos.reshape(3), non_blocking=True)
         self.gt_image.copy_(gt_image.reshape(self.gt_image.shape), non_blocking=True)

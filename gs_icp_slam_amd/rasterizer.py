@@ -114,6 +114,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 if count_out is not None:
                     count_out.fill_(max(int(n), 0))
             _lib.check(n, "gsicp_raster_forward")
+        ctx.set_materialize_grads(False)   # no zero tensors for the non-differentiable int outputs (two 5 us fills per backward otherwise)
         ctx.rs = rs
         ctx.num_rendered = n
         ctx.M = int(M)

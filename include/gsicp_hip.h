@@ -195,6 +195,13 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
                       float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
                       char* scratch, void* stream);
 
+/* Keyframe selection for a captured (hipGraph) mapper iteration: copies the camera (viewmatrix 16, projmatrix 16, campos 3 floats)
+ * and the two target images (gt_image (3,H,W), gt_depth (1,H,W)) of the chosen keyframe [REF mp_Mapper.py:205-217] into the fixed
+ * DEVICE buffers the captured kernels read, in one launch.  All pointers are DEVICE pointers; images 16-byte aligned, W*H % 4 == 0. */
+int gsicp_mapper_set_view(int width, int height, const float* viewmatrix, const float* projmatrix, const float* campos, const float* gt_image,
+                          const float* gt_depth, float* dst_viewmatrix, float* dst_projmatrix, float* dst_campos, float* dst_gt_image,
+                          float* dst_gt_depth, void* stream);
+
 /* GaussianModel's activation getters in one launch each way [REF scene/gaussian_model.py:44-56, 105-125], reached from
  * render_3 at [REF gaussian_renderer/__init__.py:263, 273-274]: opacity = sigmoid(opacity_raw) (P), scaling =
  * exp(scaling_raw) (P,3), rotation = rotation_raw / max(||rotation_raw||, 1e-12) (P,4).  All DEVICE float arrays. */
