@@ -277,11 +277,22 @@ def main():
         tj = json.load(open(tpath)).get(dominant)
         if tj:
             traffic = int(tj["fetch_bytes"] + tj["write_bytes"])
+    # the blend kernels gather 48-byte records that sit in the 256 MiB Infinity Cache: they are instruction-issue bound, not HBM bound.
+    # When the SQ counter pass of this command is on disk (profiles/), state the VALU-issue floor next to the HBM fraction.
+    note = "working set (~60 MB) sits in the 256 MiB Infinity Cache; the kernel is VALU-issue bound, the HBM fraction is a formality"
+    kernel_of = {"blend_backward": "blend_backward_strip_kernel", "blend_forward": "blend_forward_strip_kernel"}
+    sqpath = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_sq.csv")
+    if os.path.exists(sqpath) and dominant in kernel_of and world == 1 and args.res == "replica" and P == 300_000:
+        import csv
+        for row in csv.DictReader(open(sqpath)):
+            if row["kernel"] == kernel_of[dominant] and float(row.get("SQ_INSTS_VALU", 0) or 0) > 0:
+                valu = float(row["SQ_INSTS_VALU"])
+                floor_us = valu * 4.0 / 1024.0 / 2.4e3      # wave64 VALU op = 4 cycles on a 16-lane SIMD; 1024 SIMDs; 2.4 GHz
+                note += (f"; SQ_INSTS_VALU = {valu / 1e6:.1f} M wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz = {floor_us:.0f} us "
+                         f"issue floor vs kernel_us (profiles/r01_rocprofv3_pmc_sq.csv)")
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel_us": round(per_launch_us[dominant], 2),
-                "algorithmic_bytes": int(alg_bytes[dominant]),
-                "note": "working set (~60 MB) sits in the 256 MiB Infinity Cache; this kernel is VALU-issue bound: 82 M wave-instructions "
-                        "x ~4 cycles / 1024 SIMDs = 133 us ideal vs the measured kernel_us (PMC in profiles/); HBM fraction is a formality"}
+                "algorithmic_bytes": int(alg_bytes[dominant]), "note": note}
 
     # ---------------- CPU baseline: OpenMP GICP oracle (port), rank 0 only ----------------
     cpu = None
