@@ -73,6 +73,13 @@ SIGNATURES = {
     "gsicp_gicp_align": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gsicp_gicp_get_source_correspondence": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "gsicp_gicp_knn_stats": (c_int, [c_void_p, c_void_p]),
+    "gsicp_gicp_stream": (c_void_p, [c_void_p]),
+    "gsicp_gicp_set_input_target_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    "gsicp_gicp_set_input_source_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    "gsicp_gicp_set_target_covariances_fromqs_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]),
+    "gsicp_gicp_set_target_from_gaussians_device": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "gsicp_gicp_get_source_rotationsq_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "gsicp_gicp_get_source_scales_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gsicp_gicp_num_source": (c_int, [c_void_p]),
     "gsicp_gicp_num_target": (c_int, [c_void_p]),
     "gsicp_gicp_last_align_stats": (c_int, [c_void_p, c_void_p]),

@@ -649,6 +649,7 @@ struct HostMailbox {
     AlignResult result;
     unsigned align_seq;          // written (system scope) after `result`
     unsigned export_seq;         // written after the correspondence export below
+    unsigned scratch_u32;        // small read-backs (selection count)
 };
 
 constexpr int AL_T = 256;        // threads per workgroup
@@ -1107,6 +1108,71 @@ __global__ __launch_bounds__(256) void ingest_track_kernel(int n, const int* __r
     if (i < n) track[i] = h_track[i];
 }
 
+// ---- device-side hand-off: clouds and Gaussians that already live in device memory -----------------
+__global__ __launch_bounds__(256) void ingest_points_dev_kernel(int n, const float* __restrict__ xyz, float4* __restrict__ pts, int* __restrict__ track) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { pts[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f); track[i] = i; }
+}
+__global__ __launch_bounds__(256) void copy_f32_kernel(size_t n, const float* __restrict__ src, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+// Order-preserving selection of the map's trackable Gaussians [REF scene/gaussian_model.py:207-215]:
+// keep i iff opacity[i] > th and trackable_mask[i]; outputs in index order, exactly like torch's boolean indexing.
+__device__ inline bool select_keep(int i, int P, const float* __restrict__ opacity, const unsigned char* __restrict__ mask, float th) {
+    return i < P && opacity[i] > th && (mask == nullptr || mask[i] != 0);
+}
+__global__ __launch_bounds__(256) void select_count_kernel(int P, const float* __restrict__ opacity, const unsigned char* __restrict__ mask, float th,
+                                                           unsigned* __restrict__ block_count) {
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long b = __ballot(select_keep(i, P, opacity, mask, th));
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// single workgroup: exclusive scan of the block counts in place; total -> *total_out and the mailbox
+__global__ __launch_bounds__(1024) void select_scan_kernel(int nblocks, unsigned* __restrict__ block_count, unsigned* __restrict__ total_out) {
+    __shared__ unsigned s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per) < nblocks ? (lo + per) : nblocks;
+    unsigned sum = 0;
+    for (int c = lo; c < hi; ++c) sum += block_count[c];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = s_part[tid] - sum;
+    for (int c = lo; c < hi; ++c) { const unsigned cnt = block_count[c]; block_count[c] = run; run += cnt; }
+    if (tid == 1023) *total_out = s_part[1023];
+}
+__global__ __launch_bounds__(256) void select_scatter_kernel(int P, const float* __restrict__ xyz, const float* __restrict__ rotation,
+                                                             const float* __restrict__ scaling, const float* __restrict__ opacity,
+                                                             const unsigned char* __restrict__ mask, float th, const unsigned* __restrict__ block_base,
+                                                             float4* __restrict__ pts, int* __restrict__ track, float* __restrict__ rotq,
+                                                             float* __restrict__ scales) {
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool keep = select_keep(i, P, opacity, mask, th);
+    const unsigned long long b = __ballot(keep);
+    if (lane == 0) s_w[wave] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (!keep) return;
+    unsigned pos = block_base[blockIdx.x] + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += s_w[w];
+    pts[pos] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
+    track[pos] = (int)pos;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) rotq[4 * (size_t)pos + d] = rotation[4 * (size_t)i + d];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) scales[3 * (size_t)pos + d] = scaling[3 * (size_t)i + d];
+}
+
 // ---------------------------------------------------------------------------------------------- host object
 template <class T>
 struct DevBuf {
@@ -1183,7 +1249,8 @@ struct gsicp_gicp {
     bool stats_pending = false;            // device_us of the last align not read from the events yet
     PinnedBuf<int> h_corr;
     PinnedBuf<float> h_sqd;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_xs = nullptr, ev_xs2 = nullptr;
+    DevBuf<unsigned> sel_blocks;
     AlignResult host_result{};
     bool aligned = false, dist_exact = false;
     std::vector<float> h_stage;
@@ -1383,6 +1450,8 @@ void gsicp_gicp_destroy(gsicp_gicp* g) {
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->ev_done) (void)hipEventDestroy(g->ev_done);
+    if (g->ev_xs) (void)hipEventDestroy(g->ev_xs);
+    if (g->ev_xs2) (void)hipEventDestroy(g->ev_xs2);
     delete g;
 }
 int gsicp_gicp_set_max_correspondence_distance(gsicp_gicp* g, double d) { g->max_corr = d; g->grid_valid = false; return 0; }
@@ -1453,6 +1522,109 @@ int gsicp_gicp_set_target_covariances_fromqs(gsicp_gicp* g, const float* rots, i
     }
     t.cov_valid = true; t.qs_valid = true;
     return 0;
+}
+
+// ---- device-pointer overloads (additive; the numpy API above is unchanged) --------------------------------------------------
+namespace {
+// order the tracker stream after whatever produced the caller's device buffers
+int wait_for_producer(gsicp_gicp* g, void* producer_stream) {
+    if (!g->ev_xs) GC(hipEventCreateWithFlags(&g->ev_xs, hipEventDisableTiming));
+    GC(hipEventRecord(g->ev_xs, (hipStream_t)producer_stream));
+    GC(hipStreamWaitEvent(g->stream, g->ev_xs, 0));
+    return 0;
+}
+int upload_points_device(gsicp_gicp* g, Cloud& c, const float* xyz, int n, void* producer_stream, int wait) {
+    if (n < 0 || (n > 0 && !xyz)) { g_last_error = "bad device point array"; return -2; }
+    c.n = n; c.n_track = n; c.cov_valid = false; c.qs_valid = false;
+    if (c.pts.ensure((size_t)n) || c.track.ensure((size_t)n)) { g_last_error = "hipMalloc failed"; return -1; }
+    if (n > 0) {
+        if (int rc = wait_for_producer(g, producer_stream)) return rc;
+        hipLaunchKernelGGL(ingest_points_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, xyz, c.pts.p, c.track.p);
+        GC(hipGetLastError());
+        if (wait) { if (int rc_ = drain(g)) return rc_; }
+    }
+    return 0;
+}
+}  // namespace
+
+void* gsicp_gicp_stream(gsicp_gicp* g) { return (void*)g->stream; }
+
+int gsicp_gicp_set_input_target_device(gsicp_gicp* g, const float* xyz, int n, void* producer_stream, int wait) {
+    g->grid_valid = false; g->aligned = false;
+    return upload_points_device(g, g->tgt, xyz, n, producer_stream, wait);
+}
+int gsicp_gicp_set_input_source_device(gsicp_gicp* g, const float* xyz, int n, void* producer_stream, int wait) {
+    g->aligned = false;
+    return upload_points_device(g, g->src, xyz, n, producer_stream, wait);
+}
+int gsicp_gicp_set_target_covariances_fromqs_device(gsicp_gicp* g, const float* rots, int n_rots, const float* scales, int n_scales,
+                                                    void* producer_stream, int wait) {
+    Cloud& t = g->tgt;
+    if (n_rots != 4 * t.n || n_scales != 3 * t.n) { g_last_error = "rotations / scales do not match the target cloud size"; return -2; }
+    const size_t n = (size_t)(t.n ? t.n : 1);
+    if (t.cov.ensure(6 * n) || t.rotq.ensure(4 * n) || t.scales.ensure(3 * n)) { g_last_error = "hipMalloc failed"; return -1; }
+    if (t.n > 0) {
+        if (int rc = wait_for_producer(g, producer_stream)) return rc;
+        hipLaunchKernelGGL(copy_f32_kernel, dim3((4 * t.n + 255) / 256), dim3(256), 0, g->stream, (size_t)4 * t.n, rots, t.rotq.p);
+        hipLaunchKernelGGL(copy_f32_kernel, dim3((3 * t.n + 255) / 256), dim3(256), 0, g->stream, (size_t)3 * t.n, scales, t.scales.p);
+        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, t.rotq.p, t.scales.p, t.cov.p);
+        GC(hipGetLastError());
+        if (wait) { if (int rc_ = drain(g)) return rc_; }
+    }
+    t.cov_valid = true; t.qs_valid = true;
+    return 0;
+}
+int gsicp_gicp_set_target_from_gaussians_device(gsicp_gicp* g, int P, const float* xyz, const float* rotation, const float* scaling,
+                                                const float* opacity, const unsigned char* trackable_mask, float opacity_th,
+                                                void* producer_stream) {
+    if (P < 0 || (P > 0 && (!xyz || !rotation || !scaling || !opacity))) { g_last_error = "set_target_from_gaussians: bad arguments"; return -2; }
+    Cloud& t = g->tgt;
+    g->grid_valid = false; g->aligned = false;
+    t.n = 0; t.n_track = 0; t.cov_valid = false; t.qs_valid = false;
+    if (P == 0) return 0;
+    const int nblocks = (P + 255) / 256;
+    const size_t cap = (size_t)P;
+    if (t.pts.ensure(cap) || t.track.ensure(cap) || t.cov.ensure(6 * cap) || t.rotq.ensure(4 * cap) || t.scales.ensure(3 * cap) ||
+        g->sel_blocks.ensure((size_t)nblocks + 1)) { g_last_error = "hipMalloc failed"; return -1; }
+    if (int rc = wait_for_producer(g, producer_stream)) return rc;
+    unsigned* total_dev = g->sel_blocks.p + nblocks;
+    hipLaunchKernelGGL(select_count_kernel, dim3(nblocks), dim3(256), 0, g->stream, P, opacity, trackable_mask, opacity_th, g->sel_blocks.p);
+    hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(1024), 0, g->stream, nblocks, g->sel_blocks.p, total_dev);
+    hipLaunchKernelGGL(select_scatter_kernel, dim3(nblocks), dim3(256), 0, g->stream, P, xyz, rotation, scaling, opacity, trackable_mask, opacity_th,
+                       g->sel_blocks.p, t.pts.p, t.track.p, t.rotq.p, t.scales.p);
+    GC(hipGetLastError());
+    unsigned total = 0;
+    GC(hipMemcpyAsync(&g->mailbox->scratch_u32, total_dev, sizeof(unsigned), hipMemcpyDeviceToHost, g->stream));
+    if (int rc_ = drain(g)) return rc_;
+    total = g->mailbox->scratch_u32;
+    t.n = (int)total; t.n_track = (int)total;
+    if (total > 0) {
+        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, t.rotq.p, t.scales.p, t.cov.p);
+        GC(hipGetLastError());
+    }
+    t.cov_valid = true; t.qs_valid = true;
+    return (int)total;
+}
+static int fetch_floats_device(gsicp_gicp* g, const float* dev, int n_pts, int width, float* out_dev, int cap_pts, void* consumer_stream) {
+    const int n = n_pts < cap_pts ? n_pts : cap_pts;
+    if (n > 0) {
+        if (!out_dev) { g_last_error = "null device output"; return -2; }
+        const size_t cnt = (size_t)n * width;
+        hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g->stream, cnt, dev, out_dev);
+        GC(hipGetLastError());
+        if (!g->ev_xs2) GC(hipEventCreateWithFlags(&g->ev_xs2, hipEventDisableTiming));
+        GC(hipEventRecord(g->ev_xs2, g->stream));
+        GC(hipStreamWaitEvent((hipStream_t)consumer_stream, g->ev_xs2, 0));   // the consumer's stream sees the data; no host wait
+    }
+    return n;
+}
+int gsicp_gicp_get_source_rotationsq_device(gsicp_gicp* g, float* out_dev, int cap, void* consumer_stream) {
+    if (!g->src.qs_valid) { if (int rc = calc_cov(g, g->src)) return rc; }
+    return fetch_floats_device(g, g->src.rotq.p, g->src.n, 4, out_dev, cap, consumer_stream);
+}
+int gsicp_gicp_get_source_scales_device(gsicp_gicp* g, float* out_dev, int cap, void* consumer_stream) {
+    if (!g->src.qs_valid) { if (int rc = calc_cov(g, g->src)) return rc; }
+    return fetch_floats_device(g, g->src.scales.p, g->src.n, 3, out_dev, cap, consumer_stream);
 }
 
 int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {

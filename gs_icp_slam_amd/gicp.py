@@ -4,6 +4,13 @@
 RuntimeError-on-failure behaviour of the pybind11 class the tracker drives [REF mp_Tracker.py:53, 109-110, 157-169,
 191-200, 231, 256-264, 287-288].  Device residency is internal: every call uploads / downloads through the C ABI,
 and all kernels run on the object's own HIP stream.
+
+Additive device-pointer overloads: `set_input_target`, `set_input_source` and
+`set_target_covariances_fromqs` also accept torch tensors on the HIP device (no host round trip; the tracker's stream is ordered
+after torch's current stream), `set_target_from_gaussians(...)` replaces the whole keyframe hand-off
+`get_trackable_gaussians_tensor -> .cpu() -> numpy -> set_input_target + set_target_covariances_fromqs`
+[REF scene/gaussian_model.py:207-215; mp_Tracker.py:284-289], and `get_source_rotationsq_tensor` / `get_source_scales_tensor`
+return device tensors.  The numpy behaviour is unchanged.
 """
 import ctypes
 
@@ -18,6 +25,25 @@ def _vp(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _is_device_tensor(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "is_cuda") and x.is_cuda
+
+
+def _dev_f32(t, shape_last=None):
+    import torch
+    t = t.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    if shape_last is not None and (t.dim() != 2 or t.shape[1] != shape_last):
+        raise RuntimeError(f"pygicp.FastGICP: expected a (N, {shape_last}) tensor")
+    return t
+
+
+def _cur_stream(t):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
 class FastGICP:
     def __init__(self):
         self._lib = _lib.load()
@@ -25,6 +51,7 @@ class FastGICP:
         if not h:
             raise RuntimeError("pygicp.FastGICP (gfx950): " + _lib.last_error())
         self._h = ctypes.c_void_p(h)
+        self._live = []   # device tensors handed over with wait=0: kept alive until the next synchronous call has returned
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -73,12 +100,45 @@ class FastGICP:
         return np.ascontiguousarray(pts, dtype=np.float64 if f64 else np.float32), int(f64)
 
     def set_input_target(self, points):
+        if _is_device_tensor(points):
+            t = _dev_f32(points, 3)
+            self._live.append(t)
+            self._ck(self._lib.gsicp_gicp_set_input_target_device(self._h, ctypes.c_void_p(t.data_ptr()), t.shape[0], _cur_stream(t), 0),
+                     "set_input_target")
+            return
         p, f64 = self._points(points)
         self._ck(self._lib.gsicp_gicp_set_input_target(self._h, _vp(p), p.shape[0], f64), "set_input_target")
 
     def set_input_source(self, points):
+        if _is_device_tensor(points):
+            t = _dev_f32(points, 3)
+            self._live.append(t)
+            self._ck(self._lib.gsicp_gicp_set_input_source_device(self._h, ctypes.c_void_p(t.data_ptr()), t.shape[0], _cur_stream(t), 0),
+                     "set_input_source")
+            return
         p, f64 = self._points(points)
         self._ck(self._lib.gsicp_gicp_set_input_source(self._h, _vp(p), p.shape[0], f64), "set_input_source")
+
+    def set_target_from_gaussians(self, xyz, rotation, scaling, opacity, trackable_mask=None, opacity_th=0.0):
+        """Device-side keyframe hand-off: the Gaussians with opacity > opacity_th (and trackable_mask set) become the target cloud,
+        in index order, with covariances from their (activated) rotations and scales.  Returns the number of target points."""
+        import torch
+        xyz, rotation, scaling = _dev_f32(xyz, 3), _dev_f32(rotation, 4), _dev_f32(scaling, 3)
+        opacity = _dev_f32(opacity.reshape(-1, 1), 1)
+        P = xyz.shape[0]
+        if rotation.shape[0] != P or scaling.shape[0] != P or opacity.shape[0] != P:
+            raise RuntimeError("pygicp.FastGICP.set_target_from_gaussians: tensor sizes differ")
+        m = None
+        if trackable_mask is not None:
+            m = trackable_mask.detach().to(device=xyz.device, dtype=torch.bool).contiguous().view(torch.uint8)
+            if m.numel() != P:
+                raise RuntimeError("pygicp.FastGICP.set_target_from_gaussians: mask size differs")
+        n = self._ck(self._lib.gsicp_gicp_set_target_from_gaussians_device(
+            self._h, P, ctypes.c_void_p(xyz.data_ptr()), ctypes.c_void_p(rotation.data_ptr()), ctypes.c_void_p(scaling.data_ptr()),
+            ctypes.c_void_p(opacity.data_ptr()), None if m is None else ctypes.c_void_p(m.data_ptr()), float(opacity_th), _cur_stream(xyz)),
+            "set_target_from_gaussians")
+        self._live.clear()
+        return n
 
     def set_target_filter(self, num_trackable, input_filter):
         f = np.ascontiguousarray(input_filter, dtype=np.int32).ravel()
@@ -112,7 +172,29 @@ class FastGICP:
     def get_source_scales(self):
         return self._fetch(self._lib.gsicp_gicp_get_source_scales, self._lib.gsicp_gicp_num_source(self._h), 3, "get_source_scales")
 
+    def _fetch_tensor(self, fn, width, what, device=None):
+        import torch
+        n = self._lib.gsicp_gicp_num_source(self._h)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        out = torch.empty((n, width), dtype=torch.float32, device=dev)
+        got = self._ck(fn(self._h, ctypes.c_void_p(out.data_ptr()), n, _cur_stream(out)), what)
+        return out[:got]
+
+    def get_source_rotationsq_tensor(self, device=None):
+        """(n,4) xyzw quaternions of the source covariances as a device tensor (torch's current stream is ordered after the copy)."""
+        return self._fetch_tensor(self._lib.gsicp_gicp_get_source_rotationsq_device, 4, "get_source_rotationsq_tensor", device)
+
+    def get_source_scales_tensor(self, device=None):
+        return self._fetch_tensor(self._lib.gsicp_gicp_get_source_scales_device, 3, "get_source_scales_tensor", device)
+
     def set_target_covariances_fromqs(self, rotations_flat, scales_flat):
+        if _is_device_tensor(rotations_flat) and _is_device_tensor(scales_flat):
+            r, sc = _dev_f32(rotations_flat).reshape(-1), _dev_f32(scales_flat).reshape(-1)
+            self._live += [r, sc]
+            self._ck(self._lib.gsicp_gicp_set_target_covariances_fromqs_device(
+                self._h, ctypes.c_void_p(r.data_ptr()), r.numel(), ctypes.c_void_p(sc.data_ptr()), sc.numel(), _cur_stream(r), 0),
+                "set_target_covariances_fromqs")
+            return
         r = np.ascontiguousarray(rotations_flat, dtype=np.float32).ravel()
         s = np.ascontiguousarray(scales_flat, dtype=np.float32).ravel()
         self._ck(self._lib.gsicp_gicp_set_target_covariances_fromqs(self._h, _vp(r), r.size, _vp(s), s.size),
@@ -126,6 +208,7 @@ class FastGICP:
         init = np.ascontiguousarray(init, dtype=np.float64)
         out = np.empty((4, 4), np.float64)
         self.iterations = self._ck(self._lib.gsicp_gicp_align(self._h, _vp(init), _vp(out)), "align")
+        self._live.clear()   # everything enqueued before the align kernel has completed
         return out.astype(np.float32)   # the reference binding returns an Eigen::Matrix4f
 
     def get_source_correspondence(self):

@@ -167,6 +167,30 @@ int gsicp_gicp_align(gsicp_gicp*, const double* initial_pose, double* final_pose
  * the squared distance to the nearest target point, as of the last linearisation  [REF mp_Tracker.py:231].
  * Returns the number of entries. */
 int gsicp_gicp_get_source_correspondence(gsicp_gicp*, int32_t* target_index, float* sq_distance, int capacity);
+/* ---- Device-pointer overloads (additive — the numpy-style entry points above are unchanged) ----------
+ * The reference hands the map's trackable Gaussians to the tracker through host memory on every tracking keyframe while the
+ * tracker blocks: GPU -> CPU tensors -> numpy -> set_input_target + set_target_covariances_fromqs
+ * [REF scene/gaussian_model.py:207-215; scene/shared_objs.py:81-126; mp_Tracker.py:284-289].  These take DEVICE pointers
+ * (contiguous f32).  `producer_stream` is the stream the buffers were written on: the tracker's stream is ordered after it.
+ * With wait = 0 the call returns once the work is enqueued and the caller must keep the buffers alive (and unmodified) until
+ * the next synchronous tracker call returns; with wait = 1 the buffers are consumed on return. */
+void* gsicp_gicp_stream(gsicp_gicp*);   /* the object's hipStream_t (for record_stream-style lifetime management) */
+int gsicp_gicp_set_input_target_device(gsicp_gicp*, const float* xyz /* (n,3) */, int n, void* producer_stream, int wait);
+int gsicp_gicp_set_input_source_device(gsicp_gicp*, const float* xyz /* (n,3) */, int n, void* producer_stream, int wait);
+int gsicp_gicp_set_target_covariances_fromqs_device(gsicp_gicp*, const float* rots /* (n,4) xyzw */, int n_rots, const float* scales /* (n,3) */,
+                                                    int n_scales, void* producer_stream, int wait);
+/* get_trackable_gaussians_tensor + set_input_target + set_target_covariances_fromqs in one call: keeps Gaussian i iff
+ * opacity[i] > opacity_th and trackable_mask[i] != 0 (mask may be NULL), in index order (what torch's boolean indexing yields),
+ * and installs the survivors as the target cloud with covariances R diag(s^2) R^T (+ the configured regularisation).
+ * rotation / scaling / opacity are the ACTIVATED values (get_rotation, get_scaling, get_opacity).  Returns the number of target
+ * points (synchronises once for that count). */
+int gsicp_gicp_set_target_from_gaussians_device(gsicp_gicp*, int P, const float* xyz, const float* rotation, const float* scaling,
+                                                const float* opacity, const unsigned char* trackable_mask, float opacity_th,
+                                                void* producer_stream);
+/* Source covariances as quaternions / scales written into DEVICE buffers; `consumer_stream` is ordered after the copy (no host wait). */
+int gsicp_gicp_get_source_rotationsq_device(gsicp_gicp*, float* out_dev, int cap_points, void* consumer_stream);
+int gsicp_gicp_get_source_scales_device(gsicp_gicp*, float* out_dev, int cap_points, void* consumer_stream);
+
 /* Diagnostics of the last k-NN covariance pass: out = {cell edge, nx, ny, nz, cells, queries settled by whole-grid coverage,
  * after ring 1, ring 2, ring 3, by the exhaustive scan, 0, 0}.  Synchronises. */
 int gsicp_gicp_knn_stats(gsicp_gicp* g, double out[12]);
