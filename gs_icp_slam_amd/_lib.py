@@ -78,6 +78,9 @@ SIGNATURES = {
     "gsicp_gicp_set_input_source_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "gsicp_gicp_set_target_covariances_fromqs_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]),
     "gsicp_gicp_set_target_from_gaussians_device": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
+    "gsicp_gicp_set_source_track_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    "gsicp_frontend_make_pointcloud": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_gicp_get_source_rotationsq_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gsicp_gicp_get_source_scales_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gsicp_gicp_num_source": (c_int, [c_void_p]),

@@ -18,6 +18,7 @@ SOURCES = [
     ("raster.hip", []),
     ("knn.hip", []),
     ("mapper_ops.hip", []),
+    ("frontend.hip", ["-ffp-contract=off"]),
     ("gicp.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",

@@ -1605,6 +1605,20 @@ int gsicp_gicp_set_target_from_gaussians_device(gsicp_gicp* g, int P, const floa
     t.cov_valid = true; t.qs_valid = true;
     return (int)total;
 }
+int gsicp_gicp_set_source_track_device(gsicp_gicp* g, const int* trackable_idx, int n_track, void* producer_stream, int wait) {
+    Cloud& c = g->src;
+    if (n_track < 0 || n_track > c.n || (n_track > 0 && !trackable_idx)) { g_last_error = "set_source_track: bad list"; return -2; }
+    c.n_track = n_track;
+    if (c.track.ensure((size_t)(n_track ? n_track : 1))) { g_last_error = "hipMalloc failed"; return -1; }
+    if (n_track > 0) {
+        if (int rc = wait_for_producer(g, producer_stream)) return rc;
+        hipLaunchKernelGGL(ingest_track_kernel, dim3((n_track + 255) / 256), dim3(256), 0, g->stream, n_track, trackable_idx, c.track.p);
+        GC(hipGetLastError());
+        if (wait) { if (int rc_ = drain(g)) return rc_; }
+    }
+    g->aligned = false;
+    return 0;
+}
 static int fetch_floats_device(gsicp_gicp* g, const float* dev, int n_pts, int width, float* out_dev, int cap_pts, void* consumer_stream) {
     const int n = n_pts < cap_pts ? n_pts : cap_pts;
     if (n > 0) {

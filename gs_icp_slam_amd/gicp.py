@@ -119,6 +119,19 @@ class FastGICP:
         p, f64 = self._points(points)
         self._ck(self._lib.gsicp_gicp_set_input_source(self._h, _vp(p), p.shape[0], f64), "set_input_source")
 
+    def set_source_trackable(self, trackable_idx):
+        """Device-side `set_source_filter`: trackable_idx[r] = index of the r-th trackable source point (int32 device tensor, e.g.
+        DepthFrontEnd.make_pointcloud(...).trackable_idx)."""
+        import torch
+        t = trackable_idx.detach()
+        if not t.is_cuda:
+            raise RuntimeError("pygicp.FastGICP.set_source_trackable: expected a device tensor (use set_source_filter for numpy)")
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            t = t.to(torch.int32).contiguous()
+        self._live.append(t)
+        self._ck(self._lib.gsicp_gicp_set_source_track_device(self._h, ctypes.c_void_p(t.data_ptr()), t.numel(), _cur_stream(t), 0),
+                 "set_source_trackable")
+
     def set_target_from_gaussians(self, xyz, rotation, scaling, opacity, trackable_mask=None, opacity_th=0.0):
         """Device-side keyframe hand-off: the Gaussians with opacity > opacity_th (and trackable_mask set) become the target cloud,
         in index order, with covariances from their (activated) rotations and scales.  Returns the number of target points."""

@@ -252,6 +252,23 @@ int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* 
                                float* const* exp_avg_sq, const long long* numel, const float* lr_dev, float beta1, float beta2,
                                float eps, int* step_dev, void* stream);
 
+/* --------------------------------------------------------------------------------------------------------
+ * 5. Tracker front-end — Tracker.downsample_and_make_pointcloud2 [REF mp_Tracker.py:415-431] in one
+ *    launch.  All pointers are DEVICE pointers.  pick_idx (n_pick int64), x_pre, y_pre (n_pick f32) are the arrays
+ *    set_downsample_filter builds once [REF mp_Tracker.py:393-413]; depth is the (H*W) raw depth image, depth_type 0 = uint16,
+ *    1 = float32; rgb the (H*W*3) uint8 image (may be NULL together with colors).
+ *    Outputs (capacity n_pick each): points (n,3) = (x_pre z, y_pre z, z) of the picks with z = depth / depth_scale != 0, in pick
+ *    order; colors (n,3) = rgb / 255; z_values (n); trackable_idx (m) = indices INTO those arrays with z <= depth_trunc, ascending;
+ *    counts[0] = n, counts[1] = m (device ints).  Feed points / trackable_idx to gsicp_gicp_set_input_source_device and
+ *    gsicp_gicp_set_source_track_device.
+ * ------------------------------------------------------------------------------------------------------ */
+int gsicp_frontend_make_pointcloud(int n_pick, const long long* pick_idx, const float* x_pre, const float* y_pre, const void* depth,
+                                   int depth_type, const unsigned char* rgb, float depth_scale, float depth_trunc, float* points,
+                                   float* colors, float* z_values, int* trackable_idx, int* counts, void* stream);
+/* set_source_filter for a device-resident list: trackable_idx[r] is the index of the r-th trackable source point (what
+ * `input_filter[trackable_filter] = 1..m` encodes on the numpy API [REF mp_Tracker.py:192-195]). */
+int gsicp_gicp_set_source_track_device(gsicp_gicp*, const int* trackable_idx, int n_track, void* producer_stream, int wait);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,14 @@ reg.set_input_target(pw)
 reg.set_target_filter(len(sp["trackable_a"]), filt(len(pw), sp["trackable_a"]))
 reg.calculate_target_covariance_with_filter()
 f_src = filt(len(sp["points_b"]), sp["trackable_b"])
-names = ["set_input_source", "set_source_filter", "align", "get_source_correspondence"]
+DEVICE = "--device" in sys.argv   # device-resident frame: front-end kernel -> set_input_source(tensor) -> set_source_trackable
+if DEVICE:
+    from gs_icp_slam_amd.frontend import DepthFrontEnd
+    stride = 10 if cfg is synth.REPLICA else 5
+    fe = DepthFrontEnd(cfg["H"], cfg["W"], cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], stride, cfg["depth_scale"], 3.0)
+    raw = np.clip(np.round(synth.raycast_depth(cfg, sp["pose_b"]) * cfg["depth_scale"]), 0, 65535).astype(np.uint16)
+    depth_dev = torch.from_numpy(raw.view(np.int16)).cuda()
+names = ["make_pointcloud / set_input_source", "set_source_filter / trackable", "align", "get_source_correspondence"]
 acc = np.zeros(4)
 N = 300
 _lib.profile_enable(True)
@@ -39,9 +46,15 @@ for it in range(N + 20):
         _lib.profile_read()
         t_all = time.perf_counter()
     t0 = time.perf_counter()
-    reg.set_input_source(sp["points_b"])
-    t1 = time.perf_counter()
-    reg.set_source_filter(len(sp["trackable_b"]), f_src)
+    if DEVICE:
+        pc = fe.make_pointcloud(depth_dev)
+        reg.set_input_source(pc.points)
+        t1 = time.perf_counter()
+        reg.set_source_trackable(pc.trackable_idx)
+    else:
+        reg.set_input_source(sp["points_b"])
+        t1 = time.perf_counter()
+        reg.set_source_filter(len(sp["trackable_b"]), f_src)
     t2 = time.perf_counter()
     T = reg.align(sp["pose_a"])
     t3 = time.perf_counter()
@@ -52,7 +65,7 @@ wall = (time.perf_counter() - t_all) / N
 prof = _lib.profile_read()
 print("frame wall %.1f us" % (wall * 1e6))
 for n, a in zip(names, acc):
-    print("  %-28s %.1f us" % (n, a / N * 1e6))
+    print("  %-36s %.1f us" % (n, a / N * 1e6))
 print("  kernels:", {k: round(1e3 * ms / N, 1) for k, (ms, c) in prof.items() if c > 0})
 print("  align stats:", reg.last_align_stats())
 print("  knn grid:", reg.knn_stats())
