@@ -152,23 +152,28 @@ def main():
         optimizer.zero_grad(set_to_none=True)
         return loss, radii
 
+    # Duplicate-list capacity for the sync-free forward: 1.5x the count of one probe forward (per rank: each rank bins its own tiles).
+    def probe_capacity():
+        cap = max(8 * P // world, 1 << 20)
+        from gs_icp_slam_amd.rasterizer import GaussianRasterizer as _PlainRasterizer
+        while True:   # plain rasteriser on this rank's tiles: no collective inside a loop whose trip count may differ between ranks
+            probe = _PlainRasterizer(rs._replace(capacity=cap, tile_mod=world, tile_rem=rank))
+            with torch.no_grad():
+                a0 = activated()
+                probe(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"],
+                      scales=a0["scales"], rotations=a0["rotations"])
+            r = int(probe.num_rendered.item())
+            if r <= cap:
+                return int(1.5 * r) + 4096
+            cap *= 2
+    capacity = probe_capacity()
+    rast = ShardedGaussianRasterizer(rs._replace(capacity=capacity))   # eager iterations also run without the forward's host sync
+
     mg = None
     if use_graph:
-        # Single GPU: the whole iteration is one hipGraph launch (gs_icp_slam_amd/graph.py).  The duplicate-list capacity comes
-        # from one synchronous forward (x1.5); the keyframe (camera + targets) is re-selected before every replay, as the
-        # reference's mapper does [REF mp_Mapper.py:205-217].
+        # Single GPU: the whole iteration is one hipGraph launch (gs_icp_slam_amd/graph.py); the keyframe (camera + targets) is
+        # re-selected before every replay, as the reference's mapper does [REF mp_Mapper.py:205-217].
         from gs_icp_slam_amd.graph import MapperIterationGraph
-        with torch.no_grad():
-            a0 = activated()
-            rast(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"],
-                 scales=a0["scales"], rotations=a0["rotations"])
-        from gs_icp_slam_amd.rasterizer import GaussianRasterizer as _GR
-        probe = _GR(rs._replace(capacity=1 << 27))
-        with torch.no_grad():
-            probe(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"],
-                  scales=a0["scales"], rotations=a0["rotations"])
-        capacity = int(1.5 * int(probe.num_rendered.item())) + 4096
-        del probe
         mg = MapperIterationGraph(params, optimizer, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=capacity,
                                   lambda_dssim=0.2, warmup=2)
         mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_color, gt_depth)
@@ -226,6 +231,8 @@ def main():
             pstats.Stats(prof_py, stream=fh).sort_stats("cumulative").print_stats(45)
     prof = _lib.profile_read()
     n_prof = {k: args.steps for k in prof}
+    if mg is None and int(rast.inner.num_rendered.item()) > capacity:
+        raise RuntimeError("duplicate-list capacity overflowed during the timed region")
     if mg is not None:
         # kernels inside a replayed graph carry no HIP events: time the SAME kernels on the same inputs in eager iterations
         # right after the timed region (rocprofv3's kernel trace of this command sees both and agrees — profiles/README.md)
@@ -258,10 +265,7 @@ def main():
     means2D = torch.zeros_like(a_["means3D"], requires_grad=True)
     depth, color, radii, used = rast(means3D=a_["means3D"], means2D=means2D, shs=a_["shs"], opacities=a_["opacities"],
                                      scales=a_["scales"], rotations=a_["rotations"])
-    node = depth.grad_fn
-    while node is not None and not hasattr(node, "num_rendered"):
-        node = node.next_functions[0][0] if node.next_functions else None
-    D_local = int(getattr(node, "num_rendered", 0))
+    D_local = int(rast.inner.num_rendered.item())
     P_vis = int((radii > 0).sum())
     T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
     # Algorithmic bytes per launch: list word 4 B per (strip, entry) visit = 16 B per duplicate,
