@@ -260,7 +260,7 @@ template <int CAP, int THREADS, int MIN_N>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __restrict__ order, const uint2* __restrict__ ranges,
                                                         const uint32_t* __restrict__ sc_keys, const uint32_t* __restrict__ sc_vals,
                                                         const uint32_t* __restrict__ entry_gauss, uint32_t* __restrict__ point_list,
-                                                        uint32_t* __restrict__ tile_keys) {
+                                                        uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ list_gauss) {
     __shared__ unsigned long long s_key[CAP];
     __shared__ uint32_t s_val[CAP];
     const uint32_t tile = order[blockIdx.x];
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __re
             }
             point_list[range.x + rank] = v;
             tile_keys[range.x + rank] = tile;
+            list_gauss[range.x + rank] = (uint32_t)k;
         }
         return;
     }
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __re
     for (int i = tid; i < n; i += THREADS) {
         point_list[range.x + i] = s_val[i];
         tile_keys[range.x + i] = tile;
+        list_gauss[range.x + i] = (uint32_t)s_key[i];   // low word of the sort key = Gaussian id
     }
 }
 
@@ -332,7 +334,7 @@ struct BlendArgs {
     float* final_T;     // (H,W)
     uint32_t* n_contrib;
     int* is_used;
-    const uint32_t* entry_gauss;   // emission slot -> Gaussian id
+    const uint32_t* list_gauss;    // Gaussian id of every list entry, in list order (a coalesced read next to point_list)
     // backward only
     const float* dL_dpix;
     const float* dL_ddepth;
@@ -380,15 +382,14 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
     for (uint32_t base = range.x; base < range.y; base += 64) {
         if (__ballot(!done) == 0ull) break;   // every pixel of the strip has saturated
         const uint32_t k = base + lane;
-        uint32_t e = 0;
-        if (k < range.y) e = a.point_list[k];
+        uint32_t e = 0, id = 0;
+        if (k < range.y) { e = a.point_list[k]; id = a.list_gauss[k]; }
         const bool keep = (e & strip_bit) != 0;
         const unsigned long long m = __ballot(keep);
         if (m == 0ull) continue;
         const int n = __popcll(m);
         if (keep) {
             const int slot = __popcll(m & ((1ull << lane) - 1ull));
-            const uint32_t id = a.entry_gauss[e & ID_MASK];
             s_id[slot] = id;
             s_pos[slot] = k - range.x + 1;   // 1-based position in the tile list (the reference's "contributor")
             s_rec[slot] = a.rec[id];
@@ -543,8 +544,8 @@ __global__ __launch_bounds__(64) void blend_backward_strip_kernel(BlendArgs a) {
     const int total = (int)(range.y - range.x);
     for (int top = total; top > 0; top -= 64) {   // entries [top-64, top) back-to-front; lane 0 holds the last one
         const int posn = top - 1 - lane;   // 0-based list position of this lane's entry
-        uint32_t e = 0;
-        if (posn >= 0) e = a.point_list[range.x + (uint32_t)posn];
+        uint32_t e = 0, gid = 0;
+        if (posn >= 0) { e = a.point_list[range.x + (uint32_t)posn]; gid = a.list_gauss[range.x + (uint32_t)posn]; }
         const bool keep = (e & strip_bit) != 0;
         const unsigned long long m = __ballot(keep);
         if (m == 0ull) continue;
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(64) void blend_backward_strip_kernel(BlendArgs a) {
             const int slot = __popcll(m & ((1ull << lane) - 1ull));
             s_pos[slot] = posn;
             s_u[slot] = e & ID_MASK;
-            s_rec[slot] = a.rec[a.entry_gauss[e & ID_MASK]];
+            s_rec[slot] = a.rec[gid];
         }
 #pragma unroll
         for (int c = 0; c < NGRAD; ++c) s_sum[lane][c] = 0.f;
@@ -809,10 +810,10 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
             // two size classes over the same (LPT-ordered) tile list; each kernel skips the other class's tiles
             hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP, 256, SORT_SMALL>), dim3(n_local), dim3(256), 0, stream, order, ranges,
                                (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
-                               (uint32_t*)(bin + BL.tile_keys));
+                               (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss));
             hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 128, 0>), dim3(n_local), dim3(128), 0, stream, order, ranges,
                                (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
-                               (uint32_t*)(bin + BL.tile_keys));
+                               (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss));
         }
     }
 
@@ -820,7 +821,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     std::memset(&ba, 0, sizeof(ba));
     ba.W = width; ba.H = height; ba.gx = gx; ba.tile_mod = tile_mod; ba.tile_rem = tile_rem;
     ba.n_tiles_local = (T - tile_rem + tile_mod - 1) / tile_mod;
-    ba.ranges = ranges; ba.point_list = point_list; ba.rec = rec; ba.entry_gauss = entry_gauss;
+    ba.ranges = ranges; ba.point_list = point_list; ba.rec = rec; ba.list_gauss = (const uint32_t*)(bin + BL.list_gauss);
     ba.order = order;
     ba.bg = background;
     ba.out_color = out_color; ba.out_depth = out_depth; ba.final_T = final_T; ba.n_contrib = n_contrib; ba.is_used = is_used;
@@ -895,7 +896,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     ba.ranges = (const uint2*)(img_buffer + IL.ranges);
     ba.order = (const uint32_t*)(img_buffer + IL.order);
     ba.point_list = (const uint32_t*)(binning_buffer + BL.point_list);
-    ba.entry_gauss = (const uint32_t*)(binning_buffer + BL.entry_gauss);
+    ba.list_gauss = (const uint32_t*)(binning_buffer + BL.list_gauss);
     ba.rec = (const SplatRec*)(geom_buffer + GL.records);
     ba.bg = background;
     ba.final_T = (float*)(img_buffer + IL.final_T);

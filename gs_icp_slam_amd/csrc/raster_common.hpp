@@ -29,7 +29,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // Section offsets inside the three torch-owned scratch buffers.
 struct GeomLayout { size_t records, clamped, slot_base, tiles_touched, total; };
-struct BinLayout { size_t point_list, tile_keys, entry_gauss, entry_bits, emit_tile, emit_depth, scatter_keys, scatter_vals, block_hist, total; };
+struct BinLayout { size_t point_list, tile_keys, list_gauss, entry_gauss, entry_bits, emit_tile, emit_depth, scatter_keys, scatter_vals, block_hist, total; };
 constexpr int SPLIT_BLOCKS_MAX = 128;   // workgroups of the tile multi-split (each owns a contiguous chunk of emission slots)
 struct ImgLayout { size_t ranges, final_T, n_contrib, order, tile_count, total; };
 
@@ -50,6 +50,7 @@ inline BinLayout bin_layout(size_t R, size_t T) {
     const size_t Rp = R > 0 ? R : 1;
     L.point_list = o; o = align_up(o + Rp * 4);       // per tile, depth-sorted: emission slot | strip bits << 28
     L.tile_keys = o; o = align_up(o + Rp * 4);        // tile id of every list entry
+    L.list_gauss = o; o = align_up(o + Rp * 4);       // Gaussian id of every list entry (same order as point_list: coalesced for the blend kernels)
     L.entry_gauss = o; o = align_up(o + Rp * 4);      // emission slot -> Gaussian id
     L.entry_bits = o; o = align_up(o + Rp * 4);       // emission slot -> strip bits
     L.emit_tile = o; o = align_up(o + Rp * 4);        // forward-only: tile id of each emission slot
