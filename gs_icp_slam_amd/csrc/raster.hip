@@ -397,6 +397,7 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
         __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order; this only stops compiler reordering
         SplatRec rn = s_rec[0];
         uint32_t pn = s_pos[0];
+        unsigned long long used = 0ull;
         for (int j = 0; j < n; ++j) {
             const SplatRec r = rn;
             const uint32_t pos_j = pn;
@@ -419,11 +420,10 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
                     contrib = true;
                 }
             }
-            if (a.is_used) {
-                const unsigned long long mc = __ballot(contrib);
-                if (mc != 0ull && lane == (__ffsll((long long)mc) - 1)) a.is_used[s_id[j]] = 1;
-            }
+            used |= (__ballot(contrib) != 0ull ? 1ull : 0ull) << j;   // wave-uniform bookkeeping in scalar registers
         }
+        // is_used: one store instruction per batch (lane j reports compacted entry j) instead of a store per visit
+        if (a.is_used && lane < n && ((used >> lane) & 1ull)) a.is_used[s_id[lane]] = 1;
         __builtin_amdgcn_wave_barrier();
     }
     if (inside) {
