@@ -73,6 +73,7 @@ SIGNATURES = {
     "gsicp_gicp_align": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gsicp_gicp_get_source_correspondence": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
     "gsicp_gicp_knn_stats": (c_int, [c_void_p, c_void_p]),
+    "gsicp_gicp_align_trace": (c_int, [c_void_p, c_void_p, c_int]),
     "gsicp_gicp_stream": (c_void_p, [c_void_p]),
     "gsicp_gicp_set_input_target_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "gsicp_gicp_set_input_source_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),

@@ -98,28 +98,75 @@ __device__ inline void grid_nn(const GridView& g, float qx, float qy, float qz, 
     const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
     const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
     const int ox = (fx - flx) >= 0.5f ? 1 : -1, oy = (fy - fly) >= 0.5f ? 1 : -1, oz = (fz - flz) >= 0.5f ? 1 : -1;
-    unsigned long long cell[8];
+    // Latency is everything here (one point per thread, 30-odd dependent loads if done cell by cell).  The table is read in
+    // 4-slot buckets (64-byte aligned: 4 keys + 4 values = four 16-byte loads) and a key's probe sequence starts at its bucket, so
+    // one round of 32 independent loads answers all 8 cells; the sequential continuation only runs when a bucket is full of other
+    // keys (load factor 1/8: ~1e-4 of the lookups).  A per-slot probe loop made the whole wave walk every lane's collision chain,
+    // cell after cell: 7 us of every phase.  Then the first point of every non-empty cell is fetched together.  The result does
+    // not depend on the visiting order: (d, id) is a total order.
+    unsigned long long key[8], cell[8];
+    unsigned slot[8];
+    ulonglong2 ka[8], kb[8], va[8], vb[8];
+    const ulonglong2* K2 = (const ulonglong2*)g.keys;
+    const ulonglong2* V2 = (const ulonglong2*)g.vals;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {   // issue all 8 first probes together (independent loads)
-        const unsigned long long key = cell_key(cx + ((c & 1) ? ox : 0), cy + ((c & 2) ? oy : 0), cz + ((c & 4) ? oz : 0));
-        unsigned slot = hash_key(key) & g.mask;
+    for (int c = 0; c < 8; ++c) {
+        key[c] = cell_key(cx + ((c & 1) ? ox : 0), cy + ((c & 2) ? oy : 0), cz + ((c & 4) ? oz : 0));
+        slot[c] = (hash_key(key[c]) << 2) & g.mask;     // first slot of the key's bucket
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const unsigned h2 = slot[c] >> 1;
+        ka[c] = K2[h2]; kb[c] = K2[h2 + 1]; va[c] = V2[h2]; vb[c] = V2[h2 + 1];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const unsigned long long k = key[c];
         unsigned long long v = 0ull;
-        for (;;) {
-            const unsigned long long k = g.keys[slot];
-            if (k == key) { v = g.vals[slot]; break; }
-            if (k == EMPTY_KEY) break;
-            slot = (slot + 1) & g.mask;
+        if (ka[c].x == k) v = va[c].x;
+        else if (ka[c].x == EMPTY_KEY) v = 0ull;
+        else if (ka[c].y == k) v = va[c].y;
+        else if (ka[c].y == EMPTY_KEY) v = 0ull;
+        else if (kb[c].x == k) v = vb[c].x;
+        else if (kb[c].x == EMPTY_KEY) v = 0ull;
+        else if (kb[c].y == k) v = vb[c].y;
+        else if (kb[c].y != EMPTY_KEY) {          // bucket full of other keys: continue the linear probe
+            unsigned sl = (slot[c] + 4) & g.mask;
+            for (;;) {
+                const unsigned long long kk = g.keys[sl];
+                if (kk == k) { v = g.vals[sl]; break; }
+                if (kk == EMPTY_KEY) break;
+                sl = (sl + 1) & g.mask;
+            }
         }
         cell[c] = v;
+    }
+    float4 p0[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const unsigned start = (unsigned)(cell[c] >> 32), cnt = (unsigned)cell[c];
+        p0[c] = g.sorted[cnt ? start : 0u];     // unconditional load (index 0 is always valid when the grid is in use)
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const unsigned start = (unsigned)(cell[c] >> 32), cnt = (unsigned)cell[c];
-        for (unsigned j = 0; j < cnt; ++j) {
-            const float4 p = g.sorted[start + j];
-            const float d = dist2(qx, qy, qz, p.x, p.y, p.z);
-            const int id = __float_as_int(p.w);
+        if (cnt) {
+            const float d = dist2(qx, qy, qz, p0[c].x, p0[c].y, p0[c].z);
+            const int id = __float_as_int(p0[c].w);
             if (d < best_d || (d == best_d && id < best_i)) { best_d = d; best_i = id; }
+        }
+        for (unsigned j = 1; j < cnt; j += 4) {   // dense cells: four independent loads per round (the slowest lane of the wave sets the pace)
+            float4 pj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pj[u] = g.sorted[start + (j + u < cnt ? j + u : j)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j + u < cnt) {
+                    const float d = dist2(qx, qy, qz, pj[u].x, pj[u].y, pj[u].z);
+                    const int id = __float_as_int(pj[u].w);
+                    if (d < best_d || (d == best_d && id < best_i)) { best_d = d; best_i = id; }
+                }
+            }
         }
     }
 }
@@ -614,7 +661,7 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(int n, const unsigned lo
     if (s == 0 || skeys[s - 1] != key) {
         unsigned cnt = 1;
         while (s + (int)cnt < n && skeys[s + cnt] == key) ++cnt;
-        unsigned slot = hash_key(key) & mask;
+        unsigned slot = (hash_key(key) << 2) & mask;   // first slot of the key's 4-slot bucket (grid_nn reads whole buckets)
         for (;;) {
             const unsigned long long prev = atomicCAS(&tkeys[slot], EMPTY_KEY, key);
             if (prev == EMPTY_KEY) break;
@@ -660,7 +707,7 @@ struct AlignSync {               // zeroed once at creation; every launch leaves
     unsigned abort;
     unsigned exit_count;
     unsigned pad[29];
-    double partials[2][AL_MAX_WG][NRED];
+    double partials[2][AL_MAX_WG][NRED + 1];   // + the trial cost that rides along with a speculative linearisation
 };
 
 struct AlignArgs {
@@ -678,11 +725,15 @@ struct AlignArgs {
     int* corr;                 // per trackable source point
     float* sqd;
     double* maha;              // 6 per trackable source point
+    int* corr2;                // shadow set for the speculative linearisation (same sizes)
+    float* sqd2;
+    double* maha2;
     AlignResult* result;
     AlignSync* sync;
     int* miss_counter;         // zeroed here for the exact-distance pass that follows (saves a memset launch per frame)
     HostMailbox* mailbox;      // pinned host memory
     unsigned seq;              // this launch's sequence number
+    unsigned long long* trace; // diagnostics (GSICP_ALIGN_TRACE): wall_clock64 stamps of workgroup 0 at phase boundaries, or NULL
 };
 
 __device__ inline double wave_sum_d(double v) {
@@ -692,24 +743,53 @@ __device__ inline double wave_sum_d(double v) {
 }
 
 __device__ inline bool solve6(const double* H, const double* b, double* x) {
+    // fully unrolled so that L / Dg / y live in registers (with runtime loop bounds they went to scratch memory and this serial
+    // step cost 4-5 us of every LM phase); the arithmetic and its order are unchanged
     double L[36], Dg[6];
+#pragma unroll
     for (int i = 0; i < 36; ++i) L[i] = 0;
+    bool ok = true;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = H[6 * j + j];
-        for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * Dg[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < j) d -= L[6 * j + k] * L[6 * j + k] * Dg[k];
         Dg[j] = d;
-        if (d == 0.0 || !isfinite(d)) return false;
+        if (d == 0.0 || !isfinite(d)) ok = false;
+        const double inv_d = 1.0 / d;   // one fp64 division (~40 instructions on a single lane) per column instead of one per entry
         L[6 * j + j] = 1.0;
-        for (int i = j + 1; i < 6; ++i) {
-            double v = H[6 * i + j];
-            for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k] * Dg[k];
-            L[6 * i + j] = v / d;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i > j) {
+                double v = H[6 * i + j];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if (k < j) v -= L[6 * i + k] * L[6 * j + k] * Dg[k];
+                L[6 * i + j] = v * inv_d;
+            }
         }
     }
+    if (!ok) return false;
     double y[6];
-    for (int i = 0; i < 6; ++i) { double v = b[i]; for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k]; y[i] = v; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < i) v -= L[6 * i + k] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
     for (int i = 0; i < 6; ++i) y[i] /= Dg[i];
-    for (int i = 5; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * x[k]; x[i] = v; }
+    double xs[6];
+#pragma unroll
+    for (int ii = 0; ii < 6; ++ii) {
+        const int i = 5 - ii;
+        double v = y[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k > i) v -= L[6 * k + i] * xs[k];
+        xs[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = xs[i];
     return true;
 }
 
@@ -752,30 +832,93 @@ __device__ inline bool is_converged(const double* R, const double* t, double rot
 }
 
 struct AlignShared {
-    double scratch[AL_T / 64][NRED];
-    double red[NRED];
+    double scratch[AL_T / 64][NRED + 1];
+    double red[NRED + 1];
     double x0[12];      // current pose R,t
     double xi[12];      // trial pose
     double delta[12];
     double H[36], b[6];
+    double spec[NRED];  // H (21), b (6), cost (1) of the speculative linearisation at the accepted trial pose
     double y0, lambda, nu, denom;
     int state;          // 0 continue LM trials, 1 step accepted / done with this outer iteration, 2 abort
     int converged;
     int abort;
+    int accepted;       // the last LM trial moved x0 to xi (so the speculative linearisation at xi is the next iteration's)
 };
 
 // Grid-wide sum of NV doubles per thread.  Workgroup partials go to global memory, one monotonic-counter grid barrier
 // (agent-scope release before the arrive, relaxed polling by ONE lane, agent-scope acquire after — the protocol of
 // cdna_hip_programming.md §6 G16), then every workgroup adds the partials in the same fixed order, so all workgroups
 // hold bit-identical totals and take identical decisions without any further communication.
+typedef unsigned gi_uint2 __attribute__((ext_vector_type(2)));
+// (A_lo + A_hi | B_lo + B_hi) per 32-lane half: the sum over the two halves of value A lands in the lower half, of B in the upper
+__device__ inline double fold_swap32(double a, double b) {
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    const gi_uint2 lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+    const gi_uint2 hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    const double x = __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x));
+    const double y = __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
+    return x + y;
+}
+// rows (A_r0 + A_r1, B_r0 + B_r1, A_r2 + A_r3, B_r2 + B_r3)
+__device__ inline double fold_swap16(double a, double b) {
+    const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+    const gi_uint2 lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    const gi_uint2 hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    const double x = __longlong_as_double((long long)(((unsigned long long)hi.x << 32) | lo.x));
+    const double y = __longlong_as_double((long long)(((unsigned long long)hi.y << 32) | lo.y));
+    return x + y;
+}
+template <int CTRL>
+__device__ inline double dpp_move_d(double v) {   // v as seen through a DPP lane pattern (invalid source lanes read 0: bound_ctrl)
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// sum over the 16 lanes of each row; valid in the row's last lane (row_shr 1, 2, 4, 8: lane i accumulates lanes i-15..i)
+__device__ inline double row_sum_last(double v) {
+    v += dpp_move_d<0x111>(v);   // row_shr:1
+    v += dpp_move_d<0x112>(v);   // row_shr:2
+    v += dpp_move_d<0x114>(v);   // row_shr:4
+    v += dpp_move_d<0x118>(v);   // row_shr:8
+    return v;
+}
+
+__device__ inline void trace_stamp(unsigned long long* trace, int& n, int tag) {
+    if (trace && blockIdx.x == 0 && threadIdx.x == 0 && n < 250) { trace[2 * n] = (unsigned long long)tag; trace[2 * n + 1] = wall_clock64(); ++n; }
+}
 template <int NV>
-__device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, unsigned& epoch, int tid) {
+__device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, unsigned& epoch, int tid, unsigned long long* trace = nullptr,
+                                int* trace_n = nullptr) {
     const int lane = tid & 63, wave = tid >> 6;
     const int nwg = gridDim.x;
+    // Wave reduction of NV doubles without the LDS crossbar: gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves /
+    // odd-even rows of two registers, so two VALUES fold into one per level (NV -> NV/2 -> NV/4 values), and only the remaining
+    // quarter goes through the four in-row DPP steps.  ~6 instructions per value instead of 18 ds_bpermute-based ones (8.5 us ->
+    // ~1 us per phase).  Row r of folded value q holds original value 4q + {0, 2, 1, 3}[r]; the row total sits in the row's last lane.
+    constexpr int N2 = (NV + 1) / 2, N4 = (N2 + 1) / 2;
+    double f2[N2], f4[N4];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const double s = wave_sum_d(vals[k]);
-        if (lane == 0) sh.scratch[wave][k] = s;
+    for (int k = 0; k < N2; ++k) {
+        const double a0 = vals[2 * k], b0 = (2 * k + 1 < NV) ? vals[2 * k + 1] : 0.0;
+        f2[k] = fold_swap32(a0, b0);
+    }
+#pragma unroll
+    for (int k = 0; k < N4; ++k) {
+        const double a0 = f2[2 * k], b0 = (2 * k + 1 < N2) ? f2[2 * k + 1] : 0.0;
+        f4[k] = fold_swap16(a0, b0);
+    }
+#pragma unroll
+    for (int k = 0; k < N4; ++k) f4[k] = row_sum_last(f4[k]);
+    if ((lane & 15) == 15) {
+        const int r = lane >> 4;
+        const int sub = r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+#pragma unroll
+        for (int k = 0; k < N4; ++k) {
+            const int idx = 4 * k + sub;
+            if (idx < NV) sh.scratch[wave][idx] = f4[k];
+        }
     }
     __syncthreads();
     const int buf = epoch & 1;
@@ -786,6 +929,7 @@ __device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, un
         sy->partials[buf][blockIdx.x][tid] = s;
     }
     ++epoch;
+    if (trace) trace_stamp(trace, *trace_n, 10);   // wave + LDS reduction done, partial stored
     if (nwg > 1) {
         __syncthreads();
         if (tid == 0) {
@@ -808,14 +952,107 @@ __device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, un
         }
     }
     __syncthreads();
+    if (trace) trace_stamp(trace, *trace_n, 11);   // barrier passed
     if (tid < NV) {
         double s = 0;
-        for (int w = 0; w < nwg; ++w) s += sy->partials[buf][w][tid];
+        for (int w0 = 0; w0 < nwg; w0 += 8) {   // eight loads in flight, added in workgroup order (same sum, an eighth of the latency)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (w0 + u < nwg) ? sy->partials[buf][w0 + u][tid] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (w0 + u < nwg) s += v[u];
+        }
         sh.red[tid] = s;
     }
     __syncthreads();
+    if (trace) trace_stamp(trace, *trace_n, 12);   // partials of all workgroups summed
 }
 
+// Linearisation at pose x (R 9, t 3): nearest target inside the gate (fp32 search, fixed order), Mahalanobis matrix, and this
+// thread's share of H (21), b (6), cost (1) over its strided source points.  Writes the correspondences / distances / matrices
+// of the points it owns into the given buffer set.
+__device__ inline void linearize_points(const AlignArgs& a, const double* __restrict__ x, int* __restrict__ corr, float* __restrict__ sqd,
+                                        double* __restrict__ maha, int gtid, int gstride, double* __restrict__ acc, int* tn = nullptr) {
+    double R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = x[9 + i];
+    float Rf[9], tf[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tf[i] = (float)t[i];
+    for (int s = gtid; s < a.n_src; s += gstride) {
+        const int i = a.src_track[s];
+        const float4 p = a.src_pts[i];
+        const float qx = ((Rf[0] * p.x + Rf[1] * p.y) + Rf[2] * p.z) + tf[0];
+        const float qy = ((Rf[3] * p.x + Rf[4] * p.y) + Rf[5] * p.z) + tf[1];
+        const float qz = ((Rf[6] * p.x + Rf[7] * p.y) + Rf[8] * p.z) + tf[2];
+        float bd; int bi;
+        if (tn) trace_stamp(a.trace, *tn, 20);
+        grid_nn(a.grid, qx, qy, qz, bd, bi);
+        if (tn) trace_stamp(a.trace, *tn, 21);
+        sqd[s] = bd;
+        int c = -1;
+        if (bi >= 0 && bd < a.gate) {
+            const double* A = a.src_cov + 6 * (size_t)i;
+            const double* B = a.tgt_cov + 6 * (size_t)bi;
+            const double Am[9] = {A[0], A[1], A[2], A[1], A[3], A[4], A[2], A[4], A[5]};
+            double RA[9], S[6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) RA[3 * r + cc] = R[3 * r] * Am[cc] + R[3 * r + 1] * Am[3 + cc] + R[3 * r + 2] * Am[6 + cc];
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = r; cc < 3; ++cc) {
+                    S[k] = B[k] + (RA[3 * r] * R[3 * cc] + RA[3 * r + 1] * R[3 * cc + 1] + RA[3 * r + 2] * R[3 * cc + 2]);
+                    ++k;
+                }
+            double m[6];
+            if (inv_sym3(S, m)) {
+                c = bi;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) maha[6 * (size_t)s + d] = m[d];
+                const float4 bp = a.tgt_pts[bi];
+                double ta[3], e[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) ta[r] = R[3 * r] * (double)p.x + R[3 * r + 1] * (double)p.y + R[3 * r + 2] * (double)p.z + t[r];
+                e[0] = (double)bp.x - ta[0]; e[1] = (double)bp.y - ta[1]; e[2] = (double)bp.z - ta[2];
+                const double Mm[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]};
+                double Me[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) Me[r] = Mm[3 * r] * e[0] + Mm[3 * r + 1] * e[1] + Mm[3 * r + 2] * e[2];
+                acc[27] += e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
+                const double J[18] = {0, -ta[2], ta[1], -1, 0, 0, ta[2], 0, -ta[0], 0, -1, 0, -ta[1], ta[0], 0, 0, 0, -1};
+                double MJ[18];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) MJ[6 * r + cc] = Mm[3 * r] * J[cc] + Mm[3 * r + 1] * J[6 + cc] + Mm[3 * r + 2] * J[12 + cc];
+                int kk = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                    for (int cc = r; cc < 6; ++cc) { acc[kk] += J[r] * MJ[cc] + J[6 + r] * MJ[6 + cc] + J[12 + r] * MJ[12 + cc]; ++kk; }
+                    acc[21 + r] += J[r] * Me[0] + J[6 + r] * Me[1] + J[12 + r] * Me[2];
+                }
+            }
+        }
+        corr[s] = c;
+        if (tn) trace_stamp(a.trace, *tn, 22);
+    }
+}
+
+// The whole Levenberg-Marquardt loop in one persistent launch.  Every grid-wide phase costs ~20 us of cross-XCD barrier and
+// reduction latency whatever it computes, so the phase count is what matters: the trial-cost phase also linearises at the trial
+// pose into a shadow buffer set and reduces both in ONE barrier.  When the trial is accepted (the common case: every step of
+// the benchmark pairs) the next outer iteration starts from that linearisation instead of spending a phase on it; when it is
+// rejected the speculative result is dropped.  The arithmetic, its order and therefore every result bit are those of the
+// phase-per-linearisation schedule (and of the oracle).
 __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
     __shared__ AlignShared sh;
     const int tid = threadIdx.x;
@@ -823,101 +1060,49 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
     const bool leader = blockIdx.x == 0 && tid == 0;
     unsigned epoch = 0;
     if (tid < 12) sh.x0[tid] = a.init[tid];
-    if (tid == 0) { sh.lambda = -1.0; sh.converged = 0; sh.abort = 0; }
+    if (tid == 0) { sh.lambda = -1.0; sh.converged = 0; sh.abort = 0; sh.accepted = 0; }
     if (leader && a.miss_counter) *a.miss_counter = 0;
     __syncthreads();
 
     int iterations = 0, lm_trials = 0, failed = 0;
+    int tn = 0;
+    trace_stamp(a.trace, tn, 0);
+    int cur = 0;               // which buffer set holds the linearisation in use (wave-uniform, identical in every workgroup)
+    bool have_lin = false;     // the speculative linearisation of the previous trial is this iteration's
 
     for (int it = 0; it < a.max_iter; ++it) {
-        // ---------------- linearize at x0: correspondences + Mahalanobis + H, b, cost
-        double R[9], t[3];
+        int* corr_c = cur ? a.corr2 : a.corr;
+        float* sqd_c = cur ? a.sqd2 : a.sqd;
+        double* maha_c = cur ? a.maha2 : a.maha;
+        int* corr_n = cur ? a.corr : a.corr2;
+        float* sqd_n = cur ? a.sqd : a.sqd2;
+        double* maha_n = cur ? a.maha : a.maha2;
+        if (!have_lin) {
+            // ---------------- linearize at x0: correspondences + Mahalanobis + H, b, cost
+            double acc[NRED];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = sh.x0[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t[i] = sh.x0[9 + i];
-        float Rf[9], tf[3];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Rf[i] = (float)R[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) tf[i] = (float)t[i];
-        double acc[NRED];
-#pragma unroll
-        for (int k = 0; k < NRED; ++k) acc[k] = 0;
-
-        for (int s = gtid; s < a.n_src; s += gstride) {
-            const int i = a.src_track[s];
-            const float4 p = a.src_pts[i];
-            const float qx = ((Rf[0] * p.x + Rf[1] * p.y) + Rf[2] * p.z) + tf[0];
-            const float qy = ((Rf[3] * p.x + Rf[4] * p.y) + Rf[5] * p.z) + tf[1];
-            const float qz = ((Rf[6] * p.x + Rf[7] * p.y) + Rf[8] * p.z) + tf[2];
-            float bd; int bi;
-            grid_nn(a.grid, qx, qy, qz, bd, bi);
-            a.sqd[s] = bd;
-            int c = -1;
-            if (bi >= 0 && bd < a.gate) {
-                const double* A = a.src_cov + 6 * (size_t)i;
-                const double* B = a.tgt_cov + 6 * (size_t)bi;
-                const double Am[9] = {A[0], A[1], A[2], A[1], A[3], A[4], A[2], A[4], A[5]};
-                double RA[9], S[6];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) RA[3 * r + cc] = R[3 * r] * Am[cc] + R[3 * r + 1] * Am[3 + cc] + R[3 * r + 2] * Am[6 + cc];
-                int k = 0;
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int cc = r; cc < 3; ++cc) {
-                        S[k] = B[k] + (RA[3 * r] * R[3 * cc] + RA[3 * r + 1] * R[3 * cc + 1] + RA[3 * r + 2] * R[3 * cc + 2]);
-                        ++k;
-                    }
-                double m[6];
-                if (inv_sym3(S, m)) {
-                    c = bi;
-#pragma unroll
-                    for (int d = 0; d < 6; ++d) a.maha[6 * (size_t)s + d] = m[d];
-                    const float4 bp = a.tgt_pts[bi];
-                    double ta[3], e[3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) ta[r] = R[3 * r] * (double)p.x + R[3 * r + 1] * (double)p.y + R[3 * r + 2] * (double)p.z + t[r];
-                    e[0] = (double)bp.x - ta[0]; e[1] = (double)bp.y - ta[1]; e[2] = (double)bp.z - ta[2];
-                    const double Mm[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]};
-                    double Me[3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) Me[r] = Mm[3 * r] * e[0] + Mm[3 * r + 1] * e[1] + Mm[3 * r + 2] * e[2];
-                    acc[27] += e[0] * Me[0] + e[1] * Me[1] + e[2] * Me[2];
-                    const double J[18] = {0, -ta[2], ta[1], -1, 0, 0, ta[2], 0, -ta[0], 0, -1, 0, -ta[1], ta[0], 0, 0, 0, -1};
-                    double MJ[18];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) MJ[6 * r + cc] = Mm[3 * r] * J[cc] + Mm[3 * r + 1] * J[6 + cc] + Mm[3 * r + 2] * J[12 + cc];
-                    int kk = 0;
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                        for (int cc = r; cc < 6; ++cc) { acc[kk] += J[r] * MJ[cc] + J[6 + r] * MJ[6 + cc] + J[12 + r] * MJ[12 + cc]; ++kk; }
-                        acc[21 + r] += J[r] * Me[0] + J[6 + r] * Me[1] + J[12 + r] * Me[2];
-                    }
-                }
-            }
-            a.corr[s] = c;
+            for (int k = 0; k < NRED; ++k) acc[k] = 0;
+            trace_stamp(a.trace, tn, 1);
+            linearize_points(a, sh.x0, corr_c, sqd_c, maha_c, gtid, gstride, acc, a.trace ? &tn : nullptr);
+            trace_stamp(a.trace, tn, 2);
+            grid_sum<NRED>(acc, sh, a.sync, epoch, tid, a.trace, &tn);
+            if (sh.abort) { failed = 2; break; }
+            if (tid < NRED) sh.spec[tid] = sh.red[tid];
+            __syncthreads();
         }
-        grid_sum<NRED>(acc, sh, a.sync, epoch, tid);
-        if (sh.abort) { failed = 2; break; }
         if (tid == 0) {
             int kk = 0;
             for (int r = 0; r < 6; ++r)
-                for (int cc = r; cc < 6; ++cc) { sh.H[6 * r + cc] = sh.red[kk]; sh.H[6 * cc + r] = sh.red[kk]; ++kk; }
-            for (int r = 0; r < 6; ++r) sh.b[r] = sh.red[21 + r];
-            sh.y0 = sh.red[27];
+                for (int cc = r; cc < 6; ++cc) { sh.H[6 * r + cc] = sh.spec[kk]; sh.H[6 * cc + r] = sh.spec[kk]; ++kk; }
+            for (int r = 0; r < 6; ++r) sh.b[r] = sh.spec[21 + r];
+            sh.y0 = sh.spec[27];
             if (sh.lambda < 0.0) {
                 double mx = 0;
                 for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(sh.H[7 * i]));
                 sh.lambda = a.lm_init * mx;
             }
             sh.nu = 2.0;
+            sh.accepted = 0;
             if (leader) for (int i = 0; i < 12; ++i) a.result->lin_pose[i] = sh.x0[i];
         }
         __syncthreads();
@@ -946,16 +1131,19 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
                 }
             }
             __syncthreads();
+            trace_stamp(a.trace, tn, 3);   // solve + se3_exp done
             if (sh.state == 2) break;
-            // trial cost with frozen correspondences / Mahalanobis matrices
+            // trial cost with frozen correspondences / Mahalanobis matrices ...
             double Rx[9], tx[3];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rx[i] = sh.xi[i];
 #pragma unroll
             for (int i = 0; i < 3; ++i) tx[i] = sh.xi[9 + i];
-            double cost[1] = {0};
+            double both[NRED + 1];
+#pragma unroll
+            for (int k = 0; k <= NRED; ++k) both[k] = 0;
             for (int s = gtid; s < a.n_src; s += gstride) {
-                const int c = a.corr[s];
+                const int c = corr_c[s];
                 if (c < 0) continue;
                 const float4 p = a.src_pts[a.src_track[s]];
                 const float4 bp = a.tgt_pts[c];
@@ -963,14 +1151,18 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) e[r] = -(Rx[3 * r] * (double)p.x + Rx[3 * r + 1] * (double)p.y + Rx[3 * r + 2] * (double)p.z + tx[r]);
                 e[0] += (double)bp.x; e[1] += (double)bp.y; e[2] += (double)bp.z;
-                const double* m = a.maha + 6 * (size_t)s;
-                cost[0] += e[0] * (m[0] * e[0] + m[1] * e[1] + m[2] * e[2]) + e[1] * (m[1] * e[0] + m[3] * e[1] + m[4] * e[2]) +
-                           e[2] * (m[2] * e[0] + m[4] * e[1] + m[5] * e[2]);
+                const double* m = maha_c + 6 * (size_t)s;
+                both[NRED] += e[0] * (m[0] * e[0] + m[1] * e[1] + m[2] * e[2]) + e[1] * (m[1] * e[0] + m[3] * e[1] + m[4] * e[2]) +
+                              e[2] * (m[2] * e[0] + m[4] * e[1] + m[5] * e[2]);
             }
-            grid_sum<1>(cost, sh, a.sync, epoch, tid);
+            // ... and, in the same phase, the linearisation at the trial pose into the shadow buffers
+            trace_stamp(a.trace, tn, 4);   // trial cost done
+            linearize_points(a, sh.xi, corr_n, sqd_n, maha_n, gtid, gstride, both);
+            trace_stamp(a.trace, tn, 5);   // speculative linearisation done
+            grid_sum<NRED + 1>(both, sh, a.sync, epoch, tid, a.trace, &tn);
             if (sh.abort) { failed = 2; break; }
             if (tid == 0) {
-                const double yi = sh.red[0];
+                const double yi = sh.red[NRED];
                 const double rho = (sh.y0 - yi) / sh.denom;
                 if (rho < 0) {
                     if (is_converged(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps)) {
@@ -982,6 +1174,7 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
                     }
                 } else {
                     for (int i = 0; i < 12; ++i) sh.x0[i] = sh.xi[i];
+                    for (int i = 0; i < NRED; ++i) sh.spec[i] = sh.red[i];
                     const double f = 2 * rho - 1;
                     sh.lambda = sh.lambda * fmax(1.0 / 3.0, 1 - f * f * f);
                     if (leader) {
@@ -989,6 +1182,7 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
                         a.result->cost = yi;
                     }
                     sh.state = 1;
+                    sh.accepted = 1;
                 }
             }
             __syncthreads();
@@ -1000,6 +1194,13 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
         if (tid == 0) sh.converged = is_converged(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps) ? 1 : 0;
         __syncthreads();
         if (sh.converged) break;
+        have_lin = sh.accepted != 0 && it + 1 < a.max_iter;
+        if (have_lin) cur ^= 1;   // the shadow set becomes the set in use; correspondences exported are always those of the set in use
+    }
+    trace_stamp(a.trace, tn, 99);
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[511] = (unsigned long long)tn;
+    if (cur) {   // leave the exported correspondences / distances in the primary buffers (each thread moves the entries it wrote)
+        for (int s = gtid; s < a.n_src; s += gstride) { a.corr[s] = a.corr2[s]; a.sqd[s] = a.sqd2[s]; }
     }
     if (leader) {
         AlignResult* r = a.result;
@@ -1235,13 +1436,14 @@ struct gsicp_gicp {
     DevBuf<float4> sorted;
     DevBuf<char> sort_temp;
     // per-source-point outputs
-    DevBuf<int> corr, miss, counters, nbr_idx, knn_cell_of;
+    DevBuf<int> corr, corr2, miss, counters, nbr_idx, knn_cell_of;
     DevBuf<KnnGrid> knn_params;
     DevBuf<unsigned> knn_count, knn_start, knn_fill;
     DevBuf<float4> knn_sorted;
     DevBuf<float> nbr_d2;
-    DevBuf<float> sqd;
-    DevBuf<double> maha;
+    DevBuf<unsigned long long> trace;
+    DevBuf<float> sqd, sqd2;
+    DevBuf<double> maha, maha2;
     DevBuf<AlignResult> result;
     DevBuf<AlignSync> sync;
     HostMailbox* mailbox = nullptr;        // pinned
@@ -1388,8 +1590,10 @@ int build_grid(gsicp_gicp* g) {
     }
     const float h = (float)(2.0 * g->max_corr * 1.001);
     G.use_grid = 1; G.inv_h = 1.0f / h;
+    // load factor <= 1/8: most of the 8 cells a query probes do not exist, and an unsuccessful linear probe costs ~(1 + 1/(1-a)^2)/2
+    // dependent loads ON AVERAGE but the slowest lane of a wave sets the pace — at a = 1/2 the 8-cell search took 7 us of every phase
     size_t cap = 64;
-    while (cap < (size_t)2 * n) cap <<= 1;
+    while (cap < (size_t)8 * n) cap <<= 1;
     G.mask = (unsigned)(cap - 1);
     size_t temp_bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
@@ -1651,7 +1855,8 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     if (!t.cov_valid) { if (int rc = calc_cov(g, t)) return rc; ++launches; }
     if (!g->grid_valid) { if (int rc = build_grid(g)) return rc; launches += 4; }
     const size_t ns = (size_t)(s.n_track ? s.n_track : 1);
-    if (g->corr.ensure(ns) || g->sqd.ensure(ns) || g->maha.ensure(6 * ns) || g->miss.ensure(ns) || g->packed.ensure(ns)) {
+    if (g->corr.ensure(ns) || g->sqd.ensure(ns) || g->maha.ensure(6 * ns) || g->miss.ensure(ns) || g->packed.ensure(ns) ||
+        g->corr2.ensure(ns) || g->sqd2.ensure(ns) || g->maha2.ensure(6 * ns)) {
         g_last_error = "hipMalloc failed"; return -1;
     }
     AlignArgs a;
@@ -1665,6 +1870,10 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     }
     a.max_iter = g->max_iter; a.lm_max_iter = g->lm_max_iter; a.rot_eps = g->rot_eps; a.trans_eps = g->trans_eps; a.lm_init = g->lm_init;
     a.corr = g->corr.p; a.sqd = g->sqd.p; a.maha = g->maha.p; a.result = g->result.p; a.sync = g->sync.p;
+    a.corr2 = g->corr2.p; a.sqd2 = g->sqd2.p; a.maha2 = g->maha2.p;
+    static const bool trace_on = std::getenv("GSICP_ALIGN_TRACE") != nullptr;
+    a.trace = nullptr;
+    if (trace_on) { if (g->trace.ensure(512)) { g_last_error = "hipMalloc failed"; return -1; } a.trace = g->trace.p; }
     a.miss_counter = g->counters.p;
     a.mailbox = g->mailbox; a.seq = ++g->seq;
     int nwg = (s.n_track + AL_T - 1) / AL_T;
@@ -1714,6 +1923,16 @@ int gsicp_gicp_get_source_correspondence(gsicp_gicp* g, int32_t* idx, float* d2,
         std::memcpy(d2, g->h_sqd.p, sizeof(float) * m);
     }
     return m;
+}
+int gsicp_gicp_align_trace(gsicp_gicp* g, unsigned long long* out, int cap_pairs) {
+    if (!g->trace.p) return 0;
+    std::vector<unsigned long long> h(512);
+    GC(hipStreamSynchronize(g->stream));
+    GC(hipMemcpy(h.data(), g->trace.p, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int n = (int)h[511];
+    if (n > cap_pairs) n = cap_pairs;
+    for (int i = 0; i < 2 * n; ++i) out[i] = h[i];
+    return n;
 }
 int gsicp_gicp_knn_stats(gsicp_gicp* g, double out[12]) {
     KnnGrid h;

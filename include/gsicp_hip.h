@@ -194,6 +194,9 @@ int gsicp_gicp_get_source_scales_device(gsicp_gicp*, float* out_dev, int cap_poi
 /* Diagnostics of the last k-NN covariance pass: out = {cell edge, nx, ny, nz, cells, queries settled by whole-grid coverage,
  * after ring 1, ring 2, ring 3, by the exhaustive scan, 0, 0}.  Synchronises. */
 int gsicp_gicp_knn_stats(gsicp_gicp* g, double out[12]);
+/* Diagnostics (only with GSICP_ALIGN_TRACE set in the environment): (tag, wall_clock64 at 100 MHz) pairs stamped by workgroup 0 at
+ * the phase boundaries of the last align.  Returns the number of pairs written (0 when tracing is off). */
+int gsicp_gicp_align_trace(gsicp_gicp* g, unsigned long long* out, int cap_pairs);
 int gsicp_gicp_num_source(gsicp_gicp*);
 int gsicp_gicp_num_target(gsicp_gicp*);
 /* out[0..5]: kernel launches of the last align, LM trials, final cost, converged flag, device microseconds, reserved */

@@ -69,3 +69,16 @@ for n, a in zip(names, acc):
 print("  kernels:", {k: round(1e3 * ms / N, 1) for k, (ms, c) in prof.items() if c > 0})
 print("  align stats:", reg.last_align_stats())
 print("  knn grid:", reg.knn_stats())
+
+if os.environ.get("GSICP_ALIGN_TRACE"):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 500)()
+    n = _lib.load().gsicp_gicp_align_trace(reg._h, buf, 250)
+    names_t = {0: "start", 1: "lin begin", 2: "lin compute done", 3: "solve done", 4: "trial cost done", 5: "spec lin done", 10: "wave+LDS reduce, partial stored",
+               11: "barrier passed", 20: "  point loaded", 21: "  nn done", 22: "  maha/J done", 12: "partials summed", 99: "end"}
+    t0 = buf[1]
+    prev = t0
+    for i in range(n):
+        tag, t = buf[2 * i], buf[2 * i + 1]
+        print("  %7.2f us (+%6.2f)  %s" % ((t - t0) / 100.0, (t - prev) / 100.0, names_t.get(tag, tag)))
+        prev = t
