@@ -12,12 +12,15 @@
 //    probe chosen by which half of the cell the query falls in), not a kd-tree: the problem is 8-12 k queries
 //    against <= 1 M targets, which is latency- not bandwidth-bound, and a hash probe is a handful of dependent
 //    L2 hits where a kd-tree descent is ~20.  Points are stored sorted by cell so candidates are contiguous.
-//  * One align() = ONE kernel launch: a persistent 1024-thread workgroup runs every Levenberg-Marquardt iteration
-//    on the device (correspondences, Mahalanobis matrices, 6x6 normal equations by wave-shuffle + LDS tree
-//    reduction in fp64, LDL^T solve, SE(3) exponential, trial-cost evaluation, accept/reject), so a frame costs
-//    one launch and one 512-byte read-back instead of ~64 x 11 launches and host round-trips.
-//  * k-NN covariances (k = 20 over <= 12 k points) are an LDS-tiled brute force with a register-resident sorted
-//    top-k per thread; the 3x3 eigen-decomposition (cyclic Jacobi, fp64) is fused into the same kernel.
+//  * One align() = ONE kernel launch: a persistent grid (<= 240 workgroups, one source point per thread) runs every
+//    Levenberg-Marquardt iteration on the device (correspondences, Mahalanobis matrices, 6x6 normal equations reduced in
+//    fp64 with permlane-swap folding + LDS + a grid barrier, LDL^T solve, SE(3) exponential, trial cost, accept/reject).
+//    The trial phase also linearises at the trial pose, so an accepted step costs one grid-wide phase, not two.  The result
+//    reaches the host through a pinned mailbox the kernel writes: no read-back copy, no stream synchronise.
+//  * k-NN covariances (k = 20 over <= 12 k points): counting sort of the cloud into a uniform grid on the device, then one
+//    wave per query with the running top-k held across the lanes, cells visited nearest-first and pruned against the k-th
+//    distance, exactness guaranteed by the distance to the faces of the scanned cube (ring growth, full scan as last resort);
+//    the fp64 covariance / Jacobi eigen-decomposition runs one thread per point in a second kernel.
 //  * Per-point arithmetic follows the reference algorithm's precision: correspondence search in fp32 with a fixed
 //    evaluation order (this file is compiled with -ffp-contract=off, so nearest-neighbour indices are bit-exact
 //    against the CPU oracle), cost / Jacobians / reductions in fp64.
@@ -278,7 +281,7 @@ __device__ inline void regularise(int method, const double* evals, const double*
 
 // ---------------------------------------------------------------------------------------------- k-NN covariances
 // One WAVE per query point (4 queries per 256-thread workgroup, so ~n/4 workgroups fill the chip even at n = 8 k).
-// The 64 lanes stream the cloud 64 candidates at a time (one coalesced 1 KiB load); the running top-k is a sorted
+// The 64 lanes take candidates 64 at a time (one coalesced 1 KiB load per cell range); the running top-k is a sorted
 // list held ACROSS the lanes (lane r = rank r), so an insertion is a ballot + popcount + one wave_shr DPP move
 // instead of a 20-deep per-thread compare chain.  Ordering is lexicographic (d2, index) like the oracle's.
 __device__ inline bool lex_less(float d, int i, float d2, int i2) { return d < d2 || (d == d2 && i < i2); }

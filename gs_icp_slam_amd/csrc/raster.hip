@@ -18,7 +18,7 @@
 //    stages only the surviving 48-byte records in LDS — no workgroup barriers, and culled entries cost 1/64 of a
 //    vector instruction.  Work items are dispatched longest list first (LPT).
 //  * Backward: every lane of a wave walks the same splat at the same step, so the 10 partial gradients are reduced
-//    across the 64 lanes with 60 hand-scheduled DPP adds and stored into a private slot per (emission slot, strip);
+//    across the 64 lanes with 16 permlane-swap folds + 12 DPP adds and stored into a private slot per (emission slot, strip);
 //    a streaming pass adds the strips and each Gaussian sums its own contiguous run.  No float atomics anywhere:
 //    device-scope atomics resolve at the memory side on this 8-XCD part, and gradients stay bit-reproducible.
 #include <atomic>
@@ -438,30 +438,9 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
     }
 }
 
-// Wave64 sums of ten values at once: 6 DPP steps x 10 values = exactly 60 VALU instructions.  Doing the steps
-// value-interleaved (all ten values per step) keeps every DPP source >= 10 instructions behind its producer, so no
-// wait states are needed, and writing it by hand avoids the v_mov / s_nop padding hipcc emits around
-// partially-masked row_bcast moves.  Disabled lanes / rows keep their old value (dst == src).  Lane 63 ends up
-// with the wave totals.
-#define GS_DPP10(CTRL)                                                                              \
-    asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\t"     \
-                 "v_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"     \
-                 "v_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL "\n\t"     \
-                 "v_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\t"     \
-                 "v_add_f32_dpp %8, %8, %8 " CTRL "\n\tv_add_f32_dpp %9, %9, %9 " CTRL            \
-                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9))
-__device__ inline void wave_sum10(float& v0, float& v1, float& v2, float& v3, float& v4, float& v5, float& v6, float& v7,
-                                  float& v8, float& v9) {
-    asm volatile("s_nop 1");   // the first DPP reads registers the preceding VALU code may just have written
-    GS_DPP10("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    GS_DPP10("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    GS_DPP10("row_shr:4 row_mask:0xf bank_mask:0xf");
-    GS_DPP10("row_shr:8 row_mask:0xf bank_mask:0xf");
-    GS_DPP10("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    GS_DPP10("row_bcast:31 row_mask:0xc bank_mask:0xf");
-}
-
-// The same ten sums in 28 instructions instead of 60.  gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves /
+// Ten partial sums per lane -> ten wave totals.  (The first version was 60 hand-scheduled v_add_f32_dpp — 6 per value —
+// because hipcc's own lowering of the reduction took ~110 instructions; the permlane-swap folding below needs 28.)
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves /
 // odd-even rows of TWO registers in one instruction, so two values can be folded into one register per level ("A keeps its
 // lower half and receives B's lower half; B keeps its upper halves"): 10 -> 5 registers across the 32-lane halves, 5 (+ a zero)
 // -> 3 across the row pairs, and only those 3 registers go through the 4 in-row DPP steps.  Row k (lanes 16k..16k+15) of
