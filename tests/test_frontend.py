@@ -23,6 +23,22 @@ def test_oracle_pick_table_and_pointcloud_small_case():
     assert np.allclose(col[0], rgb[0, 3] / 255.0)
 
 
+def test_mirror_pick_table_equals_oracle_on_cpu():
+    """DepthFrontEnd builds its table with its own (index-arithmetic) formulation; it must equal the restated reference
+    construction (meshgrid + gather) exactly, for both benchmark resolutions and a stride that does not divide H."""
+    from oracle import frontend_oracle as fo
+    from gs_icp_slam_amd import synth
+    from gs_icp_slam_amd.frontend import DepthFrontEnd
+    for cfg, s in ((synth.REPLICA, 10), (synth.TUM, 5), (synth.TUM, 7)):
+        H, W = cfg["H"], cfg["W"]
+        pick, x_pre, y_pre = fo.downsample_filter(H, W, cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], s)
+        fe = DepthFrontEnd(H, W, cfg["fx"], cfg["fy"], cfg["cx"], cfg["cy"], s, cfg["depth_scale"], 3.0, device="cpu")
+        assert torch.equal(fe.pick_idx_cpu, pick) and torch.equal(fe.x_pre_cpu, x_pre) and torch.equal(fe.y_pre_cpu, y_pre)
+        assert fe.x_pre_cpu.dtype == torch.float32 and int(pick.max()) < H * W
+    with pytest.raises(RuntimeError):
+        fe.make_pointcloud(torch.zeros((cfg["H"], cfg["W"]), dtype=torch.float32))   # no CPU path
+
+
 def _images(cfg, seed=0, holes=0.05):
     from gs_icp_slam_amd import synth
     depth_m = synth.raycast_depth(cfg, synth.DEFAULT_POSE_A).astype(np.float32)
