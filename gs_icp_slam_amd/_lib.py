@@ -41,6 +41,8 @@ SIGNATURES = {
     "gsicp_mapper_loss_scratch_bytes": (c_size_t, [c_int, c_int]),
     "gsicp_mapper_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
+    "gsicp_store_compact_scratch_bytes": (c_size_t, [c_int]),
+    "gsicp_store_compact": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_set_view": (c_int, [c_int, c_int] + [c_void_p] * 11),
     "gsicp_mapper_activations_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_activations_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

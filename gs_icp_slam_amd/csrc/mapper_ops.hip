@@ -297,6 +297,64 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ map compaction (prune)
+// GaussianModel.prune_points [REF scene/gaussian_model.py:409-447] filters every parameter, both Adam moments and the per-Gaussian
+// statistics with a boolean mask — ~20 boolean-index launches, each allocating its result.  Here: one order-preserving stream
+// compaction (count -> single-workgroup scan -> scatter) moves the surviving rows of ALL arrays from one preallocated buffer set
+// to the other (gs_icp_slam_amd/gaussian_store.py keeps two sets and swaps them), so nothing is allocated and addresses are stable.
+constexpr int COMPACT_MAX_ARRAYS = 24;
+struct CompactTable {
+    const unsigned* src[COMPACT_MAX_ARRAYS];   // row-major arrays, rows are multiples of 4 bytes
+    unsigned* dst[COMPACT_MAX_ARRAYS];
+    int row_words[COMPACT_MAX_ARRAYS];
+    int n_arrays;
+};
+__global__ __launch_bounds__(256) void compact_count_kernel(int n, const unsigned char* __restrict__ keep, unsigned* __restrict__ block_count) {
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long b = __ballot(i < n && keep[i] != 0);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int nblocks, unsigned* __restrict__ block_count, int* __restrict__ n_out) {
+    __shared__ unsigned s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per) < nblocks ? (lo + per) : nblocks;
+    unsigned sum = 0;
+    for (int c = lo; c < hi; ++c) sum += block_count[c];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = s_part[tid] - sum;
+    for (int c = lo; c < hi; ++c) { const unsigned cnt = block_count[c]; block_count[c] = run; run += cnt; }
+    if (tid == 1023) *n_out = (int)s_part[1023];
+}
+__global__ __launch_bounds__(256) void compact_scatter_kernel(int n, const unsigned char* __restrict__ keep, const unsigned* __restrict__ block_base,
+                                                              CompactTable t) {
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool k = i < n && keep[i] != 0;
+    const unsigned long long b = __ballot(k);
+    if (lane == 0) s_w[wave] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (!k) return;
+    unsigned pos = block_base[blockIdx.x] + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += s_w[w];
+    for (int a = 0; a < t.n_arrays; ++a) {
+        const int rw = t.row_words[a];
+        const unsigned* __restrict__ sp = t.src[a] + (size_t)i * rw;
+        unsigned* __restrict__ dp = t.dst[a] + (size_t)pos * rw;
+        for (int w = 0; w < rw; ++w) dp[w] = sp[w];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ keyframe selection
 // The captured mapper iteration reads its camera and target images from fixed device buffers; selecting the keyframe of the
 // next replay is ONE launch that refreshes all five (five separate runtime copies cost ~5 us each of fixed latency).
@@ -474,6 +532,36 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
         hipLaunchKernelGGL(loss_pass2_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                            (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss: kernel launch failed"; return -1; }
+    return 0;
+}
+
+size_t gsicp_store_compact_scratch_bytes(int n) { return ((size_t)(n > 0 ? (n + 255) / 256 : 1) + 1) * sizeof(unsigned); }
+
+int gsicp_store_compact(int n, const unsigned char* keep, int n_arrays, const void* const* src, void* const* dst, const int* row_bytes,
+                        void* scratch, int* n_out_dev, void* stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (n < 0 || n_arrays < 0 || n_arrays > COMPACT_MAX_ARRAYS || !n_out_dev || (n > 0 && (!keep || !scratch))) {
+        g_last_error = "gsicp_store_compact: bad arguments (at most 24 arrays)"; return -2;
+    }
+    CompactTable t;
+    t.n_arrays = n_arrays;
+    for (int a = 0; a < COMPACT_MAX_ARRAYS; ++a) { t.src[a] = nullptr; t.dst[a] = nullptr; t.row_words[a] = 0; }
+    for (int a = 0; a < n_arrays; ++a) {
+        if (row_bytes[a] <= 0 || (row_bytes[a] & 3) || !src[a] || !dst[a] || src[a] == dst[a]) {
+            g_last_error = "gsicp_store_compact: rows must be non-empty multiples of 4 bytes and src != dst"; return -2;
+        }
+        t.src[a] = (const unsigned*)src[a]; t.dst[a] = (unsigned*)dst[a]; t.row_words[a] = row_bytes[a] / 4;
+    }
+    const int nblocks = n > 0 ? (n + 255) / 256 : 1;
+    unsigned* block_count = (unsigned*)scratch;
+    if (n == 0) {
+        hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, 0, block_count, n_out_dev);
+    } else {
+        hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(256), 0, stream, n, keep, block_count);
+        hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, block_count, n_out_dev);
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(256), 0, stream, n, keep, (const unsigned*)block_count, t);
+    }
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_store_compact: kernel launch failed"; return -1; }
     return 0;
 }
 

@@ -255,6 +255,16 @@ int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* 
                                float* const* exp_avg_sq, const long long* numel, const float* lr_dev, float beta1, float beta2,
                                float eps, int* step_dev, void* stream);
 
+/* Map pruning without reallocation: GaussianModel.prune_points / _prune_optimizer
+ * [REF scene/gaussian_model.py:409-447] apply one boolean mask to every parameter, both Adam moments and the per-Gaussian
+ * statistics.  This moves the rows with keep[i] != 0 of `n_arrays` (<= 24) row-major DEVICE arrays from src[a] to dst[a] (distinct
+ * buffers), preserving order, in three launches for all arrays together.  row_bytes[a] is a multiple of 4; src / dst / row_bytes are
+ * HOST arrays of n_arrays entries; `scratch` is a DEVICE buffer of gsicp_store_compact_scratch_bytes(n); *n_out_dev (DEVICE int)
+ * receives the number of surviving rows. */
+size_t gsicp_store_compact_scratch_bytes(int n);
+int gsicp_store_compact(int n, const unsigned char* keep, int n_arrays, const void* const* src, void* const* dst, const int* row_bytes,
+                        void* scratch, int* n_out_dev, void* stream);
+
 /* --------------------------------------------------------------------------------------------------------
  * 5. Tracker front-end — Tracker.downsample_and_make_pointcloud2 [REF mp_Tracker.py:415-431] in one
  *    launch.  All pointers are DEVICE pointers.  pick_idx (n_pick int64), x_pre, y_pre (n_pick f32) are the arrays
