@@ -462,20 +462,13 @@ __device__ inline float knn_gap(float q, float o, float h, int c0, int c1, float
 // running k-th distance (dense regions settle after one or two cells).  Ring 2: the 5x5x5 shell as 34 row segments, pruned the
 // same way, keeping the list.  After each ring the k-th distance is tested against the distance to the faces of the scanned
 // cube; a query that is still open after ring 2 scans the whole cloud.  Exact for any cell size.
-__global__ __launch_bounds__(256) void knn_grid_kernel(int n, int k, const float4* __restrict__ pts, const KnnGrid* __restrict__ gp,
-                                                       const unsigned* __restrict__ cell_start, const float4* __restrict__ sorted,
-                                                       int* __restrict__ nbr_idx, float* __restrict__ nbr_d2, unsigned* __restrict__ ring_hist) {
-    const int lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= n) return;                       // wave-uniform
-    const int kk = k < n ? k : n;             // <= 64
-    const unsigned long long kmask = kk >= 64 ? ~0ull : ((1ull << kk) - 1ull);
-    const KnnGrid g = *gp;
-    const float4 Q = pts[q];
+// The search itself (shared by the k-NN covariance pass and the exact 1-NN export): fills `t` with the kk nearest points of the
+// cell-sorted cloud to Q; returns how the query settled (0 whole grid, 1 / 2 ring, 4 full scan).
+__device__ inline int knn_search(const float4 Q, int kk, unsigned long long kmask, const KnnGrid& g, const unsigned* __restrict__ cell_start,
+                                 const float4* __restrict__ sorted, int n, int lane, TopK& t) {
     const float slack = 2e-3f * g.h;
     int cx, cy, cz;
     knn_cell_of(g, Q.x, Q.y, Q.z, cx, cy, cz);
-    TopK t;
     t.my_d = FLT_MAX; t.my_i = 0x7fffffff; t.tau_d = FLT_MAX; t.tau_i = 0x7fffffff;
     int how = 4;
     bool done = false;
@@ -560,11 +553,53 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int n, int k, const float
         t.my_d = FLT_MAX; t.my_i = 0x7fffffff; t.tau_d = FLT_MAX; t.tau_i = 0x7fffffff;
         knn_scan_range(t, Q, sorted, 0u, (unsigned)n, kk, kmask, lane);
     }
+    return how;
+}
+
+__global__ __launch_bounds__(256) void knn_grid_kernel(int n, int k, const float4* __restrict__ pts, const KnnGrid* __restrict__ gp,
+                                                       const unsigned* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                                       int* __restrict__ nbr_idx, float* __restrict__ nbr_d2, unsigned* __restrict__ ring_hist) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= n) return;                       // wave-uniform
+    const int kk = k < n ? k : n;             // <= 64
+    const unsigned long long kmask = kk >= 64 ? ~0ull : ((1ull << kk) - 1ull);
+    const KnnGrid g = *gp;
+    TopK t;
+    const int how = knn_search(pts[q], kk, kmask, g, cell_start, sorted, n, lane, t);
     if (lane < kk) {
         nbr_idx[(size_t)q * 64 + lane] = t.my_i;
         nbr_d2[(size_t)q * 64 + lane] = t.my_d;
     }
     if (lane == 0 && ring_hist) atomicAdd(&ring_hist[how], 1u);
+}
+
+// Exact nearest-target distance for the source points the gated search left without a neighbour (the reference exports the raw
+// kd-tree distance whatever the gate): the same grid search with k = 1 over the TARGET's cell-sorted copy, instead of a scan of all
+// targets per query.  Same dist2 arithmetic, and a minimum does not depend on the visiting order: bit-identical distances.
+__global__ __launch_bounds__(256) void nn1_grid_kernel(const int* __restrict__ miss, const int* __restrict__ n_miss_p, const int* __restrict__ src_track,
+                                                       const float4* __restrict__ src_pts, const double* __restrict__ lin_pose,
+                                                       const KnnGrid* __restrict__ gp, const unsigned* __restrict__ cell_start,
+                                                       const float4* __restrict__ sorted, int n_tgt, float* __restrict__ sqd) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= *n_miss_p) return;   // wave-uniform
+    const int s = miss[qi];
+    const float4 p = src_pts[src_track[s]];
+    float Rf[9], tf[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)lin_pose[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tf[i] = (float)lin_pose[9 + i];
+    float4 Q;
+    Q.x = ((Rf[0] * p.x + Rf[1] * p.y) + Rf[2] * p.z) + tf[0];
+    Q.y = ((Rf[3] * p.x + Rf[4] * p.y) + Rf[5] * p.z) + tf[1];
+    Q.z = ((Rf[6] * p.x + Rf[7] * p.y) + Rf[8] * p.z) + tf[2];
+    Q.w = 0.f;
+    const KnnGrid g = *gp;
+    TopK t;
+    (void)knn_search(Q, 1, 1ull, g, cell_start, sorted, n_tgt, lane, t);
+    if (lane == 0) sqd[s] = t.my_d;
 }
 
 // One THREAD per point: mean / covariance of its neighbours in fp64 (summed in rank order, as the oracle does), cyclic
@@ -1443,6 +1478,12 @@ struct gsicp_gicp {
     DevBuf<KnnGrid> knn_params;
     DevBuf<unsigned> knn_count, knn_start, knn_fill;
     DevBuf<float4> knn_sorted;
+    // the same kind of grid over the trackable TARGET points (built with the hashed grid, keyframe rate): exact 1-NN export
+    DevBuf<KnnGrid> tg_params;
+    DevBuf<unsigned> tg_count, tg_start, tg_fill;
+    DevBuf<float4> tg_sorted;
+    DevBuf<int> tg_cell_of;
+    bool tg_valid = false;
     DevBuf<float> nbr_d2;
     DevBuf<unsigned long long> trace;
     DevBuf<float> sqd, sqd2;
@@ -1580,6 +1621,7 @@ int build_grid(gsicp_gicp* g) {
     const int n = t.n_track;
     GridView& G = g->grid;
     std::memset(&G, 0, sizeof(G));
+    g->tg_valid = false;
     if (g->sorted.ensure((size_t)(n ? n : 1))) { g_last_error = "hipMalloc failed"; return -1; }
     G.sorted = g->sorted.p; G.n_sorted = n;
     gsicp::ProfileScope ps(gsicp::ST_GICP_GRID, g->stream);
@@ -1611,6 +1653,18 @@ int build_grid(gsicp_gicp* g) {
     hipLaunchKernelGGL(grid_fill_kernel, grid, block, 0, g->stream, n, g->gskeys.p, g->gsvals.p, t.pts.p, g->sorted.p, G.mask, g->tkeys.p, g->tvals.p);
     GC(hipGetLastError());
     G.keys = g->tkeys.p; G.vals = g->tvals.p;
+    // coarse dense grid over the same points for the exact-distance export (nn1_grid_kernel)
+    g->tg_valid = false;
+    if (!(g->tg_params.ensure(1) || g->tg_cell_of.ensure((size_t)n) || g->tg_count.ensure(KNN_MAX_CELLS + 1) ||
+          g->tg_start.ensure(KNN_MAX_CELLS + 1) || g->tg_fill.ensure(KNN_MAX_CELLS + 1) || g->tg_sorted.ensure((size_t)n))) {
+        hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, g->stream, n, (const float4*)g->sorted.p, KNN_H_AREA, KNN_H_VOL,
+                           g->tg_params.p, g->tg_count.p);
+        hipLaunchKernelGGL(knn_count_kernel, grid, block, 0, g->stream, n, (const float4*)g->sorted.p, g->tg_params.p, g->tg_cell_of.p, g->tg_count.p);
+        hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, g->stream, g->tg_params.p, g->tg_count.p, g->tg_start.p, g->tg_fill.p);
+        hipLaunchKernelGGL(knn_fill_kernel, grid, block, 0, g->stream, n, (const float4*)g->sorted.p, g->tg_cell_of.p, g->tg_fill.p, g->tg_sorted.p);
+        GC(hipGetLastError());
+        g->tg_valid = true;
+    }
     g->grid_valid = true;
     return 0;
 }
@@ -1909,8 +1963,12 @@ int gsicp_gicp_get_source_correspondence(gsicp_gicp* g, int32_t* idx, float* d2,
         gsicp::ProfileScope ps(gsicp::ST_GICP_MISS, g->stream);
         hipLaunchKernelGGL(miss_list_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, g->sqd.p, g->corr.p, gate, g->miss.p,
                            g->counters.p);
-        hipLaunchKernelGGL(brute_nn_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
-                           g->result.p->lin_pose, g->sorted.p, t.n_track, g->sqd.p);
+        if (g->tg_valid)
+            hipLaunchKernelGGL(nn1_grid_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
+                               g->result.p->lin_pose, g->tg_params.p, g->tg_start.p, g->tg_sorted.p, t.n_track, g->sqd.p);
+        else
+            hipLaunchKernelGGL(brute_nn_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
+                               g->result.p->lin_pose, g->sorted.p, t.n_track, g->sqd.p);
         GC(hipGetLastError());
         g->dist_exact = true;
     }
