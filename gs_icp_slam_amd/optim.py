@@ -31,7 +31,7 @@ class FusedAdam(torch.optim.Optimizer):
         for key, (t, plist, vals) in list(self._lr_dev.items()):
             new = [lr_of.get(i, v) for i, v in zip(plist, vals)]
             if new != vals:
-                t.copy_(torch.tensor(new, dtype=torch.float32))
+                t.copy_(torch.tensor(new, dtype=torch.float64))
                 self._lr_dev[key] = (t, plist, new)
 
     def _step_capturable(self, lib):
@@ -65,9 +65,9 @@ class FusedAdam(torch.optim.Optimizer):
             if key not in self._lr_dev:
                 if capturing:
                     raise RuntimeError("FusedAdam(capturable): run one step() outside graph capture first (allocates the device lr array)")
-                self._lr_dev[key] = (torch.tensor(lrs, dtype=torch.float32).to(dev), [id(t[0]) for t in items], lrs)
+                self._lr_dev[key] = (torch.tensor(lrs, dtype=torch.float64).to(dev), [id(t[0]) for t in items], lrs)
             elif not capturing and self._lr_dev[key][2] != lrs:
-                self._lr_dev[key][0].copy_(torch.tensor(lrs, dtype=torch.float32))
+                self._lr_dev[key][0].copy_(torch.tensor(lrs, dtype=torch.float64))
                 self._lr_dev[key] = (self._lr_dev[key][0], self._lr_dev[key][1], lrs)
             lr_dev = self._lr_dev[key][0]
             with torch.cuda.device(dev):

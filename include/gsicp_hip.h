@@ -248,11 +248,11 @@ int gsicp_adam_step(int n_groups, float* const* params, const float* const* grad
                     const long long* numel, const float* lr, float beta1, float beta2, float eps, int step, void* stream);
 
 /* The same step with the step count and the learning rates in DEVICE memory (the counterpart of
- * torch.optim.Adam(capturable=True)): `lr_dev` is a DEVICE float array of n_groups learning rates, `step_dev` a DEVICE
+ * torch.optim.Adam(capturable=True)): `lr_dev` is a DEVICE double array of n_groups learning rates (double, so that lr / (1 - beta1^t) rounds exactly as on the host path), `step_dev` a DEVICE
  * int holding the number of steps taken so far; the call applies step *step_dev + 1 and then increments it.  No host
  * value other than the pointers is baked into the launches, so a captured HIP graph replays correctly. */
 int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
-                               float* const* exp_avg_sq, const long long* numel, const float* lr_dev, float beta1, float beta2,
+                               float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
                                float eps, int* step_dev, void* stream);
 
 /* Map pruning without reallocation: GaussianModel.prune_points / _prune_optimizer

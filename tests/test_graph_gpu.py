@@ -90,7 +90,9 @@ def test_capturable_adam_equals_host_step_adam():
         ob.step()
     assert int(ob.state[p_b[0]]["step"].item()) == 12
     for pa, pb in zip(p_a, p_b):
-        torch.testing.assert_close(pa, pb, rtol=2e-6, atol=1e-8)
+        # both variants round like torch.optim.Adam up to the last bits of step_size and 1/sqrt(1 - beta2^t) (host pow vs device pow):
+        # a few parts per million of one update (lr <= 0.05), which is the scale that matters for elements that happen to sit near zero
+        torch.testing.assert_close(pa, pb, rtol=2e-6, atol=2e-7)
 
 
 def _mapper_setup(P, W, H, capturable):
