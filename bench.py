@@ -208,8 +208,6 @@ def main():
             T, idx, d2 = tracker_step(reg)
             loss, radii = mapper_iteration()
         last.update(T=T, loss=loss, radii=radii)
-        if mg is not None and os.environ.get("GSICP_DEBUG_R"):
-            print("R", int(mg.num_rendered.item()), "cap", mg.capacity, "loss", float(loss), file=sys.stderr)
 
     def barrier():
         if world > 1:
@@ -218,7 +216,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    _lib.profile_enable(not os.environ.get("GSICP_DEBUG_NOPROF"))
+    _lib.profile_enable(True)
     _lib.profile_read()
     barrier()
     prof_py = None
