@@ -77,7 +77,7 @@ def main():
               "rotations": torch.from_numpy(g["rotations"]),
               "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-4, 1 - 1e-4)), "shs": torch.from_numpy(g["shs"])}
     params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in params.items()}
-    from gs_icp_slam_amd.loss import mapper_loss
+    from gs_icp_slam_amd.loss import mapper_loss_and_grads
     from gs_icp_slam_amd.optim import FusedAdam
     lrs = {"means3D": 1.6e-6 * 2.5, "shs": 2.5e-3, "opacities": 0.05, "scales": 5e-3, "rotations": 1e-3}   # REF arguments/__init__.py:141-148
     use_graph = (world == 1) and not args.no_graph
@@ -153,11 +153,12 @@ def main():
         means2D = torch.zeros_like(a["means3D"], requires_grad=True)
         depth, color, radii, used = rast(means3D=a["means3D"], means2D=means2D, shs=a["shs"], opacities=a["opacities"],
                                          scales=a["scales"], rotations=a["rotations"])
-        loss = mapper_loss(color, depth, gt_color, gt_depth, lambda_dssim=0.2)
-        loss.backward()
+        # the fused loss hands dL/dimage and dL/ddepth straight to autograd (no loss node, no ones_like / multiply launches)
+        parts, g_color, g_depth = mapper_loss_and_grads(color, depth, gt_color, gt_depth, lambda_dssim=0.2)
+        torch.autograd.backward((color, depth), (g_color, g_depth))
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)
-        return loss, radii
+        return parts[0], radii
 
     # Duplicate-list capacity for the sync-free forward: 1.5x the count of one probe forward (per rank: each rank bins its own tiles).
     def probe_capacity():

@@ -398,38 +398,28 @@ __device__ inline AdamPMV adam_update(float p, float m, float v, float g, float 
 }
 // torch.optim.Adam (amsgrad off, weight decay 0, maximize off):  m += (1-b1)(g-m);  v = b2 v + (1-b2) g g;
 // p -= step_size * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
-__global__ __launch_bounds__(256) void adam_kernel(AdamTable t, float beta1, float beta2, float eps, float inv_bc2_sqrt, long long total) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        int gidx = 0;
-        long long base = 0;
-#pragma unroll
-        for (int k = 0; k < ADAM_MAX_GROUPS - 1; ++k)
-            if (k < t.n - 1 && i >= t.end[k]) { gidx = k + 1; base = t.end[k]; }
-        const long long j = i - base;
-        const AdamPMV a0 = adam_update(t.p[gidx][j], t.m[gidx][j], t.v[gidx][j], t.g[gidx][j], beta1, beta2, eps, inv_bc2_sqrt, t.step_size[gidx]);
-        t.m[gidx][j] = a0.m; t.v[gidx][j] = a0.v; t.p[gidx][j] = a0.p;
-    }
-}
-
-// Same update with the step count and the learning rates in DEVICE memory, so that one captured HIP graph can be replayed
-// for every iteration (torch.optim.Adam(capturable=True) keeps its step on the device for the same reason).
 // grid = (x, tensor): blockIdx.y picks the tensor, so no per-element group lookup, and each lane moves 16 bytes per access (the update
 // is pure streaming: 7 float accesses per element, 118 MB at P = 300 k).  Tensors that are not 16-byte aligned take the scalar loop.
-__global__ __launch_bounds__(256) void adam_capturable_kernel(AdamTable t, const double* __restrict__ lr_dev, const int* __restrict__ step_dev,
-                                                              float beta1, float beta2, float eps, long long total) {
-    (void)total;
+// CAPTURABLE: the step count and the learning rates come from device memory (a captured hipGraph replays them); otherwise the host
+// has already folded them into t.step_size / inv_bc2_sqrt_host.
+template <bool CAPTURABLE>
+__global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const double* __restrict__ lr_dev, const int* __restrict__ step_dev,
+                                                          float beta1, float beta2, float eps, float inv_bc2_sqrt_host) {
     __shared__ double s_bc1;
     __shared__ float s_inv_bc2_sqrt;
-    if (threadIdx.x == 0) {   // two double pow() per BLOCK, not per thread
-        const int step = *step_dev + 1;
-        s_bc1 = 1.0 - pow((double)beta1, (double)step);
-        s_inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+    if (CAPTURABLE) {
+        if (threadIdx.x == 0) {   // two double pow() per BLOCK, not per thread
+            const int step = *step_dev + 1;
+            s_bc1 = 1.0 - pow((double)beta1, (double)step);
+            s_inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int gidx = blockIdx.y;
     if (gidx >= t.n) return;
-    const float inv_bc2_sqrt = s_inv_bc2_sqrt;
-    const float step_size = (float)(lr_dev[t.src[gidx]] / s_bc1);   // the host-step kernel's formula, in double like torch's
+    const float inv_bc2_sqrt = CAPTURABLE ? s_inv_bc2_sqrt : inv_bc2_sqrt_host;
+    const float step_size = CAPTURABLE ? (float)(lr_dev[t.src[gidx]] / s_bc1)   // the host path's formula, in double like torch's
+                                       : t.step_size[gidx];
     const long long numel = t.end[gidx] - (gidx ? t.end[gidx - 1] : 0);
     float* __restrict__ P = t.p[gidx];
     const float* __restrict__ G = t.g[gidx];
@@ -643,6 +633,15 @@ static long long adam_table(AdamTable& t, int n_groups, float* const* params, co
     return total;
 }
 
+static dim3 adam_grid(const AdamTable& t) {   // x: 16-byte units of the largest tensor (grid-stride beyond 1024 blocks), y: tensor
+    long long largest = 0;
+    for (int k = 0; k < t.n; ++k) { const long long ne = t.end[k] - (k ? t.end[k - 1] : 0); largest = ne > largest ? ne : largest; }
+    long long blocks = (largest / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    return dim3((unsigned)blocks, (unsigned)t.n);
+}
+
 int gsicp_adam_step(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                     const long long* numel, const float* lr, float beta1, float beta2, float eps, int step, void* stream_v) {
     hipStream_t stream = (hipStream_t)stream_v;
@@ -651,9 +650,8 @@ int gsicp_adam_step(int n_groups, float* const* params, const float* const* grad
     const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, bc1);
     if (total == 0) return 0;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, beta1, beta2, eps, (float)(1.0 / std::sqrt(bc2)), total);
+    hipLaunchKernelGGL(adam_tensor_kernel<false>, adam_grid(t), dim3(256), 0, stream, t, (const double*)nullptr, (const int*)nullptr, beta1, beta2, eps,
+                       (float)(1.0 / std::sqrt(bc2)));
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step: kernel launch failed"; return -1; }
     return 0;
 }
@@ -667,15 +665,8 @@ int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* 
     }
     AdamTable t;
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, nullptr, 1.0);
-    if (total > 0) {
-        long long largest = 0;
-        for (int k = 0; k < t.n; ++k) { const long long ne = t.end[k] - (k ? t.end[k - 1] : 0); largest = ne > largest ? ne : largest; }
-        long long blocks = (largest / 4 + 255) / 256;
-        if (blocks < 1) blocks = 1;
-        if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(adam_capturable_kernel, dim3((unsigned)blocks, (unsigned)t.n), dim3(256), 0, stream, t, lr_dev, step_dev, beta1, beta2, eps,
-                           total);
-    }
+    if (total > 0)
+        hipLaunchKernelGGL(adam_tensor_kernel<true>, adam_grid(t), dim3(256), 0, stream, t, lr_dev, (const int*)step_dev, beta1, beta2, eps, 0.f);
     hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, stream, step_dev);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step_capturable: kernel launch failed"; return -1; }
     return 0;
