@@ -5,7 +5,10 @@ package.  The product path (``gs_icp_slam_amd``) never does; it fails loudly whe
 
 PARITY UNPINNED: the reference's native submodules are empty directories and it has no tests or golden
 vectors, so these restatements follow the reference's call sites plus the published
-upstream algorithms; see the header of each ``*_oracle.cpp``.
+upstream algorithms; see the header of each ``*_oracle.cpp``.  Pinned exceptions — pieces the reference restates in Python that
+is present, checked against golden vectors produced by RUNNING that Python (tests/golden/make_golden_utils.py,
+tests/test_oracle_pinned.py): the (x,y,z,w) quaternion convention and covariance assembly (utils/general_utils.py), SH evaluation
+degrees 0-3 (utils/sh_utils.py), camera matrices (utils/graphics_utils.py + scene/shared_objs.py), and the loss (loss_oracle.py).
 """
 import ctypes
 import os

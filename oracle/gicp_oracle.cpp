@@ -4,6 +4,8 @@
 // CPU (C++17 + OpenMP, exact kd-tree) restatement of the GICP scan-to-model tracker behind `pygicp.FastGICP`,
 // also used as the "fast_gicp OpenMP CPU path" stand-in for BASELINE.json config 1 (cpu_baseline.kind = "port").
 //
+// Pinned piece (golden vectors from the reference's own Python, tests/test_oracle_pinned.py): the (x,y,z,w) quaternion convention and
+// R diag(s^2) R^T of set_target_covariances_fromqs against utils/general_utils.py:60-114.
 // PARITY UNPINNED: /root/reference/submodules/fast_gicp is an EMPTY directory (fork
 // Lab-of-AI-and-Robotics/fast_gicp, branch gs_icp_slam, commit unpinned: /root/reference/.gitmodules:4-7), its
 // dependencies (PCL, Eigen, FLANN) are absent, and the reference has no tests.  This file follows

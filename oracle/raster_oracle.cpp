@@ -4,6 +4,8 @@
 // CPU restatement of the tile-binned, depth-sorted, alpha-blended 3D-Gaussian rasteriser
 // (forward + backward, colour + depth) behind `diff_gaussian_rasterization`.
 //
+// Pinned pieces (golden vectors from the reference's own Python, tests/test_oracle_pinned.py): quaternion convention + 3-D covariance
+// assembly (utils/general_utils.py:60-114), SH evaluation degrees 0-3 (utils/sh_utils.py:57-112), camera matrices.
 // PARITY UNPINNED: the reference ships submodules/diff-gaussian-rasterization as an EMPTY directory
 // (/root/reference/.gitmodules:1-3, no pinned commit) and has no tests or golden vectors, so there is
 // no reference file:line for the arithmetic.  This restatement follows
