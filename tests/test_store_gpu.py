@@ -14,11 +14,12 @@ LRS = {"xyz": 4e-6, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.05, "scaling
 class RefModel:
     """The reference's bookkeeping, restated: every growth / prune re-creates the parameters and re-keys the optimiser state."""
 
-    def __init__(self, first, trackable):
+    def __init__(self, first, trackable, device="cuda"):
+        self.device = device
         self.p = {k: nn.Parameter(first[k].clone().requires_grad_(True)) for k in NAMES}
         self.opt = torch.optim.Adam([{"params": [self.p[k]], "lr": LRS[k], "name": k} for k in NAMES], lr=0.0, eps=1e-15)
         self.trackable = trackable.clone()
-        self.accum = torch.zeros((first["xyz"].shape[0], 1), device="cuda")
+        self.accum = torch.zeros((first["xyz"].shape[0], 1), device=device)
 
     def cat(self, new, trackable):        # cat_tensors_to_optimizer + densification_postfix [REF :448-492]
         for g in self.opt.param_groups:
@@ -33,7 +34,7 @@ class RefModel:
             else:
                 g["params"][0] = nn.Parameter(torch.cat((g["params"][0], ext), dim=0).requires_grad_(True))
             self.p[g["name"]] = g["params"][0]
-        self.accum = torch.zeros((self.p["xyz"].shape[0], 1), device="cuda")
+        self.accum = torch.zeros((self.p["xyz"].shape[0], 1), device=self.device)
         self.trackable = torch.concat([self.trackable, trackable], dim=0)
 
     def prune(self, remove):              # prune_points + _prune_optimizer [REF :409-447]
