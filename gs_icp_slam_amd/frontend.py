@@ -84,3 +84,43 @@ class DepthFrontEnd:
         written with the inverse pose's rotation/translation is the same rigid map)."""
         pose = torch.as_tensor(pose_c2w, dtype=torch.float32, device=points.device)
         return points @ pose[:3, :3].T + pose[:3, 3]
+
+
+# ---- the remaining per-frame front-end arithmetic of the tracker, as device-agnostic torch (no host round trip when the inputs are
+# ---- device tensors; SURVEY.md §8f rank 3: "world transform, quaternion composition, overlap statistics")
+
+def quaternion_multiply(q1, Q2):
+    """q1 * Q2 for one (x,y,z,w) quaternion q1 and an (n,4) batch Q2 — the Hamilton product exactly as
+    Tracker.quaternion_multiply writes it [REF mp_Tracker.py:385-392] (used to rotate the GICP covariances' quaternions into the
+    world frame at keyframes [REF mp_Tracker.py:259-261, 304-306])."""
+    Q2 = torch.as_tensor(Q2)
+    q1 = torch.as_tensor(q1, dtype=Q2.dtype, device=Q2.device)
+    x0, y0, z0, w0 = q1[0], q1[1], q1[2], q1[3]
+    return torch.stack([w0 * Q2[:, 0] + x0 * Q2[:, 3] + y0 * Q2[:, 2] - z0 * Q2[:, 1],
+                        w0 * Q2[:, 1] + y0 * Q2[:, 3] + z0 * Q2[:, 0] - x0 * Q2[:, 2],
+                        w0 * Q2[:, 2] + z0 * Q2[:, 3] + x0 * Q2[:, 1] - y0 * Q2[:, 0],
+                        w0 * Q2[:, 3] - x0 * Q2[:, 0] - y0 * Q2[:, 1] - z0 * Q2[:, 2]], dim=1)
+
+
+def rotation_to_quaternion_xyzw(R):
+    """(x,y,z,w) quaternion of a 3x3 rotation matrix (what scipy's Rotation.from_matrix(R).as_quat() yields, up to the overall sign,
+    which is immaterial: q and -q are the same rotation and the rasteriser normalises)."""
+    R = torch.as_tensor(R, dtype=torch.float64)
+    t = R[0, 0] + R[1, 1] + R[2, 2]
+    cand = torch.stack([1.0 + 2.0 * R[0, 0] - t, 1.0 + 2.0 * R[1, 1] - t, 1.0 + 2.0 * R[2, 2] - t, 1.0 + t])   # 4x^2, 4y^2, 4z^2, 4w^2
+    k = int(torch.argmax(cand))
+    q = torch.empty(4, dtype=torch.float64)
+    if k == 3:
+        q[3] = cand[3]; q[0] = R[2, 1] - R[1, 2]; q[1] = R[0, 2] - R[2, 0]; q[2] = R[1, 0] - R[0, 1]
+    else:
+        i, j, l = k, (k + 1) % 3, (k + 2) % 3
+        q[i] = cand[k]; q[j] = R[j, i] + R[i, j]; q[l] = R[l, i] + R[i, l]; q[3] = R[l, j] - R[j, l]
+    return q / q.norm()
+
+
+def overlap_statistics(sq_distances, overlapped_th, new_point_th):
+    """Keyframe statistics from get_source_correspondence()'s squared distances [REF mp_Tracker.py:231-239, 266-269, 433-439]:
+    -> (ratio of trackable points with d^2 < overlapped_th, indices of points with d^2 > new_point_th — the not-yet-mapped ones)."""
+    d = torch.as_tensor(sq_distances)
+    ratio = float((d < overlapped_th).sum()) / max(int(d.shape[0]), 1)
+    return ratio, torch.where(d > new_point_th)[0]

@@ -38,7 +38,19 @@ out = {}
 rng = np.random.default_rng(5)
 
 # ------------------------------------------------------------------------------------------------ tracker front-end
-tr = lift(os.path.join(REF, "mp_Tracker.py"), "Tracker", ["set_downsample_filter", "downsample_and_make_pointcloud2"])
+tr = lift(os.path.join(REF, "mp_Tracker.py"), "Tracker", ["set_downsample_filter", "downsample_and_make_pointcloud2", "quaternion_multiply",
+                                                         "eliminate_overlapped2"])
+# quaternion composition and overlap statistics [REF mp_Tracker.py:385-392, 433-439, 235]
+from scipy.spatial.transform import Rotation  # noqa: E402  (the reference's own dependency for R -> quaternion)
+Rm = Rotation.from_euler("xyz", [20.0, -35.0, 110.0], degrees=True).as_matrix()
+q_cam = Rotation.from_matrix(Rm).as_quat()
+Q2 = rng.normal(size=(50, 4)); Q2 /= np.linalg.norm(Q2, axis=1, keepdims=True)
+out["qm_R"], out["qm_q1"], out["qm_Q2"] = Rm, q_cam, Q2
+out["qm_out"] = tr["quaternion_multiply"](None, q_cam, Q2)
+dist = np.abs(rng.normal(0, 4e-4, 500)).astype(np.float32)
+out["ov_d"] = dist
+out["ov_new"] = tr["eliminate_overlapped2"](None, dist, 5e-5)[0]
+out["ov_len_corres"] = np.array(len(np.where(dist < 5e-4)[0]))
 for tag, (H, W, fx, fy, cx, cy, stride, dscale, trunc) in {"a": (48, 64, 50.0, 52.0, 31.5, 23.5, 5, 1000.0, 3.0),
                                                             "b": (57, 83, 61.3, 60.2, 40.1, 28.7, 7, 6553.5, 2.5)}.items():
     me = SimpleNamespace(H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy, depth_scale=dscale, depth_trunc=trunc)

@@ -57,4 +57,22 @@ def test_store_reference_restatement_equals_reference_methods(gold):
             assert np.array_equal(st["exp_avg"].numpy(), gold[f"st_op{step}_m_{n}"]), (step, n)
             assert np.array_equal(st["exp_avg_sq"].numpy(), gold[f"st_op{step}_v_{n}"]), (step, n)
         assert np.array_equal(ref.trackable.numpy(), gold[f"st_op{step}_trackable"])
-    assert ref.p["xyz"].shape[0] == 21
+    assert ref.p["xyz"].shape[0] == gold[f"st_op{len(gold['st_ops']) - 1}_xyz"].shape[0] > 0
+
+
+def test_quaternion_composition_and_overlap_statistics_equal_reference_methods(gold):
+    from gs_icp_slam_amd.frontend import overlap_statistics, quaternion_multiply, rotation_to_quaternion_xyzw
+    got = quaternion_multiply(torch.from_numpy(gold["qm_q1"]), torch.from_numpy(gold["qm_Q2"])).numpy()
+    np.testing.assert_allclose(got, gold["qm_out"], rtol=0, atol=1e-15)
+    q = rotation_to_quaternion_xyzw(gold["qm_R"]).numpy()
+    ref = gold["qm_q1"]
+    assert min(np.abs(q - ref).max(), np.abs(q + ref).max()) < 1e-12          # same rotation (sign of a quaternion is free)
+    for R_test in (np.eye(3), np.diag([1.0, -1.0, -1.0]), np.diag([-1.0, 1.0, -1.0]), np.diag([-1.0, -1.0, 1.0])):   # w = 0 branches
+        qq = rotation_to_quaternion_xyzw(R_test).numpy()
+        x, y, z, w = qq
+        Rb = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        np.testing.assert_allclose(Rb, R_test, atol=1e-12)
+    ratio, new_idx = overlap_statistics(torch.from_numpy(gold["ov_d"]), 5e-4, 5e-5)
+    assert abs(ratio - int(gold["ov_len_corres"]) / len(gold["ov_d"])) < 1e-12
+    assert np.array_equal(new_idx.numpy(), gold["ov_new"])
