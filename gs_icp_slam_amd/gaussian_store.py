@@ -26,6 +26,27 @@ from . import _lib
 PARAM_NAMES = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
 
 
+def rows_from_gicp(points, colors, rots, scales, z_values, trackable_idxs=None, max_sh_degree=0):
+    """Parameter rows for new Gaussians from the tracker's outputs, initialised exactly as the reference does in
+    create_from_pcd2_tensor / add_from_pcd2_tensor [REF scene/gaussian_model.py:134-180]: DC colour = RGB2SH(colour), higher SH
+    coefficients zero, log-scales = log(scales / clamp_min(2 z^1.5, 1)), rotation copied, opacity = inverse_sigmoid(0.1).
+    -> (dict for GaussianStore.append, trackable mask)."""
+    n = points.shape[0]
+    dev = points.device
+    C0 = 0.28209479177387814
+    n_coef = (int(max_sh_degree) + 1) ** 2
+    features = torch.zeros((n, 3, n_coef), dtype=torch.float32, device=dev)
+    features[:, :3, 0] = (colors - 0.5) / C0
+    z = torch.clamp_min((z_values ** 1.5) * 2.0, 1.0).unsqueeze(-1).repeat(1, 3)
+    opac = 0.1 * torch.ones((n, 1), dtype=torch.float, device=dev)
+    rows = dict(xyz=points, f_dc=features[:, :, 0:1].transpose(1, 2).contiguous(), f_rest=features[:, :, 1:].transpose(1, 2).contiguous(),
+                opacity=torch.log(opac / (1 - opac)), scaling=torch.log(scales / z), rotation=rots)
+    mask = torch.zeros((n,), dtype=torch.bool, device=dev)
+    if trackable_idxs is not None and len(trackable_idxs) != 0:
+        mask[trackable_idxs] = True
+    return rows, mask
+
+
 class GaussianStore:
     def __init__(self, capacity, n_rest=0, device="cuda"):
         self.capacity, self.n_rest, self.device = int(capacity), int(n_rest), torch.device(device)

@@ -129,6 +129,36 @@ for step, (kind, arg) in enumerate([("cat", 15), ("prune", 0.3), ("cat", 7), ("p
         out[f"st_op{step}_v_{n}"] = me.optimizer.state[p]["exp_avg_sq"].numpy().copy()
     out[f"st_op{step}_trackable"] = me.trackable_mask.numpy().copy()
 out["st_ops"] = np.array(ops)
+
+# ------------------------------------------------------------------------------------------------ Gaussian initialisation from GICP outputs
+# GaussianModel.create_from_pcd2_tensor [REF scene/gaussian_model.py:134-164] with the reference's own RGB2SH / inverse_sigmoid;
+# `.cuda()` is a no-op here (no GPU in this container)
+sys.path.insert(0, REF)
+import utils.general_utils as gu   # noqa: E402
+import utils.sh_utils as su        # noqa: E402
+_cuda, _ones = torch.Tensor.cuda, torch.ones
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.ones = lambda *a, **k: _ones(*a, **{kk: v for kk, v in k.items() if kk != "device"})
+tree = ast.parse(open(os.path.join(REF, "scene", "gaussian_model.py")).read())
+cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "GaussianModel")
+fn = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "create_from_pcd2_tensor"]
+ns = {"torch": torch, "np": np, "nn": nn, "RGB2SH": su.RGB2SH, "inverse_sigmoid": gu.inverse_sigmoid}
+exec(compile(ast.Module(body=fn, type_ignores=[]), "gaussian_model.py", "exec"), ns)
+for deg in (0, 3):
+    n0 = 60
+    init_in = dict(points=rng.normal(size=(n0, 3)).astype(np.float32), colors=rng.uniform(0, 1, (n0, 3)).astype(np.float32),
+                   rots=rng.normal(size=(n0, 4)).astype(np.float32), scales=rng.uniform(0.005, 0.08, (n0, 3)).astype(np.float32),
+                   z=rng.uniform(0.3, 5.0, n0).astype(np.float32), trk=np.sort(rng.choice(n0, 35, replace=False)))
+    gm_me = Me(max_sh_degree=deg)
+    ns["create_from_pcd2_tensor"](gm_me, torch.from_numpy(init_in["points"]).clone(), torch.from_numpy(init_in["colors"]), torch.from_numpy(init_in["rots"]).clone(),
+                                  torch.from_numpy(init_in["scales"]), torch.from_numpy(init_in["z"]), torch.from_numpy(init_in["trk"]))
+    for k, v in init_in.items():
+        out[f"init{deg}_in_{k}"] = v
+    for k, attr in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"), ("scaling", "_scaling"),
+                    ("rotation", "_rotation")):
+        out[f"init{deg}_{k}"] = getattr(gm_me, attr).detach().numpy().copy()
+    out[f"init{deg}_trackable"] = gm_me.trackable_mask.numpy().copy()
+torch.Tensor.cuda, torch.ones = _cuda, _ones
 torch.zeros = _zeros
 
 np.savez_compressed(os.path.join(HERE, "ref_hostcode.npz"), **out)

@@ -76,3 +76,14 @@ def test_quaternion_composition_and_overlap_statistics_equal_reference_methods(g
     ratio, new_idx = overlap_statistics(torch.from_numpy(gold["ov_d"]), 5e-4, 5e-5)
     assert abs(ratio - int(gold["ov_len_corres"]) / len(gold["ov_d"])) < 1e-12
     assert np.array_equal(new_idx.numpy(), gold["ov_new"])
+
+
+@pytest.mark.parametrize("deg", [0, 3])
+def test_gaussian_initialisation_equals_reference_create_from_pcd2_tensor(gold, deg):
+    from gs_icp_slam_amd.gaussian_store import rows_from_gicp
+    t = lambda k: torch.from_numpy(gold[f"init{deg}_in_{k}"])
+    rows, mask = rows_from_gicp(t("points"), t("colors"), t("rots"), t("scales"), t("z"), t("trk"), max_sh_degree=deg)
+    for k in NAMES:
+        assert rows[k].shape == gold[f"init{deg}_{k}"].shape, k
+        assert np.array_equal(rows[k].numpy(), gold[f"init{deg}_{k}"]), k
+    assert np.array_equal(mask.numpy(), gold[f"init{deg}_trackable"])
