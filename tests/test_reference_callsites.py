@@ -111,3 +111,34 @@ def test_reference_imports_resolve_to_the_drop_in_packages():
     assert "from simple_knn._C import distCUDA2" in src
     assert "from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer" in open(REF).read()
     assert "import pygicp" in open("/root/reference/mp_Tracker.py").read()
+
+
+def test_loss_composition_is_the_reference_mappers_own_statements():
+    """The statements of Mapper.mapping that turn the rendered images into the scalar loss [REF mp_Mapper.py `mask = ...` through
+    `loss = loss_rgb + 0.1*loss_d`] are lifted by position out of the reference with `ast`, executed with the reference's own
+    l1_loss / ssim on the golden inputs, and must reproduce the golden loss the fused HIP kernel is tested against."""
+    import sys
+    import numpy as np
+    src_path = "/root/reference/mp_Mapper.py"
+    src = open(src_path).read()
+    lines = src.splitlines()
+    first = next(i for i, l in enumerate(lines, 1) if l.strip().startswith("mask = (gt_depth_image>0.)"))
+    last = next(i for i, l in enumerate(lines, 1) if i > first and l.strip().startswith("loss = loss_rgb + 0.1*loss_d"))
+    stmts = [n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.stmt) and first <= n.lineno <= last and not isinstance(n, (ast.If, ast.While, ast.For, ast.FunctionDef, ast.ClassDef))]
+    stmts.sort(key=lambda n: n.lineno)
+    assert len(stmts) >= 8
+    sys.path.insert(0, "/root/reference")
+    try:
+        from utils.loss_utils import l1_loss, ssim
+    finally:
+        sys.path.remove("/root/reference")
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "mapper_loss.npz"))
+    for case in ("a", "b"):
+        ns = {"torch": torch, "l1_loss": l1_loss, "ssim": ssim, "self": SimpleNamespace(lambda_dssim=0.2),
+              "image": torch.tensor(gold[f"{case}_image"], requires_grad=True), "depth_image": torch.tensor(gold[f"{case}_depth"], requires_grad=True),
+              "gt_image": torch.tensor(gold[f"{case}_gt_image"]), "gt_depth_image": torch.tensor(gold[f"{case}_gt_depth"])}
+        exec(compile(ast.Module(body=stmts, type_ignores=[]), src_path, "exec"), ns)
+        assert abs(float(ns["loss"]) - float(gold[f"{case}_loss"])) < 1e-7
+        ns["loss"].backward()
+        assert np.allclose(ns["image"].grad.numpy(), gold[f"{case}_grad_image"], atol=1e-9)
+        assert np.allclose(ns["depth_image"].grad.numpy(), gold[f"{case}_grad_depth"], atol=1e-12)
