@@ -108,3 +108,14 @@ def test_knn_oracle_golden_and_definition():
     D = ((p[:, None] - p[None]) ** 2).sum(-1)
     np.fill_diagonal(D, np.inf)
     np.testing.assert_allclose(got, np.sort(D, 1)[:, :3].mean(1), rtol=1e-5)
+
+
+def test_knn_oracle_is_invariant_to_point_order():
+    """distCUDA2's mean squared distance to the 3 nearest neighbours is a property of the point SET: permuting the
+    input permutes the output.  The HIP kernel is compared with this oracle in tests/test_knn_gpu.py."""
+    import oracle
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(500, 3)).astype(np.float32)
+    perm = rng.permutation(len(pts))
+    a, b = oracle.knn_dist2(pts), oracle.knn_dist2(pts[perm])
+    np.testing.assert_allclose(b, a[perm], rtol=1e-6, atol=0)
