@@ -171,6 +171,20 @@ def s_pair(cfg=REPLICA, noise=False, motion=None):
                 points_b=pb[0], z_b=pb[1], trackable_b=pb[2], depth_a=pa[3], depth_b=pb[3])
 
 
+def s_pair_survey(cfg=REPLICA, noise=False):
+    """The S-pair exactly as SURVEY.md 8(d) words it: frame A at the room centre looking +z, frame B = A o (1 deg about y,
+    then 2 cm along x).  From there a single wall and the three cuboids are in view.  With Replica's 2 cm gate the motion sits
+    at the edge of GICP's convergence basin (the 1 deg rotation alone moves points at 2 m depth by 3.5 cm): the pair is used to
+    pin HIP == oracle on a hard case and to time the long-iteration regime, not as a tracking-accuracy claim."""
+    pose_a = np.eye(4)
+    motion = se3((0.0, 1.0, 0.0), (0.02, 0.0, 0.0))
+    pose_b = pose_a @ motion
+    pa = frame_points(cfg, pose_a, **({"noise_seed": 11, "holes": 0.15} if noise else {}))
+    pb = frame_points(cfg, pose_b, **({"noise_seed": 1, "holes": 0.15} if noise else {}))
+    return dict(cfg=cfg, pose_a=pose_a, pose_b=pose_b, points_a=pa[0], z_a=pa[1], trackable_a=pa[2],
+                points_b=pb[0], z_b=pb[1], trackable_b=pb[2], depth_a=pa[3], depth_b=pb[3])
+
+
 # ------------------------------------------------------------------------------------------ surfel map
 def _faces():
     """(origin, edge_u, edge_v, inward/outward normal) rectangles of the room (facing in) and cuboids (facing out)."""

@@ -81,6 +81,83 @@ def test_align_matches_oracle(name, fromqs):
     assert ang < 0.05 and mm < (1.0 if name == "replica" else 5.0)
 
 
+@pytest.mark.parametrize("name", ["replica", "tum"])
+def test_survey_spair_matches_oracle(name):
+    """SURVEY 8(d)'s S-pair verbatim (room centre, looking +z, 1 deg about y + 2 cm along x).  Whatever basin the optimiser
+    falls into, HIP and the oracle must fall into the SAME one: correspondences bit-exact, pose to 1e-6.  The distance to the
+    ground-truth motion is reported (it is the basin limit of the algorithm on this geometry, not a property of the port)."""
+    import oracle
+    import pygicp
+    cfg = synth.REPLICA if name == "replica" else synth.TUM
+    sp = synth.s_pair_survey(cfg, noise=(name == "tum"))
+    oreg, reg = oracle.OracleGICP(), pygicp.FastGICP()
+    po, pp = drive(oreg, sp, cfg), drive(reg, sp, cfg)
+    st = reg.last_align_stats()
+    ang, mm = pose_err(pp["T"], sp["pose_b"])
+    ango, mmo = pose_err(po["T"], sp["pose_b"])
+    print(f"survey S-pair {name}: HIP {st}, oracle iterations {oreg.stats()}, error vs ground truth HIP {ang:.4f} deg / {mm:.2f} mm, "
+          f"oracle {ango:.4f} deg / {mmo:.2f} mm")
+    assert np.array_equal(pp["idx"], po["idx"]), f"{(pp['idx'] != po['idx']).sum()} correspondence indices differ"
+    assert np.array_equal(pp["d2"], po["d2"])
+    np.testing.assert_allclose(pp["T"], po["T"], rtol=0, atol=1e-6)
+    assert st["iterations"] == oreg.iterations
+
+
+def test_finite_max_knn_distance():
+    """set_max_knn_distance with a radius that actually bites [REF mp_Tracker.py:110 passes 99999]: neighbours beyond it are dropped
+    from the covariance estimate, on both sides alike — exported scales / covariances and the resulting pose agree."""
+    import oracle
+    import pygicp
+    cfg = synth.REPLICA
+    sp = synth.s_pair(cfg)
+    outs = []
+    for reg in (oracle.OracleGICP(), pygicp.FastGICP()):
+        reg.set_max_correspondence_distance(cfg["max_corr"])
+        reg.set_max_knn_distance(0.08)        # point spacing is 3-7 cm: most 20-neighbourhoods lose members, some keep < 3
+        pw = world(sp["points_a"], sp["pose_a"])
+        reg.set_input_target(pw)
+        reg.set_target_filter(len(sp["trackable_a"]), filt(len(pw), sp["trackable_a"]))
+        reg.calculate_target_covariance_with_filter()
+        s = np.reshape(reg.get_target_scales(), (-1, 3))
+        q = np.reshape(reg.get_target_rotationsq(), (-1, 4))
+        reg.set_input_source(sp["points_b"])
+        reg.set_source_filter(len(sp["trackable_b"]), filt(len(sp["points_b"]), sp["trackable_b"]))
+        T = reg.align(sp["pose_a"])
+        idx, d2 = reg.get_source_correspondence()
+        outs.append(dict(s=s, q=q, T=T, idx=idx, d2=d2))
+    o, p = outs
+    # the radius must have changed something relative to the unlimited run
+    ref = pygicp.FastGICP()
+    ref.set_input_target(world(sp["points_a"], sp["pose_a"]))
+    ref.calculate_target_covariance_with_filter()
+    s_unl = np.reshape(ref.get_target_scales(), (-1, 3))
+    assert (np.abs(s_unl - p["s"]).max(1) > 1e-4).mean() > 0.3
+    np.testing.assert_allclose(p["s"], o["s"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(quat_cov(p["q"], p["s"]), quat_cov(o["q"], o["s"]), rtol=0, atol=2e-7)
+    assert np.array_equal(p["idx"], o["idx"]) and np.array_equal(p["d2"], o["d2"])
+    np.testing.assert_allclose(p["T"], o["T"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("method", ["NONE", "MIN_EIG", "NORMALIZED_MIN_EIG", "FROBENIUS"])
+@pytest.mark.parametrize("fromqs", [False, True])
+def test_non_plane_regularisation_matches_oracle(method, fromqs):
+    """Every regularisation the option accepts besides the default PLANE, through both covariance sources (k-NN and
+    set_target_covariances_fromqs)."""
+    import oracle
+    import pygicp
+    cfg = synth.TUM
+    sp = synth.s_pair(cfg, noise=True)
+    code = {"NONE": 0, "MIN_EIG": 1, "NORMALIZED_MIN_EIG": 2, "PLANE": 3, "FROBENIUS": 4}[method]
+    oreg, reg = oracle.OracleGICP(), pygicp.FastGICP()
+    oreg.set_regularization_method(code)
+    reg.set_regularization_method(method)
+    po, pp = drive(oreg, sp, cfg, fromqs), drive(reg, sp, cfg, fromqs)
+    print(method, "fromqs", fromqs, reg.last_align_stats(), "pose err", pose_err(pp["T"], sp["pose_b"]))
+    assert np.array_equal(pp["idx"], po["idx"]), f"{(pp['idx'] != po['idx']).sum()} correspondence indices differ"
+    assert np.array_equal(pp["d2"], po["d2"])
+    np.testing.assert_allclose(pp["T"], po["T"], rtol=0, atol=2e-6)
+
+
 def test_known_answer_rigid_motion():
     """Source = target moved by a known SE(3): GICP must recover it (no sampling difference, wide gate)."""
     import pygicp

@@ -204,6 +204,96 @@ def test_full_size_smap(hip_lib, res):
     assert float(p["color"].min()) >= 0.0 and np.all(s["final_T"] <= 1.0)
 
 
+STAGE_CAMS = {
+    # name: (W, H, fx, fy) — BASELINE sizes and the coarse-to-fine training_stage sizes render_3 derives from them
+    # (image_width / (2 * stage), same tan(fov/2)) [REF gaussian_renderer/__init__.py:238-242; mp_Mapper.py:207-216]
+    "replica": (1200, 680, 600.0, 600.0), "tum": (640, 480, 517.3, 516.5),
+    "replica_stage1": (600, 340, 300.0, 300.0), "replica_stage2": (300, 170, 150.0, 150.0),
+}
+
+
+def _stage_cam(name):
+    W, H, fx, fy = STAGE_CAMS[name]
+    return synth.make_camera(W, H, fx, fy, synth.DEFAULT_POSE_A)
+
+
+@pytest.mark.parametrize("res", ["replica_stage1", "replica_stage2"])
+def test_training_stage_sizes_forward(hip_lib, res):
+    """render_3's training_stage 1 / 2 resolutions (600x340, 300x170) with the full S-map: lists bit-exact, images within 1e-5."""
+    cam = _stage_cam(res)
+    g = synth.s_map(300_000, seed=2)
+    o, p, stats = check_forward(g, cam, [0, 0, 0], 0, hip_lib, f"S-map {res}", max_fragile=4e-4)
+    print("S-map", res, "num_rendered", p["num_rendered"], stats)
+
+
+def _gaussians_near_pixels(geom, radii, ys, xs):
+    """Indices of Gaussians whose 3-sigma square covers any of the given pixels (pixels where a threshold decision is within
+    rounding of flipping: exp() differs in the last ulps between libm and the GPU, and ONE flipped pixel moves the gradient of
+    every Gaussian blended at it by that pixel's whole contribution)."""
+    hit = np.zeros(len(radii), bool)
+    vis = np.flatnonzero(radii > 0)
+    px, py, r = geom[vis, 0], geom[vis, 1], radii[vis].astype(np.float32)
+    for y, x in zip(ys, xs):
+        hit[vis[(np.abs(px - x) <= r + 1) & (np.abs(py - y) <= r + 1)]] = True
+    return hit
+
+
+@pytest.mark.parametrize("res", ["replica", "tum", "replica_stage1", "replica_stage2"])
+def test_full_size_smap_backward(hip_lib, res):
+    """R-bwd at BASELINE sizes: S-map P = 300 k at 1200x680 and 640x480 (and the training_stage sizes), random dL/dcolour and
+    dL/ddepth, all six gradients compared with the oracle ELEMENT-WISE:  |hip - oracle| <= 1e-5 * max|oracle| + 1e-4 * |oracle|.
+    Gaussians that overlap a fragile pixel (forward decision margin < 1e-5; a few per 10^4 pixels) are held to the looser bound
+    5e-3 * max|oracle| and their number is bounded."""
+    cam = _stage_cam(res)
+    W, H = cam["W"], cam["H"]
+    g = synth.s_map(300_000, seed=2)
+    rng = np.random.default_rng(7)
+    gc = rng.normal(size=(3, H, W)).astype(np.float32)
+    gd = rng.normal(size=(H, W)).astype(np.float32)
+    bg = [0.0, 0.0, 0.0]
+    of = util.oracle_forward(g, cam, bg, 0)
+    o = util.oracle_backward(g, cam, bg, gc, gd, 0)
+    p = run_product(g, cam, bg, 0, grads=(gc, gd))
+    assert np.array_equal(p["radii"], of["radii"])
+    fy, fx = np.nonzero(of["margin"] <= FRAGILE)
+    assert len(fy) <= 4e-4 * W * H, f"{len(fy)} fragile pixels"
+    near = _gaussians_near_pixels(of["geom"], of["radii"], fy, fx)
+    n_vis = int((of["radii"] > 0).sum())
+    assert near.sum() <= 0.08 * n_vis, f"{near.sum()} of {n_vis} visible Gaussians overlap a fragile pixel"
+    # list depth of each Gaussian's deepest tile (for the report)
+    tile_len = (of["ranges"][:, 1].astype(np.int64) - of["ranges"][:, 0])
+    pairs = [("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"), ("rotations", "dL_drots"),
+             ("shs", "dL_dsh"), ("means2D", "dL_dmeans2D")]
+    report = {}
+    for name, key in pairs:
+        a = p["grads"][name].reshape(300_000, -1).astype(np.float64)
+        b = o[key].reshape(300_000, -1).astype(np.float64)
+        if name == "means2D":
+            a, b = a[:, :2], b[:, :2]          # the third column is never written by the rasteriser (upstream leaves it zero)
+        mx = np.abs(b).max()
+        bound = 1e-5 * mx + 1e-4 * np.abs(b)
+        err = np.abs(a - b)
+        ratio = (err / bound).max(1)
+        robust = ~near
+        worst = int(np.argmax(np.where(robust, ratio, 0.0)))
+        report[name] = dict(max_ratio=float(ratio[robust].max()), worst_gaussian=worst, worst_abs=float(err[worst].max()), grad_max=float(mx),
+                            loose_max=float((err[near].max() / mx) if near.any() else 0.0))
+        assert ratio[robust].max() <= 1.0, f"{res} grad {name}: worst Gaussian {worst} err {err[worst]} vs oracle {b[worst]} (max|grad| {mx:.3e})"
+        if near.any():
+            assert err[near].max() <= 5e-3 * mx, f"{res} grad {name}: fragile-pixel Gaussians off by {err[near].max() / mx:.3e} of max"
+        # culled Gaussians get exactly zero
+        assert not a[of["radii"] == 0].any()
+    # depth of the worst Gaussian's lists: the tiles it touches
+    wg = max(report.values(), key=lambda r: r["max_ratio"])["worst_gaussian"]
+    x, y, r = of["geom"][wg, 0], of["geom"][wg, 1], of["radii"][wg]
+    gx = (W + 15) // 16
+    tx0, tx1 = int(max(0, (x - r) // 16)), int(min(gx - 1, (x + r) // 16))
+    ty0, ty1 = int(max(0, (y - r) // 16)), int(min((H + 15) // 16 - 1, (y + r) // 16))
+    depth = int(max(tile_len[ty * gx + tx] for ty in range(ty0, ty1 + 1) for tx in range(tx0, tx1 + 1)))
+    print(f"S-map backward {res}: fragile px {len(fy)}, Gaussians near them {int(near.sum())}/{n_vis}, worst Gaussian {wg} "
+          f"(longest tile list it sits in: {depth}), per-gradient {report}")
+
+
 def test_long_tile_lists_use_the_fallback_sort(hip_lib):
     """> 4096 entries in one tile: the per-tile sort leaves LDS and rank-sorts in global memory; lists must still be exact."""
     cam = synth.make_camera(48, 32, 40.0, 40.0)
