@@ -241,9 +241,12 @@ def _gaussians_near_pixels(geom, radii, ys, xs):
 @pytest.mark.parametrize("res", ["replica", "tum", "replica_stage1", "replica_stage2"])
 def test_full_size_smap_backward(hip_lib, res):
     """R-bwd at BASELINE sizes: S-map P = 300 k at 1200x680 and 640x480 (and the training_stage sizes), random dL/dcolour and
-    dL/ddepth, all six gradients compared with the oracle ELEMENT-WISE:  |hip - oracle| <= 1e-5 * max|oracle| + 1e-4 * |oracle|.
-    Gaussians that overlap a fragile pixel (forward decision margin < 1e-5; a few per 10^4 pixels) are held to the looser bound
-    5e-3 * max|oracle| and their number is bounded."""
+    dL/ddepth, all six gradients compared with the fp32 oracle ELEMENT-WISE:
+        |hip - oracle| <= 1e-5 * max|oracle| + 1e-4 * |oracle| + min(2 |oracle_f32 - oracle_f64|, 1e-4 * max|oracle|).
+    The last term is the fp32 oracle's OWN rounding noise on that element (conic -> covariance -> quaternion is a sum of products
+    of dL/dSigma ~ 1e5 with derivatives ~ 1e-4 that cancel to O(10): where fp32 cannot do better the bar is what fp32 delivers);
+    the number of elements that need it is reported.  Gaussians that overlap a fragile pixel (forward decision margin < 1e-5; a
+    few per 10^4 pixels) are held to the looser bound 5e-3 * max|oracle| and their number is bounded."""
     cam = _stage_cam(res)
     W, H = cam["W"], cam["H"]
     g = synth.s_map(300_000, seed=2)
@@ -253,6 +256,7 @@ def test_full_size_smap_backward(hip_lib, res):
     bg = [0.0, 0.0, 0.0]
     of = util.oracle_forward(g, cam, bg, 0)
     o = util.oracle_backward(g, cam, bg, gc, gd, 0)
+    o64 = util.oracle_backward({k: v.astype(np.float64) for k, v in g.items()}, cam, bg, gc, gd, 0, dtype=np.float64)
     p = run_product(g, cam, bg, 0, grads=(gc, gd))
     assert np.array_equal(p["radii"], of["radii"])
     fy, fx = np.nonzero(of["margin"] <= FRAGILE)
@@ -268,15 +272,18 @@ def test_full_size_smap_backward(hip_lib, res):
     for name, key in pairs:
         a = p["grads"][name].reshape(300_000, -1).astype(np.float64)
         b = o[key].reshape(300_000, -1).astype(np.float64)
+        b64 = o64[key].reshape(300_000, -1)
         if name == "means2D":
-            a, b = a[:, :2], b[:, :2]          # the third column is never written by the rasteriser (upstream leaves it zero)
+            a, b, b64 = a[:, :2], b[:, :2], b64[:, :2]   # the third column is never written by the rasteriser (upstream leaves it zero)
         mx = np.abs(b).max()
-        bound = 1e-5 * mx + 1e-4 * np.abs(b)
+        base = 1e-5 * mx + 1e-4 * np.abs(b)
+        bound = base + np.minimum(2.0 * np.abs(b - b64), 1e-4 * mx)
         err = np.abs(a - b)
         ratio = (err / bound).max(1)
         robust = ~near
         worst = int(np.argmax(np.where(robust, ratio, 0.0)))
         report[name] = dict(max_ratio=float(ratio[robust].max()), worst_gaussian=worst, worst_abs=float(err[worst].max()), grad_max=float(mx),
+                            needed_conditioning_term=int(((err > base).any(1) & robust).sum()),
                             loose_max=float((err[near].max() / mx) if near.any() else 0.0))
         assert ratio[robust].max() <= 1.0, f"{res} grad {name}: worst Gaussian {worst} err {err[worst]} vs oracle {b[worst]} (max|grad| {mx:.3e})"
         if near.any():
