@@ -114,6 +114,8 @@ def load():
             fn.argtypes = args
         if lib.gsicp_abi_version() != 1:
             raise ImportError("libgsicp_hip.so ABI version mismatch")
+        if os.environ.get("GSICP_ANNOUNCE"):   # tools/run_reference_slam.py: show which processes of the reference run loaded the library
+            print(f"GSICP_LOADED {LIB_PATH} pid={os.getpid()}", flush=True)
         _lib = lib
     return _lib
 

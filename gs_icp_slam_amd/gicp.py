@@ -44,6 +44,13 @@ def _cur_stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def _rebuild(config):
+    reg = FastGICP()
+    for name, value in config.items():
+        getattr(reg, name)(value)
+    return reg
+
+
 class FastGICP:
     def __init__(self):
         self._lib = _lib.load()
@@ -52,6 +59,13 @@ class FastGICP:
             raise RuntimeError("pygicp.FastGICP (gfx950): " + _lib.last_error())
         self._h = ctypes.c_void_p(h)
         self._live = []   # device tensors handed over with wait=0: kept alive until the next synchronous call has returned
+        self._config = {}  # setter name -> last value (what __reduce__ replays)
+
+    def __reduce__(self):
+        """The reference builds `pygicp.FastGICP()` in the parent and ships the whole Tracker object to the spawned tracking process
+        [REF mp_Tracker.py:53; gs_icp_slam.py:121-127], so the object must pickle.  Device state is per process: the copy is a fresh
+        registration object with the same configuration (clouds are always set inside the tracking process, after the spawn)."""
+        return (_rebuild, (dict(self._config),))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -66,28 +80,36 @@ class FastGICP:
 
     # ---- configuration
     def set_max_correspondence_distance(self, d):
+        self._config["set_max_correspondence_distance"] = d
         self._ck(self._lib.gsicp_gicp_set_max_correspondence_distance(self._h, float(d)), "set_max_correspondence_distance")
 
     def set_max_knn_distance(self, d):
+        self._config["set_max_knn_distance"] = d
         self._ck(self._lib.gsicp_gicp_set_max_knn_distance(self._h, float(d)), "set_max_knn_distance")
 
     def set_correspondence_randomness(self, k):
+        self._config["set_correspondence_randomness"] = k
         self._ck(self._lib.gsicp_gicp_set_correspondence_randomness(self._h, int(k)), "set_correspondence_randomness")
 
     def set_max_iterations(self, n):
+        self._config["set_max_iterations"] = n
         self._ck(self._lib.gsicp_gicp_set_max_iterations(self._h, int(n)), "set_max_iterations")
 
     def set_num_threads(self, n):
+        self._config["set_num_threads"] = n
         self._ck(self._lib.gsicp_gicp_set_num_threads(self._h, int(n)), "set_num_threads")
 
     def set_regularization_method(self, method):
+        self._config["set_regularization_method"] = method
         m = _REG[method.upper()] if isinstance(method, str) else int(method)
         self._ck(self._lib.gsicp_gicp_set_regularization_method(self._h, m), "set_regularization_method")
 
     def set_rotation_epsilon(self, e):
+        self._config["set_rotation_epsilon"] = e
         self._ck(self._lib.gsicp_gicp_set_rotation_epsilon(self._h, float(e)), "set_rotation_epsilon")
 
     def set_transformation_epsilon(self, e):
+        self._config["set_transformation_epsilon"] = e
         self._ck(self._lib.gsicp_gicp_set_transformation_epsilon(self._h, float(e)), "set_transformation_epsilon")
 
     # ---- clouds

@@ -185,6 +185,33 @@ def s_pair_survey(cfg=REPLICA, noise=False):
                 points_b=pb[0], z_b=pb[1], trackable_b=pb[2], depth_a=pa[3], depth_b=pb[3])
 
 
+def render_frame(cfg, pose_c2w, noise_seed=None, holes=0.0):
+    """One synthetic RGB-D frame as a sensor would deliver it: (rgb uint8 (H,W,3), depth uint16 (H,W)) — the ray-cast room
+    coloured by `checker_colors` at the hit points, depth quantised with the dataset's depth_scale."""
+    W, H = cfg["W"], cfg["H"]
+    depth = raycast_depth(cfg, pose_c2w)
+    u, v = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    pc = np.stack([(u - cfg["cx"]) / cfg["fx"] * depth, (v - cfg["cy"]) / cfg["fy"] * depth, depth], -1).reshape(-1, 3)
+    rgb = (checker_colors(pc @ pose_c2w[:3, :3].T + pose_c2w[:3, 3]).reshape(H, W, 3) * 255.0).astype(np.uint8)
+    if noise_seed is not None:
+        rng = np.random.default_rng(noise_seed)
+        depth = depth + rng.normal(size=depth.shape) * (0.0012 + 0.0019 * (depth - 0.4) ** 2)
+        if holes > 0:
+            depth = np.where(rng.random(depth.shape) < holes, 0.0, depth)
+    d16 = np.clip(np.round(depth * cfg["depth_scale"]), 0, 65535).astype(np.uint16)
+    return rgb, d16
+
+
+def trajectory(n_frames, step=None, start=None):
+    """Camera-to-world poses of a smooth synthetic sequence: start o step^k (default step: 0.1 / 0.25 deg, 6 / 2 mm per frame —
+    the order of Replica's inter-frame motion)."""
+    step = se3((0.1, 0.25, 0.0), (0.006, 0.0, 0.002)) if step is None else step
+    poses = [DEFAULT_POSE_A.copy() if start is None else start.copy()]
+    for _ in range(n_frames - 1):
+        poses.append(poses[-1] @ step)
+    return poses
+
+
 # ------------------------------------------------------------------------------------------ surfel map
 def _faces():
     """(origin, edge_u, edge_v, inward/outward normal) rectangles of the room (facing in) and cuboids (facing out)."""

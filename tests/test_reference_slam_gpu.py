@@ -1,0 +1,48 @@
+"""The reference's own two-process system, UNMODIFIED, on top of this repo's drop-in packages.
+
+`gs_icp_slam_unlimit.py` builds the shared objects, spawns mp_Tracker + mp_Mapper [REF gs_icp_slam.py:81-131], the tracker
+process drives `pygicp.FastGICP`, the mapper process drives `diff_gaussian_rasterization` through render_3 + torch loss +
+torch.optim.Adam [REF mp_Mapper.py:219-248], `SharedGaussians` device tensors cross the process boundary by HIP-IPC
+[REF scene/shared_objs.py:72-104], and at the end the reference prints System FPS / ATE RMSE / PSNR.  The data is a synthetic
+sequence written in Replica's on-disk layout (no dataset in this image); third-party packages the image lacks are stand-ins
+(tests/refstubs).  The reference tree is /root/reference when present, else the byte-code oracle/make_refpy.py compiled from it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, timeout=420):
+    sys.path.insert(0, ROOT)
+    from tools.run_reference_slam import find_reference
+    if find_reference() is None:
+        pytest.skip("no reference tree on this machine (neither /root/reference nor oracle/_ref/refpy)")
+    log = os.path.join(ROOT, "gpurun_out", "reference_slam_%s.log" % "_".join(a.strip("-") for a in extra if a.startswith("--")))
+    os.makedirs(os.path.dirname(log), exist_ok=True)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_slam.py"), "--log", log, "--timeout", str(timeout - 60)] + extra,
+                       capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, f"harness printed no result line\nstdout: {p.stdout[-2000:]}\nstderr: {p.stderr[-6000:]}"
+    res = json.loads(lines[-1])
+    print("reference run:", json.dumps(res))
+    assert res["status"] == "measured", f"reference run failed: {res}\n{p.stderr[-6000:]}"
+    return res
+
+
+def test_untouched_reference_two_process_run_replica_shaped():
+    res = _run(["--synthetic", "24"])
+    assert res["processes_that_loaded_it"] >= 3, "parent, tracker process and mapper process must each load libgsicp_hip.so"
+    assert res["system_fps"] > 1.0
+    assert res["ate_rmse_cm"] < 0.5, f"ATE {res['ate_rmse_cm']} cm on a 24-frame synthetic sequence"    # printed x100: centimetres
+    assert res["psnr"] is not None and res["psnr"] > 15.0
+
+
+def test_untouched_reference_two_process_run_tum_shaped():
+    res = _run(["--synthetic", "20", "--shape", "tum", "--noise"])
+    assert res["processes_that_loaded_it"] >= 3
+    assert res["ate_rmse_cm"] < 1.5

@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""Runs the reference's OWN, unmodified two-process system — `gs_icp_slam_unlimit.py` (or `gs_icp_slam.py`, capped at 30 FPS)
+spawning mp_Tracker + mp_Mapper [REF gs_icp_slam.py:121-131] — with this repo's drop-in `pygicp`, `diff_gaussian_rasterization`
+and `simple_knn` packages on PYTHONPATH, and captures the statistics it prints: System FPS / ATE RMSE [REF mp_Tracker.py:333-334]
+and PSNR / SSIM [REF mp_Mapper.py:422].
+
+    python tools/run_reference_slam.py --synthetic 30                     # writes a Replica-layout synthetic sequence first
+    python tools/run_reference_slam.py --dataset /data/Replica/room0 --config <reference>/configs/Replica/caminfo.txt
+
+The reference tree is taken from --reference, else /root/reference, else oracle/_ref/refpy (sourceless byte-code compiled from
+/root/reference by oracle/make_refpy.py, because the GPU box has no /root/reference).  Nothing in it is edited; it is executed with
+`python <reference>/gs_icp_slam_unlimit.py[c] <the flags of replica_unlimit.sh>`.  Third-party packages this image lacks
+(cv2, open3d, rerun, torchmetrics, plyfile) are served by the stand-ins in tests/refstubs, appended LAST to PYTHONPATH.
+Prints one JSON line {"system_fps": .., "ate_rmse_cm": .., "psnr": .., ...}; with no dataset and no --synthetic: "not measured".
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find_reference(explicit=None):
+    for cand in (explicit, os.environ.get("GSICP_REFERENCE"), "/root/reference", os.path.join(ROOT, "oracle", "_ref", "refpy")):
+        if cand and (os.path.exists(os.path.join(cand, "mp_Tracker.py")) or os.path.exists(os.path.join(cand, "mp_Tracker.pyc"))):
+            return cand
+    return None
+
+
+def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_flags=(), flags=None):
+    name = "gs_icp_slam_unlimit" if unlimit else "gs_icp_slam"
+    script = os.path.join(reference, name + ".py")
+    if not os.path.exists(script):
+        script += "c"
+    # the flags replica.sh / replica_unlimit.sh pass [REF replica.sh:135-142]
+    f = dict(keyframe_th=0.7, knn_maxd=99999.0, overlapped_th=5e-4, max_correspondence_distance=0.02, trackable_opacity_th=0.05,
+             overlapped_th2=5e-5, downsample_rate=10)
+    f.update(flags or {})
+    cmd = [sys.executable, "-W", "ignore", script, "--dataset_path", dataset, "--config", config, "--output_path", output]
+    for k, v in f.items():
+        cmd += [f"--{k}", str(v)]
+    cmd += list(extra_flags)
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT] + [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p] +
+                                        [os.path.join(ROOT, "tests", "refstubs")])
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MPLBACKEND", "Agg")
+    env["GSICP_ANNOUNCE"] = "1"
+    t0 = time.time()
+    p = subprocess.Popen(cmd, cwd=reference, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+        timed_out = False
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(p.pid, signal.SIGKILL)     # the exact process group started above
+        out, _ = p.communicate()
+        timed_out = True
+    res = dict(returncode=p.returncode, timed_out=timed_out, wall_s=round(time.time() - t0, 2), script=os.path.basename(script),
+               reference=reference, loaded_so=sorted(set(re.findall(r"GSICP_LOADED (\S+)", out))),
+               processes_that_loaded_it=len(set(re.findall(r"GSICP_LOADED \S+ pid=(\d+)", out))))
+    for key, pat in (("system_fps", r"System FPS:\s*([-\d.eE+naninf]+)"), ("ate_rmse_cm", r"ATE RMSE:\s*([-\d.eE+naninf]+)"),
+                     ("psnr", r"PSNR:\s*([-\d.eE+naninf]+)"), ("ssim", r"SSIM:\s*([-\d.eE+naninf]+)")):
+        m = re.search(pat, out)
+        res[key] = float(m.group(1)) if m else None
+    return res, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default=None)
+    ap.add_argument("--dataset", default=None)
+    ap.add_argument("--config", default=None)
+    ap.add_argument("--output", default=None)
+    ap.add_argument("--synthetic", type=int, default=0, help="write and use a synthetic Replica-layout sequence of this many frames")
+    ap.add_argument("--shape", choices=["replica", "tum"], default="replica")
+    ap.add_argument("--noise", action="store_true")
+    ap.add_argument("--limit30", action="store_true", help="run gs_icp_slam.py (tracker capped at 30 FPS [REF mp_Tracker.py:323]) instead of the _unlimit variant")
+    ap.add_argument("--timeout", type=float, default=600.0)
+    ap.add_argument("--log", default=None, help="write the reference's full stdout here")
+    a = ap.parse_args()
+    ref = find_reference(a.reference)
+    if ref is None:
+        print(json.dumps({"status": "not measured", "why": "no reference tree (/root/reference or oracle/_ref/refpy) on this machine"}))
+        return 0
+    tmp = None
+    flags = {}
+    if a.synthetic > 0:
+        sys.path.insert(0, ROOT)
+        from tools.make_synth_dataset import write_dataset
+        tmp = tempfile.mkdtemp(prefix="gsicp_synth_")
+        cfg, _ = write_dataset(tmp, a.synthetic, a.shape, a.noise)
+        a.dataset, a.config = tmp, os.path.join(tmp, "caminfo.txt")
+        if a.shape == "tum":   # [REF tum.sh:135-142]
+            flags = dict(keyframe_th=0.81, overlapped_th=1e-3, max_correspondence_distance=0.03, overlapped_th2=1e-4, downsample_rate=5)
+    if not a.dataset or not os.path.isdir(a.dataset):
+        print(json.dumps({"status": "not measured", "why": f"dataset {a.dataset!r} not present on this machine"}))
+        return 0
+    if not a.config:
+        a.config = os.path.join(ref, "configs", "Replica", "caminfo.txt")
+    out_dir = a.output or tempfile.mkdtemp(prefix="gsicp_out_")
+    res, log = run(ref, a.dataset, a.config, out_dir, unlimit=not a.limit30, timeout=a.timeout, flags=flags)
+    res.update(status="measured" if res["returncode"] == 0 and res["system_fps"] is not None else "failed", dataset=a.dataset,
+               data="synthetic" if a.synthetic else "real", frames=a.synthetic or None)
+    if a.log:
+        with open(a.log, "w") as fh:
+            fh.write(log)
+    if res["status"] != "measured":
+        sys.stderr.write(log[-6000:])
+    print(json.dumps(res))
+    return 0 if res["status"] == "measured" else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
