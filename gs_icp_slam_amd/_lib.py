@@ -130,6 +130,36 @@ def check(rc, what):
     return rc
 
 
+# ---- optional call trace (GSICP_CALL_TRACE=<dir>): wall-clock enter/exit of every drop-in entry point, one file per process.
+# Lets the untouched reference loop be profiled from the outside (tools/run_reference_slam.py --trace): the gaps BETWEEN calls are
+# the reference's own host code.  Costs two perf_counter() reads per call when on, one dict lookup when off.
+_TRACE_DIR = os.environ.get("GSICP_CALL_TRACE")
+_trace_fh = None
+
+
+def traced(name):
+    def deco(fn):
+        if not _TRACE_DIR:
+            return fn
+        import functools
+        import time
+
+        @functools.wraps(fn)
+        def wrapper(*a, **k):
+            global _trace_fh
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                t1 = time.perf_counter()
+                if _trace_fh is None:
+                    os.makedirs(_TRACE_DIR, exist_ok=True)
+                    _trace_fh = open(os.path.join(_TRACE_DIR, f"{os.getpid()}.trace"), "a", buffering=1)
+                _trace_fh.write(f"{name} {t0:.6f} {t1:.6f}\n")
+        return wrapper
+    return deco
+
+
 def profile_enable(on=True):
     load().gsicp_profile_enable(int(bool(on)))
 

@@ -121,6 +121,7 @@ class FastGICP:
         f64 = pts.dtype == np.float64
         return np.ascontiguousarray(pts, dtype=np.float64 if f64 else np.float32), int(f64)
 
+    @_lib.traced("gicp.set_input_target")
     def set_input_target(self, points):
         if _is_device_tensor(points):
             t = _dev_f32(points, 3)
@@ -131,6 +132,7 @@ class FastGICP:
         p, f64 = self._points(points)
         self._ck(self._lib.gsicp_gicp_set_input_target(self._h, _vp(p), p.shape[0], f64), "set_input_target")
 
+    @_lib.traced("gicp.set_input_source")
     def set_input_source(self, points):
         if _is_device_tensor(points):
             t = _dev_f32(points, 3)
@@ -175,15 +177,18 @@ class FastGICP:
         self._live.clear()
         return n
 
+    @_lib.traced("gicp.set_target_filter")
     def set_target_filter(self, num_trackable, input_filter):
         f = np.ascontiguousarray(input_filter, dtype=np.int32).ravel()
         self._ck(self._lib.gsicp_gicp_set_target_filter(self._h, int(num_trackable), _vp(f), f.shape[0]), "set_target_filter")
 
+    @_lib.traced("gicp.set_source_filter")
     def set_source_filter(self, num_trackable, input_filter):
         f = np.ascontiguousarray(input_filter, dtype=np.int32).ravel()
         self._ck(self._lib.gsicp_gicp_set_source_filter(self._h, int(num_trackable), _vp(f), f.shape[0]), "set_source_filter")
 
     # ---- covariances
+    @_lib.traced("gicp.calculate_target_covariance_with_filter")
     def calculate_target_covariance_with_filter(self):
         self._ck(self._lib.gsicp_gicp_calculate_target_covariance_with_filter(self._h), "calculate_target_covariance_with_filter")
 
@@ -195,15 +200,19 @@ class FastGICP:
         got = self._ck(fn(self._h, _vp(out), n), what)
         return out[: got * width]
 
+    @_lib.traced("gicp.get_target_rotationsq")
     def get_target_rotationsq(self):
         return self._fetch(self._lib.gsicp_gicp_get_target_rotationsq, self._lib.gsicp_gicp_num_target(self._h), 4, "get_target_rotationsq")
 
+    @_lib.traced("gicp.get_target_scales")
     def get_target_scales(self):
         return self._fetch(self._lib.gsicp_gicp_get_target_scales, self._lib.gsicp_gicp_num_target(self._h), 3, "get_target_scales")
 
+    @_lib.traced("gicp.get_source_rotationsq")
     def get_source_rotationsq(self):
         return self._fetch(self._lib.gsicp_gicp_get_source_rotationsq, self._lib.gsicp_gicp_num_source(self._h), 4, "get_source_rotationsq")
 
+    @_lib.traced("gicp.get_source_scales")
     def get_source_scales(self):
         return self._fetch(self._lib.gsicp_gicp_get_source_scales, self._lib.gsicp_gicp_num_source(self._h), 3, "get_source_scales")
 
@@ -222,6 +231,7 @@ class FastGICP:
     def get_source_scales_tensor(self, device=None):
         return self._fetch_tensor(self._lib.gsicp_gicp_get_source_scales_device, 3, "get_source_scales_tensor", device)
 
+    @_lib.traced("gicp.set_target_covariances_fromqs")
     def set_target_covariances_fromqs(self, rotations_flat, scales_flat):
         if _is_device_tensor(rotations_flat) and _is_device_tensor(scales_flat):
             r, sc = _dev_f32(rotations_flat).reshape(-1), _dev_f32(scales_flat).reshape(-1)
@@ -236,6 +246,7 @@ class FastGICP:
                  "set_target_covariances_fromqs")
 
     # ---- registration
+    @_lib.traced("gicp.align")
     def align(self, initial_guess=None):
         init = np.eye(4) if initial_guess is None else np.asarray(initial_guess)
         if init.shape != (4, 4):
@@ -246,6 +257,7 @@ class FastGICP:
         self._live.clear()   # everything enqueued before the align kernel has completed
         return out.astype(np.float32)   # the reference binding returns an Eigen::Matrix4f
 
+    @_lib.traced("gicp.get_source_correspondence")
     def get_source_correspondence(self):
         n = self._lib.gsicp_gicp_num_source(self._h)
         idx = np.empty(n, np.int32)

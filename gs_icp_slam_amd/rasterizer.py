@@ -74,6 +74,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
+    @_lib.traced("raster.forward")
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, count_out=None):
         lib = _lib.load()
         if not means3D.is_cuda:
@@ -125,6 +126,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         return depth, color, radii, is_used
 
     @staticmethod
+    @_lib.traced("raster.backward")
     def backward(ctx, grad_depth, grad_color, _grad_radii, _grad_used):
         lib = _lib.load()
         (means3D, sh_c, col_c, sc_c, rot_c, cov_c, radii, geom, binning, img, bg, view, proj, campos) = ctx.saved_tensors

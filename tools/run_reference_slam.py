@@ -32,7 +32,7 @@ def find_reference(explicit=None):
     return None
 
 
-def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_flags=(), flags=None):
+def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_flags=(), flags=None, trace_dir=None, omp_threads=1):
     name = "gs_icp_slam_unlimit" if unlimit else "gs_icp_slam"
     script = os.path.join(reference, name + ".py")
     if not os.path.exists(script):
@@ -51,6 +51,16 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MPLBACKEND", "Agg")
     env["GSICP_ANNOUNCE"] = "1"
+    # Three processes x torch's default intra-op pool (one thread per hardware thread, spinning after every parallel region) exhaust a
+    # container's cgroup CPU quota within the first ~20 ms of every 100 ms scheduler period and the whole system then stalls for the
+    # rest of it (measured: tracker frames and mapper iterations both alternate 10 ms / 90 ms).  The per-frame CPU work of the reference is
+    # a handful of small torch ops; give each process a one-thread pool (measured on the 16-CPU-quota MI355X box, 96 synthetic frames:
+    # default pool 8-10 FPS, 4 threads 15 FPS, 1 thread 84 FPS).  Environment only — no reference file is touched.
+    if omp_threads > 0:
+        env.setdefault("OMP_NUM_THREADS", str(omp_threads))
+        env.setdefault("MKL_NUM_THREADS", str(omp_threads))
+    if trace_dir:
+        env["GSICP_CALL_TRACE"] = trace_dir
     t0 = time.time()
     p = subprocess.Popen(cmd, cwd=reference, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
     try:
@@ -82,6 +92,8 @@ def main():
     ap.add_argument("--noise", action="store_true")
     ap.add_argument("--limit30", action="store_true", help="run gs_icp_slam.py (tracker capped at 30 FPS [REF mp_Tracker.py:323]) instead of the _unlimit variant")
     ap.add_argument("--timeout", type=float, default=600.0)
+    ap.add_argument("--trace", default=None, help="directory for the drop-in call trace (GSICP_CALL_TRACE): one file per process")
+    ap.add_argument("--omp-threads", type=int, default=1, help="OMP_NUM_THREADS for the reference's processes (0 = leave the environment alone)")
     ap.add_argument("--log", default=None, help="write the reference's full stdout here")
     a = ap.parse_args()
     ref = find_reference(a.reference)
@@ -104,7 +116,7 @@ def main():
     if not a.config:
         a.config = os.path.join(ref, "configs", "Replica", "caminfo.txt")
     out_dir = a.output or tempfile.mkdtemp(prefix="gsicp_out_")
-    res, log = run(ref, a.dataset, a.config, out_dir, unlimit=not a.limit30, timeout=a.timeout, flags=flags)
+    res, log = run(ref, a.dataset, a.config, out_dir, unlimit=not a.limit30, timeout=a.timeout, flags=flags, trace_dir=a.trace, omp_threads=a.omp_threads)
     res.update(status="measured" if res["returncode"] == 0 and res["system_fps"] is not None else "failed", dataset=a.dataset,
                data="synthetic" if a.synthetic else "real", frames=a.synthetic or None)
     if a.log:
