@@ -51,6 +51,8 @@ SIGNATURES = {
                                 c_void_p]),
     "gsicp_adam_step_capturable": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                            c_void_p, c_void_p]),
+    "gsicp_adam_step_guarded": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
+                                        c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p]),
     "gsicp_gicp_create": (c_void_p, []),
     "gsicp_gicp_destroy": (None, [c_void_p]),
     "gsicp_gicp_set_max_correspondence_distance": (c_int, [c_void_p, c_double]),

@@ -402,11 +402,16 @@ __device__ inline AdamPMV adam_update(float p, float m, float v, float g, float 
 // is pure streaming: 7 float accesses per element, 118 MB at P = 300 k).  Tensors that are not 16-byte aligned take the scalar loop.
 // CAPTURABLE: the step count and the learning rates come from device memory (a captured hipGraph replays them); otherwise the host
 // has already folded them into t.step_size / inv_bc2_sqrt_host.
+// GUARD (capturable path only): when *guard_count > guard_limit the iteration that produced these gradients is void — the sync-free
+// rasteriser forward rendered nothing because its duplicate lists outgrew their capacity — and the step must not happen: parameters,
+// both moments and the step count stay as they are, and the bump kernel counts the skipped step in a sticky device counter.
 template <bool CAPTURABLE>
 __global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const double* __restrict__ lr_dev, const int* __restrict__ step_dev,
-                                                          float beta1, float beta2, float eps, float inv_bc2_sqrt_host) {
+                                                          float beta1, float beta2, float eps, float inv_bc2_sqrt_host,
+                                                          const unsigned* __restrict__ guard_count, unsigned guard_limit) {
     __shared__ double s_bc1;
     __shared__ float s_inv_bc2_sqrt;
+    if (CAPTURABLE && guard_count && *guard_count > guard_limit) return;   // wave-uniform (one scalar load)
     if (CAPTURABLE) {
         if (threadIdx.x == 0) {   // two double pow() per BLOCK, not per thread
             const int step = *step_dev + 1;
@@ -444,7 +449,13 @@ __global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const dou
         M[j] = a0.m; V[j] = a0.v; P[j] = a0.p;
     }
 }
-__global__ void adam_bump_step_kernel(int* step_dev) { *step_dev += 1; }
+__global__ void adam_bump_step_kernel(int* step_dev, const unsigned* __restrict__ guard_count, unsigned guard_limit, unsigned* skipped_dev) {
+    if (guard_count && *guard_count > guard_limit) {
+        if (skipped_dev) *skipped_dev += 1u;
+        return;
+    }
+    *step_dev += 1;
+}
 
 // ------------------------------------------------------------------------------------------------ activations
 // GaussianModel's getters [REF scene/gaussian_model.py:105-125, 44-56]: opacity = sigmoid(_opacity), scaling = exp(_scaling),
@@ -651,14 +662,15 @@ int gsicp_adam_step(int n_groups, float* const* params, const float* const* grad
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, bc1);
     if (total == 0) return 0;
     hipLaunchKernelGGL(adam_tensor_kernel<false>, adam_grid(t), dim3(256), 0, stream, t, (const double*)nullptr, (const int*)nullptr, beta1, beta2, eps,
-                       (float)(1.0 / std::sqrt(bc2)));
+                       (float)(1.0 / std::sqrt(bc2)), (const unsigned*)nullptr, 0u);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step: kernel launch failed"; return -1; }
     return 0;
 }
 
-int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
-                               float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
-                               float eps, int* step_dev, void* stream_v) {
+int gsicp_adam_step_guarded(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
+                            float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
+                            unsigned int* skipped_dev, void* stream_v) {
     hipStream_t stream = (hipStream_t)stream_v;
     if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || !lr_dev || !step_dev) {
         g_last_error = "gsicp_adam_step_capturable: 1..8 tensors, device lr array and device step counter"; return -2;
@@ -666,10 +678,19 @@ int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* 
     AdamTable t;
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, nullptr, 1.0);
     if (total > 0)
-        hipLaunchKernelGGL(adam_tensor_kernel<true>, adam_grid(t), dim3(256), 0, stream, t, lr_dev, (const int*)step_dev, beta1, beta2, eps, 0.f);
-    hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, stream, step_dev);
+        hipLaunchKernelGGL(adam_tensor_kernel<true>, adam_grid(t), dim3(256), 0, stream, t, lr_dev, (const int*)step_dev, beta1, beta2, eps, 0.f,
+                           guard_count, guard_limit);
+    if (bump_step)
+        hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, stream, step_dev, guard_count, guard_limit, skipped_dev);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step_capturable: kernel launch failed"; return -1; }
     return 0;
+}
+
+int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
+                               float eps, int* step_dev, void* stream_v) {
+    return gsicp_adam_step_guarded(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr_dev, beta1, beta2, eps, step_dev, 1, nullptr, 0u,
+                                   nullptr, stream_v);
 }
 
 }  // extern "C"

@@ -10,7 +10,7 @@ What changes from iteration to iteration in the reference — the keyframe: came
 lives in static device buffers that `set_view()` overwrites before `step()`.  Everything with a fixed address (parameters,
 Adam state, learning rates, step count) is updated in place by the replay.  The graph is valid while the parameter tensors
 are the ones captured: after the map grows or is pruned (new parameter tensors, [REF scene/gaussian_model.py:409-492]) build
-a new MapperIterationGraph — capture costs about three eager iterations.
+a new MapperIterationGraph — capture costs about three eager iterations of time but applies NO optimiser update (warm-up is rolled back).
 """
 import ctypes
 
@@ -65,6 +65,12 @@ class MapperIterationGraph:
             debug=False, capacity=self.capacity)
         self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
         self._warmup = int(warmup)
+        # device-side overflow guard: a replay whose duplicate count exceeds the capacity renders nothing; the Adam kernels
+        # read the count and skip that step entirely (no stale-momentum drift, step count not advanced), counting it in a sticky counter
+        inner = self.rasterizer.inner if hasattr(self.rasterizer, "inner") else self.rasterizer
+        if getattr(inner, "num_rendered", None) is None:
+            inner.num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
+        optimizer.set_overflow_guard(inner.num_rendered, self.capacity)
         # screen-space gradient holder [REF gaussian_renderer/__init__.py:227]: the reference makes a fresh zero tensor per call;
         # its VALUE is never read by the rasteriser, so one static tensor serves every replay
         self._means2D = torch.zeros_like(params["means3D"], requires_grad=True)
@@ -113,14 +119,41 @@ class MapperIterationGraph:
         return parts, radii, used
 
     def capture(self):
+        """Warm up (allocator pools, device lr array, Adam state) and capture.  The warm-up iterations run on the live parameters
+        but are NOT optimiser steps of the caller's schedule: parameters, both moments and the step counters are snapshotted before and
+        restored after, so capturing (and re-capturing after the map changed) applies zero updates — the reference performs exactly one
+        update per loop iteration [REF mp_Mapper.py:219-248]."""
         dev = self.params["means3D"].device
         self.optimizer.zero_grad(set_to_none=True)
+        snap_p = {k: v.detach().clone() for k, v in self.params.items()}
+        snap_s = {}
+        for p in self.params.values():
+            st = self.optimizer.state.get(p, {})
+            snap_s[p] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):          # eager warm-up on a side stream (allocator pools, lr array, Adam state)
+        with torch.cuda.stream(side):          # eager warm-up on a side stream
             for _ in range(max(self._warmup, 1)):
                 self._iteration()
         torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            steps_done = set()
+            for k, v in self.params.items():
+                v.copy_(snap_p[k])
+                st = self.optimizer.state.get(v, {})
+                for name, val in st.items():
+                    if not torch.is_tensor(val):
+                        continue
+                    if name == "step":
+                        if val.data_ptr() in steps_done:
+                            continue
+                        steps_done.add(val.data_ptr())
+                    old = snap_s[v].get(name)
+                    if torch.is_tensor(old):
+                        val.copy_(old)
+                    else:                         # state was created by the warm-up: its pre-warm-up value is zero
+                        val.zero_()
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -139,5 +172,11 @@ class MapperIterationGraph:
         return self.loss_parts[0]
 
     def overflowed(self):
-        """True when the last replay produced more duplicates than the capacity (it then rendered nothing).  Synchronises."""
+        """True when the last replay produced more duplicates than the capacity (it then rendered nothing and its optimiser step was
+        skipped on the device).  Synchronises."""
         return self.num_rendered is not None and int(self.num_rendered.item()) > self.capacity
+
+    def skipped_steps(self):
+        """Number of replays whose optimiser step the device-side overflow guard skipped so far (sticky counter; synchronises)."""
+        t = self.optimizer.skipped_steps
+        return 0 if t is None else int(t.item())

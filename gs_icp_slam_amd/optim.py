@@ -23,23 +23,40 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = bool(capturable)
-        self._lr_dev = {}       # bucket key -> (device float tensor, list of host lr values it holds)
+        self._lr_dev = {}       # (group index, position, betas, eps) bucket key -> [device double tensor, host lr values it holds]
+        self._guard = None      # (count tensor uint32/int32[1], limit): skip the step when count > limit (capturable path)
+        self.skipped_steps = None   # device int32[1], sticky: steps skipped by the guard since construction (read it whenever convenient)
+
+    def set_overflow_guard(self, count, limit):
+        """Capturable path: skip the whole step (parameters, moments and step count untouched) whenever `count` (a DEVICE int32[1],
+        e.g. GaussianRasterizer.num_rendered) exceeds `limit` (the rasteriser's list capacity) at the time the step runs — the
+        sync-free forward then rendered nothing and every gradient is zero.  `skipped_steps` counts such steps on the device."""
+        if count is None:
+            self._guard = None
+            return
+        if not count.is_cuda or count.numel() != 1 or count.element_size() != 4:
+            raise RuntimeError("FusedAdam.set_overflow_guard: count must be a 4-byte integer device tensor with one element")
+        self._guard = (count, int(limit))
+        if self.skipped_steps is None or self.skipped_steps.device != count.device:
+            self.skipped_steps = torch.zeros(1, dtype=torch.int32, device=count.device)
 
     def sync_lr(self):
         """Push the param groups' current learning rates to the device arrays of the capturable path."""
-        lr_of = {id(p): float(g["lr"]) for g in self.param_groups for p in g["params"]}
-        for key, (t, plist, vals) in list(self._lr_dev.items()):
-            new = [lr_of.get(i, v) for i, v in zip(plist, vals)]
-            if new != vals:
-                t.copy_(torch.tensor(new, dtype=torch.float64))
-                self._lr_dev[key] = (t, plist, new)
+        for key, entry in self._lr_dev.items():
+            new = [float(self.param_groups[gi]["lr"]) for gi, _pi in key[0]]
+            if new != entry[1]:
+                entry[0].copy_(torch.tensor(new, dtype=torch.float64))
+                entry[1] = new
 
     def _step_capturable(self, lib):
-        buckets = {}   # (beta1, beta2, eps, id(step tensor)) -> list of (p, g, m, v, lr)
+        # bucket = tensors that share (betas, eps, step counter); identified by (param-group index, position) pairs, which stay valid when
+        # a map store re-binds fresh Parameter objects into the same groups [REF scene/gaussian_model.py:409-492] (ids of dead objects
+        # can be reused by CPython, group positions cannot)
+        buckets = {}
         fresh = {}
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            for p in group["params"]:
+            for pi, p in enumerate(group["params"]):
                 if p.grad is None:
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or not p.grad.is_contiguous():
@@ -54,22 +71,33 @@ class FusedAdam(torch.optim.Optimizer):
                 elif not torch.is_tensor(st["step"]):
                     st["step"] = torch.full((), int(st["step"]), dtype=torch.int32, device=p.device)
                 buckets.setdefault((float(b1), float(b2), float(group["eps"]), st["step"].data_ptr()), []).append(
-                    (p, p.grad, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), st["step"]))
+                    (p, p.grad, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), st["step"], (gi, pi)))
         capturing = torch.cuda.is_current_stream_capturing()
-        for (b1, b2, eps, _sp), items in buckets.items():
-            if len(items) > _MAX:
-                raise RuntimeError("FusedAdam(capturable): more than 8 tensors share one step counter")
+        # every distinct step tensor is bumped exactly once per step(): by the LAST launch that reads it
+        last_of = {}
+        launches = []
+        for (b1, b2, eps, sp), items in buckets.items():
+            for i in range(0, len(items), _MAX):
+                launches.append((b1, b2, eps, sp, items[i:i + _MAX]))
+                last_of[sp] = len(launches) - 1
+        live_keys = set()
+        for li, (b1, b2, eps, sp, items) in enumerate(launches):
             dev = items[0][0].device
-            key = (b1, b2, eps, _sp, tuple(id(t[0]) for t in items))
+            key = (tuple(t[6] for t in items), b1, b2, eps)
+            live_keys.add(key)
             lrs = [t[4] for t in items]
             if key not in self._lr_dev:
                 if capturing:
                     raise RuntimeError("FusedAdam(capturable): run one step() outside graph capture first (allocates the device lr array)")
-                self._lr_dev[key] = (torch.tensor(lrs, dtype=torch.float64).to(dev), [id(t[0]) for t in items], lrs)
-            elif not capturing and self._lr_dev[key][2] != lrs:
+                self._lr_dev[key] = [torch.tensor(lrs, dtype=torch.float64).to(dev), lrs]
+            elif not capturing and self._lr_dev[key][1] != lrs:
                 self._lr_dev[key][0].copy_(torch.tensor(lrs, dtype=torch.float64))
-                self._lr_dev[key] = (self._lr_dev[key][0], self._lr_dev[key][1], lrs)
+                self._lr_dev[key][1] = lrs
             lr_dev = self._lr_dev[key][0]
+            guard_ptr, guard_lim, skip_ptr = None, 0, None
+            if self._guard is not None and self._guard[0].device == dev:
+                guard_ptr, guard_lim = ctypes.c_void_p(self._guard[0].data_ptr()), self._guard[1]
+                skip_ptr = ctypes.c_void_p(self.skipped_steps.data_ptr())
             with torch.cuda.device(dev):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 n = len(items)
@@ -78,8 +106,12 @@ class FusedAdam(torch.optim.Optimizer):
                 M = (ctypes.c_void_p * n)(*[t[2].data_ptr() for t in items])
                 V = (ctypes.c_void_p * n)(*[t[3].data_ptr() for t in items])
                 N = (ctypes.c_longlong * n)(*[t[0].numel() for t in items])
-                _lib.check(lib.gsicp_adam_step_capturable(n, P, G, M, V, N, ctypes.c_void_p(lr_dev.data_ptr()), b1, b2, eps,
-                                                          ctypes.c_void_p(items[0][5].data_ptr()), stream), "gsicp_adam_step_capturable")
+                _lib.check(lib.gsicp_adam_step_guarded(n, P, G, M, V, N, ctypes.c_void_p(lr_dev.data_ptr()), b1, b2, eps,
+                                                       ctypes.c_void_p(items[0][5].data_ptr()), int(last_of[sp] == li), guard_ptr, guard_lim,
+                                                       skip_ptr, stream), "gsicp_adam_step_guarded")
+        if not capturing:
+            for key in [k for k in self._lr_dev if k not in live_keys]:
+                del self._lr_dev[key]
 
     @torch.no_grad()
     def step(self, closure=None):

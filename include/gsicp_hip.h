@@ -255,6 +255,18 @@ int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* 
                                float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
                                float eps, int* step_dev, void* stream);
 
+/* gsicp_adam_step_capturable with two additions for a captured mapper iteration:
+ *  - bump_step: 0 = leave *step_dev alone (several launches share one counter: bump it with the LAST launch only, so that every
+ *    bucket of one optimiser step sees the same step number);
+ *  - guard: when guard_count (DEVICE) is non-NULL and *guard_count > guard_limit, nothing is updated and the step is not counted;
+ *    *skipped_dev (DEVICE, optional, sticky) is incremented instead.  Pass the rasteriser's num_rendered_dev and its list capacity:
+ *    a sync-free forward whose duplicate lists overflowed rendered nothing, and its all-zero gradients must not move the parameters on
+ *    stale momentum. */
+int gsicp_adam_step_guarded(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                            float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
+                            float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
+                            unsigned int* skipped_dev, void* stream);
+
 /* Map pruning without reallocation: GaussianModel.prune_points / _prune_optimizer
  * [REF scene/gaussian_model.py:409-447] apply one boolean mask to every parameter, both Adam moments and the per-Gaussian
  * statistics.  This moves the rows with keep[i] != 0 of `n_arrays` (<= 24) row-major DEVICE arrays from src[a] to dst[a] (distinct

@@ -127,7 +127,7 @@ def test_captured_iteration_equals_eager_iterations():
             d, c, _, _ = GaussianRasterizer(rs_k)(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"],
                                                   opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
         views.append((rs_k, c.clone(), d.clone()))
-    schedule = [0, 0, 1, 0, 1, 1]    # first two = the graph's eager warm-up iterations (real optimiser steps)
+    schedule = [0, 1, 0, 1, 1, 0]    # capture() applies NO update (its warm-up is rolled back): the graph side replays all six
 
     losses_e = []
     for k in schedule:
@@ -145,14 +145,19 @@ def test_captured_iteration_equals_eager_iterations():
     mg = MapperIterationGraph(params_g, opt_g, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=2_000_000, warmup=2)
     rs0, c0, d0 = views[0]
     mg.set_view(rs0.viewmatrix, rs0.projmatrix, rs0.campos, c0, d0)
-    mg.capture()                      # 2 warm-up iterations on view 0, then capture (capture itself executes nothing)
+    before = {k: v.detach().clone() for k, v in params_g.items()}
+    mg.capture()                      # 2 warm-up iterations on view 0, rolled back, then capture (capture itself executes nothing)
+    for k in before:
+        assert torch.equal(before[k], params_g[k]), f"capture() moved {k}"
+    assert int(opt_g.state[params_g["means3D"]]["step"].item()) == 0
+    assert all(not bool(opt_g.state[p]["exp_avg"].any()) and not bool(opt_g.state[p]["exp_avg_sq"].any()) for p in params_g.values())
     losses_g = []
-    for k in schedule[2:]:
+    for k in schedule:
         rs_k, gt_c, gt_d = views[k]
         mg.set_view(rs_k.viewmatrix, rs_k.projmatrix, rs_k.campos, gt_c, gt_d)
         losses_g.append(float(mg.step()))
         assert not mg.overflowed()
-    np.testing.assert_allclose(losses_g, losses_e[2:], rtol=1e-5)
+    np.testing.assert_allclose(losses_g, losses_e, rtol=1e-5)
     assert int(opt_g.state[params_g["means3D"]]["step"].item()) == len(schedule)
     for k in params_e:
         torch.testing.assert_close(params_g[k], params_e[k], rtol=1e-4, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
@@ -163,6 +168,39 @@ def test_captured_iteration_equals_eager_iterations():
     torch.cuda.synchronize()
     assert not mg.overflowed() and 0 < int(mg.num_rendered.item()) < 2_000_000
     assert float(loss) < losses_g[-1]
+
+
+def test_overflowing_replay_skips_the_optimiser_step_on_the_device():
+    """a replay whose duplicate count exceeds the capacity renders nothing and yields all-zero gradients; Adam must not move
+    the parameters on stale momentum, decay exp_avg_sq or advance the step count.  The guard lives in the Adam kernels (no host sync)."""
+    from gs_icp_slam_amd.graph import MapperIterationGraph
+    P, W, H = 20000, 320, 200
+    g, cam, params, opt = _mapper_setup(P, W, H, capturable=True)
+    rs = make_settings(cam, [0.0, 0.0, 0.0])
+    gt_c = torch.rand((3, H, W), device="cuda")
+    gt_d = torch.rand((1, H, W), device="cuda") + 1.0
+    # capacity fits view A but not view B (a camera pulled back: many more tiles per Gaussian... here simply a far smaller capacity)
+    probe = MapperIterationGraph(params, opt, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=4_000_000, warmup=1)
+    probe.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_c, gt_d)
+    probe.capture()
+    probe.step()
+    R = int(probe.num_rendered.item())
+    steps0 = int(opt.state[params["means3D"]]["step"].item())
+    assert steps0 == 1 and probe.skipped_steps() == 0
+    del probe
+    small = MapperIterationGraph(params, opt, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=R // 2, warmup=1)
+    small.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_c, gt_d)
+    small.capture()
+    snap = {k: v.detach().clone() for k, v in params.items()}
+    snap_m = {k: opt.state[v]["exp_avg"].clone() for k, v in params.items()}
+    snap_v = {k: opt.state[v]["exp_avg_sq"].clone() for k, v in params.items()}
+    for _ in range(3):
+        small.step()
+    assert small.overflowed() and small.skipped_steps() == 3
+    assert int(opt.state[params["means3D"]]["step"].item()) == steps0
+    for k, v in params.items():
+        assert torch.equal(v, snap[k]), f"{k} moved on an overflowed replay"
+        assert torch.equal(opt.state[v]["exp_avg"], snap_m[k]) and torch.equal(opt.state[v]["exp_avg_sq"], snap_v[k])
 
 
 def test_graph_rejects_host_step_optimizer():
