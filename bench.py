@@ -2,20 +2,27 @@
 """bench.py — GS-ICP-SLAM hot path on MI355X.
 
 One "step" = one SLAM frame's worth of the hot path on synthetic Replica-shaped input:
-  tracker : pygicp.FastGICP  set_input_source + set_source_filter + align + get_source_correspondence
-            on S-pair (8 280 points/frame, max_correspondence_distance 0.02)          [REF mp_Tracker.py:191-231]
+  tracker : pygicp.FastGICP  set_input_source + set_source_filter + align + get_source_correspondence           [REF mp_Tracker.py:191-231]
+            on the S-pair exactly as SURVEY §8(d) words it (room centre, looking +z, 1 deg about y + 2 cm along x; 8 280 points, gate
+            0.02 m) — `config.workload` states the motion and the LM iteration count; the second pair (corner-facing, 0.36 deg / 8.5 mm,
+            inside the convergence basin) is timed as a leg
   mapper  : one full optimisation iteration — activations, GaussianRasterizer forward, the mapping loss
-            0.8 L1 + 0.2 (1-SSIM) + 0.1 L1(depth/10) (fused HIP kernel), backward, Adam step over the parameter groups
-            (fused HIP kernel), zero_grad; activations fused; P = 300 000 surfels, 1200x680                 [REF mp_Mapper.py:219-248]
-With N > 1 GPUs the mapper's tiles are sharded across ranks (strong scaling; gs_icp_slam_amd/sharded.py) and the
-tracker runs as a replica on every rank (it does not shard — DESIGN.md).
+            0.8 L1 + 0.2 (1-SSIM) + 0.1 L1(depth/10), backward, Adam step over the parameter groups, zero_grad; P = 300 000 surfels,
+            1200x680                                                                                             [REF mp_Mapper.py:219-248]
+The two halves run concurrently, as the reference's two processes do [REF gs_icp_slam.py:121-131].
+With N > 1 GPUs the mapper's tiles are sharded across ranks (strong scaling; gs_icp_slam_amd/sharded.py) and the tracker runs as a
+replica on every rank (it does not shard — DESIGN.md).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, algorithmic bytes
-over HIP-event kernel time) and `cpu_baseline` (the OpenMP GICP oracle timed on this host's cores).
+Timing: `--repeats` back-to-back blocks, each EXACTLY `--steps` steps bracketed by barrier + torch.cuda.synchronize() on both sides
+(max over ranks); `value` is the median block.  Rank 0 prints ONE JSON line with `roofline` (SURVEY §8(d) byte model over hipEvent kernel
+time), `cpu_baseline` (the OpenMP GICP oracle on this host's cores) and `legs`: each half alone, both tracker pairs, the mapper iteration
+launched eagerly, and `dropin_reference_loop` — what the UNMODIFIED mp_Mapper.py executes on top of the drop-in rasteriser (torch
+activations, synchronous forward, torch l1/ssim, torch.optim.Adam).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,35 +32,69 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LRS = {"means3D": 1.6e-6 * 2.5, "shs": 2.5e-3, "opacities": 0.05, "scales": 5e-3, "rotations": 1e-3}   # REF arguments/__init__.py:141-148
+
+
+# ---- what unmodified mp_Mapper.py runs between render_3 and optimizer.step() [REF utils/loss_utils.py:17-69; mp_Mapper.py:225-240]
+def _torch_window(channel, device):
+    import torch
+    from math import exp
+    g = torch.tensor([exp(-(x - 11 // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)])
+    g = (g / g.sum()).unsqueeze(1)
+    return g.mm(g.t()).float().unsqueeze(0).unsqueeze(0).expand(channel, 1, 11, 11).contiguous().to(device)
+
+
+def _torch_l1(x, gt):
+    import torch
+    loss = torch.abs(x - gt)
+    return torch.where(gt != 0, loss, torch.zeros_like(loss)).mean()
+
+
+def _torch_ssim(img, gt, window):
+    import torch
+    import torch.nn.functional as F
+    img = torch.where(gt != 0, img, torch.zeros_like(img))
+    c = img.size(-3)
+    conv = lambda t: F.conv2d(t, window, padding=5, groups=c)   # noqa: E731
+    mu1, mu2 = conv(img), conv(gt)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1, s2, s12 = conv(img * img) - mu1_sq, conv(gt * gt) - mu2_sq, conv(img * gt) - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
     ap.add_argument("--gaussians", type=int, default=300_000)
     ap.add_argument("--res", choices=["replica", "tum"], default="replica")
+    ap.add_argument("--pair", choices=["survey", "basin"], default="survey",
+                    help="tracker pair of the headline step: SURVEY 8(d)'s pair verbatim, or the in-basin pair (the other one is timed as a leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (tracker-only, mapper-only, eager, drop-in reference loop)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--serial", action="store_true", help="run tracker and mapper back-to-back on one thread (default: concurrently, as the\n                    reference runs them in two processes)")
-    ap.add_argument("--no-graph", action="store_true", help="drive the mapper iteration eagerly from Python instead of replaying the captured\n                    HIP graph (N > 1 always runs eagerly)")
-    ap.add_argument("--only", choices=["tracker", "mapper"], default=None, help="diagnostics: run only one half of the step (the JSON line is then\n                    NOT the contract metric)")
-    ap.add_argument("--pyprofile", default=None, help="write a cProfile of the timed region to this file (diagnostics)")
+    ap.add_argument("--serial", action="store_true", help="run tracker and mapper back-to-back on one thread (default: concurrently)")
+    ap.add_argument("--no-graph", action="store_true", help="drive the mapper iteration eagerly from Python instead of replaying the captured HIP graph")
+    ap.add_argument("--only", choices=["tracker", "mapper"], default=None, help="diagnostics: run only one half (the JSON line is then NOT the contract metric)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from gs_icp_slam_amd import _lib, synth
+    from gs_icp_slam_amd.activations import activate
+    from gs_icp_slam_amd.loss import mapper_loss_and_grads
+    from gs_icp_slam_amd.optim import FusedAdam
     from gs_icp_slam_amd.sharded import ShardedGaussianRasterizer
-    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     import pygicp
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # GSICP_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (ranks then share devices;
-    # a functional check only — RCCL refuses two ranks on one device).  The driver's runs use the default: nccl (= RCCL), one GPU per rank.
+    # GSICP_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (functional check only).
     backend = os.environ.get("GSICP_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
@@ -71,17 +112,13 @@ def main():
     # ---------------- mapper inputs (S-map) ----------------
     cam = synth.make_camera(W, H, cfg["fx"], cfg["fy"], synth.DEFAULT_POSE_A)
     g = synth.s_map(P, seed=2)
-    # raw (pre-activation) parameters as GaussianModel keeps them [REF scene/gaussian_model.py:105-125]: log-scales, logit
-    # opacities, un-normalised quaternions; the activations below are the reference's torch ops and are part of the step
-    params = {"means3D": torch.from_numpy(g["means3D"]), "scales": torch.log(torch.from_numpy(g["scales"])),
-              "rotations": torch.from_numpy(g["rotations"]),
-              "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-4, 1 - 1e-4)), "shs": torch.from_numpy(g["shs"])}
-    params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in params.items()}
-    from gs_icp_slam_amd.loss import mapper_loss_and_grads
-    from gs_icp_slam_amd.optim import FusedAdam
-    lrs = {"means3D": 1.6e-6 * 2.5, "shs": 2.5e-3, "opacities": 0.05, "scales": 5e-3, "rotations": 1e-3}   # REF arguments/__init__.py:141-148
+    # raw (pre-activation) parameters as GaussianModel keeps them [REF scene/gaussian_model.py:105-125]
+    raw = {"means3D": torch.from_numpy(g["means3D"]), "scales": torch.log(torch.from_numpy(g["scales"])),
+           "rotations": torch.from_numpy(g["rotations"]),
+           "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-4, 1 - 1e-4)), "shs": torch.from_numpy(g["shs"])}
+    params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in raw.items()}
     use_graph = (world == 1) and not args.no_graph
-    optimizer = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in lrs.items()], lr=0.0, eps=1e-15, capturable=use_graph)
+    optimizer = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in LRS.items()], lr=0.0, eps=1e-15, capturable=use_graph)
     rs = GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev), scale_modifier=1.0,
         viewmatrix=torch.from_numpy(cam["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(cam["projmatrix"]).to(dev), sh_degree=0,
@@ -95,33 +132,44 @@ def main():
         gt_depth, gt_color = gt_depth.clone(), gt_color.clone()
         del t2
 
-    # ---------------- tracker inputs (S-pair) ----------------
-    sp = synth.s_pair(cfg, noise=(args.res == "tum"))
-    pw = sp["points_a"].astype(np.float64) @ sp["pose_a"][:3, :3].T + sp["pose_a"][:3, 3]
+    # ---------------- tracker inputs (S-pairs) ----------------
+    noise = args.res == "tum"
+    pairs = {"survey": synth.s_pair_survey(cfg, noise=noise), "basin": synth.s_pair(cfg, noise=noise)}
+    motions = {"survey": "room centre looking +z, 1 deg about y + 2 cm along x (SURVEY 8d verbatim)",
+               "basin": ("corner-facing, 0.2/0.3 deg about x/y + 8 mm x + 3 mm z (inside the 2 cm-gate convergence basin)" if cfg["max_corr"] < 0.025
+                         else "corner-facing, 1 deg about y + 2 cm along x")}
 
     def filt(n, tr):
         f = np.zeros(n, np.int32)
         f[tr] = np.arange(1, len(tr) + 1)
         return f
-    f_src = filt(len(sp["points_b"]), sp["trackable_b"])
 
-    def setup_tracker(reg):
-        reg.set_max_correspondence_distance(cfg["max_corr"])
-        reg.set_max_knn_distance(99999.0)
-        reg.set_input_target(pw)
-        reg.set_target_filter(len(sp["trackable_a"]), filt(len(pw), sp["trackable_a"]))
-        reg.calculate_target_covariance_with_filter()
+    class TrackerCase:
+        def __init__(self, name, reg):
+            self.name, self.reg, self.sp = name, reg, pairs[name]
+            sp = self.sp
+            self.pw = sp["points_a"].astype(np.float64) @ sp["pose_a"][:3, :3].T + sp["pose_a"][:3, 3]
+            self.f_src = filt(len(sp["points_b"]), sp["trackable_b"])
+            reg.set_max_correspondence_distance(cfg["max_corr"])
+            reg.set_max_knn_distance(99999.0)
+            reg.set_input_target(self.pw)
+            reg.set_target_filter(len(sp["trackable_a"]), filt(len(self.pw), sp["trackable_a"]))
+            reg.calculate_target_covariance_with_filter()
 
-    reg = pygicp.FastGICP()
-    setup_tracker(reg)
+        def step(self):
+            r, sp = self.reg, self.sp
+            r.set_input_source(sp["points_b"])
+            r.set_source_filter(len(sp["trackable_b"]), self.f_src)
+            T = r.align(sp["pose_a"])
+            idx, d2 = r.get_source_correspondence()
+            return T, idx, d2
 
-    def tracker_step(r):
-        r.set_input_source(sp["points_b"])
-        r.set_source_filter(len(sp["trackable_b"]), f_src)
-        T = r.align(sp["pose_a"])
-        idx, d2 = r.get_source_correspondence()
-        return T, idx, d2
+        def pose_error(self, T):
+            gt = self.sp["pose_b"]
+            dR = np.asarray(T, np.float64)[:3, :3] @ gt[:3, :3].T
+            return (float(np.degrees(np.linalg.norm(dR - np.eye(3)) / np.sqrt(2.0))), float(1e3 * np.linalg.norm(np.asarray(T, np.float64)[:3, 3] - gt[:3, 3])))
 
+    trk = TrackerCase(args.pair, pygicp.FastGICP())
     last = {}
 
     # The reference runs the tracker and the mapper as two concurrent processes on one GPU [REF gs_icp_slam.py:121-131].
@@ -135,25 +183,22 @@ def main():
         while True:
             if jobs.get() is None:
                 return
-            done.put(tracker_step(reg))
+            done.put(trk.step())
     worker = None
-    if not args.serial:
+    if not args.serial and args.only is None:
         worker = threading.Thread(target=tracker_worker, daemon=True)
         worker.start()
 
-    from gs_icp_slam_amd.activations import activate
+    def activated(p=params):   # GaussianModel.get_opacity / get_scaling / get_rotation [REF scene/gaussian_model.py:105-125], one fused launch
+        o, s_, q = activate(p["opacities"], p["scales"], p["rotations"])
+        return dict(means3D=p["means3D"], shs=p["shs"], opacities=o, scales=s_, rotations=q)
 
-    def activated():   # GaussianModel.get_opacity / get_scaling / get_rotation [REF scene/gaussian_model.py:105-125], one fused launch
-        o, s_, q = activate(params["opacities"], params["scales"], params["rotations"])
-        return dict(means3D=params["means3D"], shs=params["shs"], opacities=o, scales=s_, rotations=q)
-
-    def mapper_iteration():
-        """One iteration of Mapper.mapping [REF mp_Mapper.py:219-248]: render_3 -> loss -> backward -> Adam step -> zero_grad."""
+    def eager_iteration():
+        """One iteration of Mapper.mapping [REF mp_Mapper.py:219-248] with the fused operators, launched from Python."""
         a = activated()
         means2D = torch.zeros_like(a["means3D"], requires_grad=True)
         depth, color, radii, used = rast(means3D=a["means3D"], means2D=means2D, shs=a["shs"], opacities=a["opacities"],
                                          scales=a["scales"], rotations=a["rotations"])
-        # the fused loss hands dL/dimage and dL/ddepth straight to autograd (no loss node, no ones_like / multiply launches)
         parts, g_color, g_depth = mapper_loss_and_grads(color, depth, gt_color, gt_depth, lambda_dssim=0.2)
         torch.autograd.backward((color, depth), (g_color, g_depth))
         optimizer.step()
@@ -163,9 +208,8 @@ def main():
     # Duplicate-list capacity for the sync-free forward: 1.5x the count of one probe forward (per rank: each rank bins its own tiles).
     def probe_capacity():
         cap = max(8 * P // world, 1 << 20)
-        from gs_icp_slam_amd.rasterizer import GaussianRasterizer as _PlainRasterizer
         while True:   # plain rasteriser on this rank's tiles: no collective inside a loop whose trip count may differ between ranks
-            probe = _PlainRasterizer(rs._replace(capacity=cap, tile_mod=world, tile_rem=rank))
+            probe = GaussianRasterizer(rs._replace(capacity=cap, tile_mod=world, tile_rem=rank))
             with torch.no_grad():
                 a0 = activated()
                 probe(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"],
@@ -178,6 +222,7 @@ def main():
     rast = ShardedGaussianRasterizer(rs._replace(capacity=capacity))   # eager iterations also run without the forward's host sync
 
     mg = None
+    mapper_iteration = eager_iteration
     if use_graph:
         # Single GPU: the whole iteration is one hipGraph launch (gs_icp_slam_amd/graph.py); the keyframe (camera + targets) is
         # re-selected before every replay, as the reference's mapper does [REF mp_Mapper.py:205-217].
@@ -186,7 +231,6 @@ def main():
                                   lambda_dssim=0.2, warmup=2)
         mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_color, gt_depth)
         mg.capture()
-        eager_iteration = mapper_iteration
 
         def mapper_iteration():   # noqa: F811
             mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_color, gt_depth)
@@ -194,7 +238,7 @@ def main():
 
     def step():
         if args.only == "tracker":
-            T, idx, d2 = tracker_step(reg)
+            T, idx, d2 = trk.step()
             last.update(T=T)
             return
         if args.only == "mapper":
@@ -206,7 +250,7 @@ def main():
             loss, radii = mapper_iteration()
             T, idx, d2 = done.get()
         else:
-            T, idx, d2 = tracker_step(reg)
+            T, idx, d2 = trk.step()
             loss, radii = mapper_iteration()
         last.update(T=T, loss=loss, radii=radii)
 
@@ -215,147 +259,257 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_blocks(fn, steps, repeats):
+        out = []
+        for _ in range(repeats):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            out.append(dt)
+        return out
+
     for _ in range(args.warmup):
         step()
-    _lib.profile_enable(True)
-    _lib.profile_read()
-    barrier()
-    prof_py = None
-    if args.pyprofile:
-        import cProfile
-        prof_py = cProfile.Profile()
-        prof_py.enable()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if prof_py is not None:
-        prof_py.disable()
-        import pstats
-        with open(args.pyprofile, "w") as fh:
-            pstats.Stats(prof_py, stream=fh).sort_stats("cumulative").print_stats(45)
-    prof = _lib.profile_read()
-    n_prof = {k: args.steps for k in prof}
+    blocks = timed_blocks(step, args.steps, max(1, args.repeats))
+    dt = statistics.median(blocks)
+    if mg is not None and mg.overflowed():
+        raise RuntimeError(f"duplicate-list capacity overflowed during the timed region: R = {int(mg.num_rendered.item())} > {mg.capacity}")
     if mg is None and int(rast.inner.num_rendered.item()) > capacity:
         raise RuntimeError("duplicate-list capacity overflowed during the timed region")
-    if mg is not None:
-        # kernels inside a replayed graph carry no HIP events: time the SAME kernels on the same inputs in eager iterations
-        # right after the timed region (rocprofv3's kernel trace of this command sees both and agrees — profiles/README.md)
-        if mg.overflowed():
-            raise RuntimeError(f"duplicate-list capacity overflowed during the timed region: R = {int(mg.num_rendered.item())} > {mg.capacity}")
-        n_e = max(5, min(args.steps, 20))
+    align_stats = trk.reg.last_align_stats() if args.only != "mapper" else {}
+
+    # ---------------- per-kernel hipEvent times ----------------
+    # kernels inside a replayed graph carry no HIP events: the SAME kernels on the same inputs are timed in eager iterations right after the
+    # timed region, the tracker stages in tracker-only frames (rocprofv3's kernel trace of this command sees all of them and must agree —
+    # profiles/README.md)
+    _lib.profile_enable(True)
+    _lib.profile_read()
+    n_e = 20
+    per_launch_us = {}
+    if args.only != "tracker":
         eager_iteration()
         torch.cuda.synchronize()
         _lib.profile_read()
         for _ in range(n_e):
             eager_iteration()
         torch.cuda.synchronize()
-        for k, v in _lib.profile_read().items():
-            if v[1] > 0 and not k.startswith("gicp"):
-                prof[k] = v
-                n_prof[k] = n_e
+        per_launch_us.update({k: 1e3 * ms / n_e for k, (ms, c) in _lib.profile_read().items() if c > 0 and not k.startswith("gicp")})
+    if args.only != "mapper":
+        for _ in range(3):
+            trk.step()
+        _lib.profile_read()
+        for _ in range(n_e):
+            trk.step()
+        per_launch_us.update({k: 1e3 * ms / n_e for k, (ms, c) in _lib.profile_read().items() if c > 0 and k.startswith("gicp")})
     _lib.profile_enable(False)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
 
-    # ---------------- roofline of the dominant kernel ----------------
-    per_launch_us = {k: (1e3 * ms / n_prof[k]) for k, (ms, c) in prof.items() if c > 0}   # us per step (a stage may be several launches)
-    raster_stages = ["preprocess", "tile_scan_lpt", "scatter", "tile_sort", "blend_forward", "blend_backward", "entry_grad_sum",
-                     "preprocess_backward"]
-    dominant = max((k for k in raster_stages if k in per_launch_us), key=lambda k: per_launch_us[k])
-    # D (duplicates) and P_vis from one extra forward
+    # ---------------- D (duplicates), P_vis ----------------
     a_ = activated()
-    means2D = torch.zeros_like(a_["means3D"], requires_grad=True)
-    depth, color, radii, used = rast(means3D=a_["means3D"], means2D=means2D, shs=a_["shs"], opacities=a_["opacities"],
-                                     scales=a_["scales"], rotations=a_["rotations"])
+    with torch.no_grad():
+        _, _, radii, _ = rast(means3D=a_["means3D"], means2D=torch.zeros_like(a_["means3D"]), shs=a_["shs"], opacities=a_["opacities"],
+                              scales=a_["scales"], rotations=a_["rotations"])
     D_local = int(rast.inner.num_rendered.item())
     P_vis = int((radii > 0).sum())
     T_tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    # Algorithmic bytes per launch: list word 4 B per (strip, entry) visit = 16 B per duplicate,
-    # 48 B record per duplicate (an upper bound: only staged records are gathered), per-pixel state, gradient slots.
-    alg_bytes = {"blend_forward": 64.0 * D_local + 24.0 * W * H / world + 8.0 * T_tiles / world,
-                 "blend_backward": 64.0 * D_local + 40.0 * W * H / world + 48.0 * D_local,
-                 "preprocess": 128.0 * P, "preprocess_backward": 184.0 * P + 48.0 * D_local, "tile_sort": 24.0 * D_local,
-                 "scatter": 16.0 * D_local + 56.0 * P_vis, "tile_scan_lpt": 16.0 * T_tiles, "entry_grad_sum": 240.0 * D_local}
-    ach = alg_bytes[dominant] / (per_launch_us[dominant] * 1e-6) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # FETCH_SIZE / WRITE_SIZE passes of this command (profiles/README.md)
-    if os.path.exists(tpath) and world == 1 and args.res == "replica" and P == 300_000:
-        tj = json.load(open(tpath)).get(dominant)
-        if tj:
-            traffic = int(tj["fetch_bytes"] + tj["write_bytes"])
-    # the blend kernels gather 48-byte records that sit in the 256 MiB Infinity Cache: they are instruction-issue bound, not HBM bound.
-    # When the SQ counter pass of this command is on disk (profiles/), state the VALU-issue floor next to the HBM fraction.
-    note = "working set (~60 MB) sits in the 256 MiB Infinity Cache; the kernel is VALU-issue bound, the HBM fraction is a formality"
-    kernel_of = {"blend_backward": "blend_backward_strip_kernel", "blend_forward": "blend_forward_strip_kernel"}
-    sqpath = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_sq.csv")
-    if os.path.exists(sqpath) and dominant in kernel_of and world == 1 and args.res == "replica" and P == 300_000:
-        import csv
-        for row in csv.DictReader(open(sqpath)):
-            if row["kernel"] == kernel_of[dominant] and float(row.get("SQ_INSTS_VALU", 0) or 0) > 0:
-                valu = float(row["SQ_INSTS_VALU"])
-                floor_us = valu * 4.0 / 1024.0 / 2.4e3      # wave64 VALU op = 4 cycles on a 16-lane SIMD; 1024 SIMDs; 2.4 GHz
-                note += (f"; SQ_INSTS_VALU = {valu / 1e6:.1f} M wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz = {floor_us:.0f} us "
-                         f"issue floor vs kernel_us (profiles/r01_rocprofv3_pmc_sq.csv)")
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "kernel_us": round(per_launch_us[dominant], 2),
-                "algorithmic_bytes": int(alg_bytes[dominant]), "note": note}
+
+    # ---------------- roofline: SURVEY 8(d) byte model ----------------
+    roofline = None
+    if args.only != "tracker":
+        n_pass = 6
+        WHr, Tr = W * H / world, T_tiles / world
+        b_r7 = 44.0 * D_local + 40.0 * WHr + 44.0 * P_vis                       # blend backward (R7)
+        b_bwd = b_r7 + 184.0 * P                                                # + R8/R9
+        b_fwd = 128.0 * P + D_local * (64.0 + 24.0 * n_pass) + 24.0 * WHr + 8.0 * Tr
+        fwd_stages = ["preprocess", "tile_scan_lpt", "emit_split", "tile_sort", "blend_forward"]
+        bwd_stages = ["blend_backward", "entry_grad_sum", "preprocess_backward"]
+        us_r7 = per_launch_us.get("blend_backward", float("nan"))
+        us_bwd = sum(per_launch_us.get(k, 0.0) for k in bwd_stages)
+        us_fwd = sum(per_launch_us.get(k, 0.0) for k in fwd_stages)
+        gbs = lambda b, us: b / (us * 1e-6) / 1e9   # noqa: E731
+        ach = gbs(b_r7, us_r7)
+        # design byte count of the kernel as built: 4 strip waves each read the list word (16 B / duplicate), staged
+        # 48-byte records, per-pixel state, 48-byte gradient slot writes per (entry, strip)
+        design_bytes = 64.0 * D_local + 40.0 * WHr + 48.0 * D_local
+        traffic, traffic_src, note = None, None, ("working set (~60 MB) sits in the 256 MiB Infinity Cache; the kernel is VALU-issue bound, "
+                                                  "the HBM fraction is a formality")
+        if world == 1 and args.res == "replica" and P == 300_000:
+            for tag in ("r02", "r01"):   # PMC passes of this command, collected by tools/capture_profiles.sh (counters cannot be read in-process)
+                tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+                if os.path.exists(tp):
+                    tj = json.load(open(tp)).get("blend_backward")
+                    if tj:
+                        traffic, traffic_src = int(tj["fetch_bytes"] + tj["write_bytes"]), f"profiles/{tag}_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command; not re-measured in this run)"
+                    sq = os.path.join(ROOT, "profiles", f"{tag}_rocprofv3_pmc_sq.csv")
+                    if os.path.exists(sq):
+                        import csv
+                        for row in csv.DictReader(open(sq)):
+                            if row["kernel"].startswith("blend_backward") and float(row.get("SQ_INSTS_VALU", 0) or 0) > 0:
+                                valu = float(row["SQ_INSTS_VALU"])
+                                note += (f"; SQ_INSTS_VALU = {valu / 1e6:.1f} M wave-instructions x 4 cycles / 1024 SIMDs / 2.4 GHz = "
+                                         f"{valu * 4.0 / 1024.0 / 2.4e3:.0f} us issue floor ({os.path.basename(sq)})")
+                                break
+                    break
+        roofline = {"bound": "hbm", "kernel": "blend_backward_strip_kernel (R7)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "kernel_us": round(us_r7, 2),
+                    "algorithmic_bytes": int(b_r7), "byte_model": "SURVEY 8(d): 44 D + 40 W H + 44 P_vis",
+                    "design_bytes": int(design_bytes), "design_frac": round(gbs(design_bytes, us_r7) / HBM_PEAK_GBS, 5),
+                    "whole_backward": {"algorithmic_bytes": int(b_bwd), "us": round(us_bwd, 2), "frac": round(gbs(b_bwd, us_bwd) / HBM_PEAK_GBS, 5),
+                                       "byte_model": "44 D + 40 W H + 44 P_vis + 184 P", "kernels": bwd_stages},
+                    "whole_forward": {"algorithmic_bytes": int(b_fwd), "us": round(us_fwd, 2), "frac": round(gbs(b_fwd, us_fwd) / HBM_PEAK_GBS, 5),
+                                      "byte_model": "128 P + D (64 + 24 x 6) + 24 W H + 8 T", "kernels": fwd_stages},
+                    "note": note}
+
+    # ---------------- legs (rank 0, single GPU) ----------------
+    legs = None
+    if rank == 0 and world == 1 and not args.no_legs and args.only is None:
+        legs = {}
+        reps = max(3, args.repeats)
+
+        def rate(fn, n, warm=3):
+            for _ in range(warm):
+                fn()
+            ts = timed_blocks(fn, n, reps)
+            return statistics.median(ts) / n
+
+        # -- tracker alone, both pairs
+        cases = {args.pair: trk}
+        other = "basin" if args.pair == "survey" else "survey"
+        cases[other] = TrackerCase(other, pygicp.FastGICP())
+        for name, case in cases.items():
+            s_frame = rate(case.step, 100)
+            T, idx, d2 = case.step()
+            st = case.reg.last_align_stats()
+            _lib.profile_enable(True)
+            _lib.profile_read()
+            for _ in range(20):
+                case.step()
+            pr = {k: round(1e3 * ms / 20, 2) for k, (ms, c) in _lib.profile_read().items() if c > 0 and k.startswith("gicp")}
+            _lib.profile_enable(False)
+            ang, mm = case.pose_error(T)
+            legs[f"tracker_only_{name}"] = {"frames_per_s": round(1.0 / s_frame, 1), "ms_per_frame": round(1e3 * s_frame, 4), "motion": motions[name],
+                                            "lm_iterations": st["iterations"], "converged": st["converged"], "stage_us": pr,
+                                            "pose_error_deg_mm": [round(ang, 4), round(mm, 3)], "correspondence_ratio": round(float((idx >= 0).mean()), 3)}
+        # -- mapper alone: graph replay, eager fused
+        s_it = rate(lambda: mapper_iteration(), 100)
+        legs["mapper_only"] = {"iterations_per_s": round(1.0 / s_it, 1), "ms_per_iteration": round(1e3 * s_it, 4),
+                               "launch": "one hipGraph replay per iteration" if mg is not None else "eager"}
+        if mg is not None:   # the same fused operators launched eagerly from Python (what N > 1 runs today)
+            opt_e = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in LRS.items()], lr=0.0, eps=1e-15)
+            optimizer_ref = [opt_e]
+
+            def eager_fused():
+                a = activated()
+                means2D = torch.zeros_like(a["means3D"], requires_grad=True)
+                depth, color, radii, used = rast(means3D=a["means3D"], means2D=means2D, shs=a["shs"], opacities=a["opacities"],
+                                                 scales=a["scales"], rotations=a["rotations"])
+                parts, g_color, g_depth = mapper_loss_and_grads(color, depth, gt_color, gt_depth, lambda_dssim=0.2)
+                torch.autograd.backward((color, depth), (g_color, g_depth))
+                optimizer_ref[0].step()
+                optimizer_ref[0].zero_grad(set_to_none=True)
+            s_e = rate(eager_fused, 50)
+            legs["mapper_eager_fused"] = {"iterations_per_s": round(1.0 / s_e, 1), "ms_per_iteration": round(1e3 * s_e, 4)}
+        # -- what UNMODIFIED mp_Mapper.py:219-248 executes on the drop-in rasteriser: torch activations [REF scene/gaussian_model.py:105-125],
+        #    GaussianRasterizer's reference-compatible synchronous forward, torch l1 / ssim, loss.backward(), torch.optim.Adam, zero_grad
+        rp = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in raw.items()}
+        topt = torch.optim.Adam([{"params": [rp[k]], "lr": lr, "name": k} for k, lr in LRS.items()], lr=0.0, eps=1e-15)
+        window = _torch_window(3, dev)
+        plain = GaussianRasterizer(rs)
+
+        def reference_loop():
+            means2D = torch.zeros_like(rp["means3D"], requires_grad=True) + 0
+            depth, image, radii, used = plain(means3D=rp["means3D"], means2D=means2D, shs=rp["shs"], opacities=torch.sigmoid(rp["opacities"]),
+                                              scales=torch.exp(rp["scales"]), rotations=torch.nn.functional.normalize(rp["rotations"]))
+            mask = (gt_depth > 0.).detach()
+            gt_im = gt_color * mask
+            Ll1 = _torch_l1(image, gt_im)
+            Ls = _torch_ssim(image, gt_im, window)
+            Ld = _torch_l1(depth / 10.0, gt_depth / 10.0)
+            loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - Ls) + 0.1 * Ld
+            loss.backward()
+            with torch.no_grad():
+                topt.step()
+                topt.zero_grad(set_to_none=True)
+        s_r = rate(reference_loop, 30)
+        legs["dropin_reference_loop"] = {"iterations_per_s": round(1.0 / s_r, 1), "ms_per_iteration": round(1e3 * s_r, 4),
+                                         "what": "torch activations + synchronous GaussianRasterizer + torch l1/ssim + loss.backward() + torch.optim.Adam "
+                                                 "(the statements of unmodified mp_Mapper.py:219-248)"}
+        del rp, topt
 
     # ---------------- CPU baseline: OpenMP GICP oracle (port), rank 0 only ----------------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and args.only != "mapper":
         import oracle
-        oreg = oracle.OracleGICP()
-        setup_tracker(oreg)
-        tracker_step(oreg)  # warm-up (thread pool, first touch)
+        oc = TrackerCase(args.pair, oracle.OracleGICP())
+        oc.step()  # warm-up (thread pool, first touch)
         # the problem is small (8 k points): more OpenMP threads than it can feed only add overhead, so pick the
         # fastest thread count on this host first and report THAT as the baseline
         ncpu = os.cpu_count() or 1
         best_thr, best_rate = ncpu, 0.0
         for thr in sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu}):
-            oreg.set_num_threads(thr)
-            tracker_step(oreg)
+            oc.reg.set_num_threads(thr)
+            oc.step()
             n, t0c = 0, time.perf_counter()
             while time.perf_counter() - t0c < 0.6:
-                tracker_step(oreg)
+                oc.step()
                 n += 1
-            rate = n / (time.perf_counter() - t0c)
-            if rate > best_rate:
-                best_thr, best_rate = thr, rate
-        oreg.set_num_threads(best_thr)
+            r_ = n / (time.perf_counter() - t0c)
+            if r_ > best_rate:
+                best_thr, best_rate = thr, r_
+        oc.reg.set_num_threads(best_thr)
         n, t_cpu0 = 0, time.perf_counter()
         while time.perf_counter() - t_cpu0 < args.cpu_seconds:
-            To, _, _ = tracker_step(oreg)
+            To, _, _ = oc.step()
             n += 1
         t_cpu = time.perf_counter() - t_cpu0
         cpu = {"value": round(n / t_cpu, 2), "unit": "tracker frames/s (GICP align only; the reference has no CPU rasteriser)",
                "cores": best_thr, "host_cores": ncpu, "kind": "port",
-               "sample": f"{n} x (set_input_source + align + get_source_correspondence) on S-pair {args.res}, {len(sp['points_b'])} points, "
-                         f"{t_cpu:.1f} s wall, OpenMP kd-tree oracle at its fastest thread count",
-               "pose_agrees_with_gpu": bool(np.allclose(To, last["T"], atol=1e-5))}
+               "sample": f"{n} x (set_input_source + align + get_source_correspondence) on the {args.pair} S-pair {args.res}, {len(trk.sp['points_b'])} points, "
+                         f"{oc.reg.iterations} LM iterations, {t_cpu:.1f} s wall, OpenMP kd-tree oracle at its fastest thread count",
+               "pose_agrees_with_gpu": bool(np.allclose(To, last["T"], atol=1e-5)) if "T" in last else None}
+
+    # ---------------- multi-GPU bookkeeping ----------------
+    ranks_seen = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        mine = f"rank {rank}: cuda:{dev_index} {props.name} uuid={getattr(props, 'uuid', '?')}"
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_seen = gathered
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
         stage_us = {k: round(v, 2) for k, v in per_launch_us.items()}
+        it = align_stats.get("iterations")
+        ang_mm = trk.pose_error(last["T"]) if "T" in last else (None, None)
         out = {
             "metric": ("SLAM hot-path FPS (GICP tracker frame + one full mapper iteration: render, loss, backward, Adam), Replica room0-shaped synthetic"
                        if args.only is None else f"DIAGNOSTIC: {args.only} half only"),
             "value": round(args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2] shape: S-pair {args.res} tracker ({len(sp['points_b'])} pts, gate {cfg['max_corr']} m) + "
-                                   f"S-map mapper iteration (P={P}, {W}x{H}, sh_degree 0)", "gaussians": P, "width": W, "height": H,
-                       "duplicates_per_rank": D_local, "visible_gaussians": P_vis,
-                       "tracker_mapper_overlap": not args.serial,
+            "repeats": len(blocks), "block_ms_per_step": [round(1e3 * b / args.steps, 4) for b in blocks], "statistic": "median block",
+            "config": {"workload": f"BASELINE configs[2] shape: tracker frame on the {args.pair} S-pair {args.res} [{motions[args.pair]}; {len(trk.sp['points_b'])} pts, "
+                                   f"gate {cfg['max_corr']} m, {it} LM iterations, lands {ang_mm[0]:.3f} deg / {ang_mm[1]:.1f} mm from the true motion] concurrent with one "
+                                   f"S-map mapper iteration (P={P}, {W}x{H}, sh_degree 0, depth = sum z alpha T, fromqs scale^2)" if "T" in last else f"{args.only} only",
+                       "tracker_pair": args.pair, "tracker_motion": motions[args.pair], "lm_iterations": it,
+                       "gaussians": P, "width": W, "height": H, "duplicates_per_rank": D_local, "visible_gaussians": P_vis,
+                       "tracker_mapper_overlap": worker is not None,
                        "mapper_iteration": "one hipGraph replay per iteration" if mg is not None else "eager launches from Python",
-                       "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-reduce image + grads), tracker replicated"},
-            "render_bwd_ms_per_iter": round(sum(per_launch_us.get(k, 0.0) for k in raster_stages) / 1e3, 4),
+                       "variants": {"depth_mode": "sum z alpha T (un-normalised)", "fromqs_scale_mode": "s^2", "regularization": "PLANE"},
+                       "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-reduce image + grads), tracker replicated",
+                       "world_size": world, "backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen},
+            "render_bwd_ms_per_iter": round(sum(per_launch_us.get(k, 0.0) for k in ["preprocess", "tile_scan_lpt", "emit_split", "tile_sort", "blend_forward",
+                                                                                   "blend_backward", "entry_grad_sum", "preprocess_backward"]) / 1e3, 4),
             "tracker_align_kernel_us": stage_us.get("gicp_align"),
             "stage_us_per_step": stage_us,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "legs": legs, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if worker is not None:

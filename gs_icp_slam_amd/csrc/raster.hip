@@ -46,7 +46,10 @@ std::vector<ProfRec> g_prof_log;
 std::vector<hipEvent_t> g_prof_pool;
 hipEvent_t g_prof_open[ST_COUNT];
 std::atomic<int> g_prof_enabled{0};
-const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "scatter", "tile_sort", "blend_forward",
+// stage -> kernels: preprocess = preprocess_kernel; tile_scan_lpt = tile_scan_lpt_kernel; emit_split = emit_kernel + split_hist_kernel +
+// split_colscan_kernel + split_scatter_kernel; tile_sort = both tile_sort_kernel size classes; blend_* = the strip kernels;
+// entry_grad_sum = entry_sum_kernel; preprocess_backward = preprocess_backward_kernel
+const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "emit_split", "tile_sort", "blend_forward",
                                              "blend_backward", "entry_grad_sum", "preprocess_backward", "gicp_knn_cov", "gicp_grid_build",
                                              "gicp_align", "gicp_exact_nn"};
 hipEvent_t prof_event() {

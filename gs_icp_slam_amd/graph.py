@@ -130,6 +130,7 @@ class MapperIterationGraph:
         for p in self.params.values():
             st = self.optimizer.state.get(p, {})
             snap_s[p] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+        skipped0 = None if self.optimizer.skipped_steps is None else self.optimizer.skipped_steps.clone()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):          # eager warm-up on a side stream
@@ -154,6 +155,8 @@ class MapperIterationGraph:
                         val.copy_(old)
                     else:                         # state was created by the warm-up: its pre-warm-up value is zero
                         val.zero_()
+            if skipped0 is not None:
+                self.optimizer.skipped_steps.copy_(skipped0)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
