@@ -5,22 +5,23 @@
 // from [REF gaussian_renderer/__init__.py:294-302] and [REF mp_Mapper.py:242].
 //
 // MI355X-first design notes (details and measurements: DESIGN.md):
-//  * Binning is "count, scatter, sort locally", five launches in total, instead of a global radix sort of all
-//    (tile, depth) duplicates (the classic implementation: ~25 small launches through a sort library, each a
-//    dependent kernel boundary of 5-10 us on this chip).  preprocess counts the duplicates of every tile with
-//    integer atomics and hands each Gaussian a private run of "emission slots"; one single-workgroup kernel turns
-//    the tile counts into list ranges and an LPT dispatch order; the scatter kernel drops every duplicate anywhere
-//    inside its tile's range (atomic cursor); one workgroup per tile then bitonic-sorts its list in LDS by
-//    (depth bits, Gaussian id).  The (depth, id) order is total, so the lists are exactly those of a stable
-//    (tile << 32 | depth) sort of duplicates emitted in id order — the parity tests compare them bit-for-bit.
+//  * Binning is "emit, multi-split, sort locally" instead of a global radix sort of all (tile, depth) duplicates (the
+//    classic implementation: ~25 small launches through a sort library, each a dependent kernel boundary of 5-10 us on
+//    this chip).  preprocess hands each Gaussian a private run of "emission slots" (block scan + one atomic per
+//    workgroup); emit_kernel fills them; a three-kernel multi-split groups them by tile through per-workgroup LDS
+//    histograms over all tiles (no global atomics, no cursor); one single-workgroup kernel turns the tile counts into
+//    list ranges and an LPT dispatch order; one workgroup per tile then bitonic-sorts its list in LDS by (depth bits,
+//    Gaussian id).  The (depth, id) order is total, so the lists are exactly those of a stable (tile << 32 | depth)
+//    sort of duplicates emitted in id order — the parity tests compare them bit-for-bit.
 //  * Blend kernels: one wave64 per (tile, 16x4 strip).  Binning tags every list entry with 4 strip bits (which
 //    strips the splat's alpha >= 1/255 footprint can reach); a wave compacts its 64-entry batches by its bit and
 //    stages only the surviving 48-byte records in LDS — no workgroup barriers, and culled entries cost 1/64 of a
 //    vector instruction.  Work items are dispatched longest list first (LPT).
-//  * Backward: every lane of a wave walks the same splat at the same step, so the 10 partial gradients are reduced
-//    across the 64 lanes with 16 permlane-swap folds + 12 DPP adds and stored into a private slot per (emission slot, strip);
-//    a streaming pass adds the strips and each Gaussian sums its own contiguous run.  No float atomics anywhere:
-//    device-scope atomics resolve at the memory side on this 8-XCD part, and gradients stay bit-reproducible.
+//  * Backward: every lane of a wave walks the same splat at the same step, so the 10 partial sums are reduced across the
+//    64 lanes with 16 permlane-swap folds + 7 bank-masked DPP adds; the four strip waves of a tile meet once per 64-entry
+//    batch and write ONE 48-byte record per (tile, entry); each Gaussian then sums its own contiguous run of records.
+//    No float atomics anywhere: device-scope atomics resolve at the memory side on this 8-XCD part, and gradients stay
+//    bit-reproducible.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +49,8 @@ hipEvent_t g_prof_open[ST_COUNT];
 std::atomic<int> g_prof_enabled{0};
 // stage -> kernels: preprocess = preprocess_kernel; tile_scan_lpt = tile_scan_lpt_kernel; emit_split = emit_kernel + split_hist_kernel +
 // split_colscan_kernel + split_scatter_kernel; tile_sort = both tile_sort_kernel size classes; blend_* = the strip kernels;
-// entry_grad_sum = entry_sum_kernel; preprocess_backward = preprocess_backward_kernel
+// blend_backward = blend_backward_tile_kernel; entry_grad_sum = (retired: the tile kernel writes entry records itself);
+// preprocess_backward = preprocess_backward_kernel
 const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "emit_split", "tile_sort", "blend_forward",
                                              "blend_backward", "entry_grad_sum", "preprocess_backward", "gicp_knn_cov", "gicp_grid_build",
                                              "gicp_align", "gicp_exact_nn"};
@@ -341,7 +343,7 @@ struct BlendArgs {
     // backward only
     const float* dL_dpix;
     const float* dL_ddepth;
-    float* slots;        // (R, 4, SLOT_F) per-(emission slot, strip) gradient sums
+    float* entry_sum;    // (R, SLOT_F) per-emission-slot gradient moment sums (see blend_backward_tile_kernel)
 };
 
 // ================================================================================================================
@@ -441,14 +443,8 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
     }
 }
 
-// Ten partial sums per lane -> ten wave totals.  (The first version was 60 hand-scheduled v_add_f32_dpp — 6 per value —
-// because hipcc's own lowering of the reduction took ~110 instructions; the permlane-swap folding below needs 28.)
-// gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves /
-// odd-even rows of TWO registers in one instruction, so two values can be folded into one register per level ("A keeps its
-// lower half and receives B's lower half; B keeps its upper halves"): 10 -> 5 registers across the 32-lane halves, 5 (+ a zero)
-// -> 3 across the row pairs, and only those 3 registers go through the 4 in-row DPP steps.  Row k (lanes 16k..16k+15) of
-//   q0 ends up holding value {0, 2, 1, 3}[k], of q1 value {4, 6, 5, 7}[k], of q2 value {8, -, 9, -}[k],
-// with the row total in the row's last lane (15, 31, 47, 63).  Every lane must be active.
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows of TWO registers in one instruction, so two
+// values can be folded into one register per level ("A keeps its lower half and receives B's lower half; B keeps its upper halves").
 typedef unsigned gs_uint2 __attribute__((ext_vector_type(2)));
 __device__ inline float swap32_add(float a, float b) {
     const gs_uint2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -458,31 +454,54 @@ __device__ inline float swap16_add(float a, float b) {
     const gs_uint2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
-#define GS_DPP3(CTRL)                                                                                                   \
-    asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL \
-                 : "+v"(q0), "+v"(q1), "+v"(q2))
-__device__ inline void wave_sum10_rows(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8, float v9,
-                                       float& q0, float& q1, float& q2) {
+
+// ================================================================================================================
+// Backward, tile workgroups (default).  One 256-thread workgroup per tile; wave s owns strip s exactly as in the forward (own
+// compaction by strip bit, own slab, own pixel state), but the four waves meet once per 64-entry batch so that every (tile, entry)
+// gradient record is written ONCE:
+//   * each wave reduces its ten partial gradients per staged entry across the 64 lanes and parks them in LDS at the entry's position
+//     inside the batch (s_part[wave][position]); a 64-bit mask per wave says which positions it wrote;
+//   * after one workgroup barrier, 192 threads add the (up to four) strip records of each batch position in strip order and store the
+//     48-byte entry record straight into entry_sum[emission slot] — the array the per-Gaussian pass (preprocess_backward) streams.
+// Against the per-(entry, strip) slot scheme this removes the slot buffer (240 B per duplicate), the entry_sum kernel that re-read it,
+// and ~60 % of the gradient write traffic; results stay bit-reproducible (fixed reduction tree, fixed strip order, no atomics).
+// The per-entry body is branch-free: an entry a pixel does not blend enters with alpha = 0, which makes T, the behind-colour A and all
+// ten gradient terms no-ops by arithmetic (T * rcp(1) = T, 0 * c + 1 * A = A, w = 0) instead of by exec masking + zero fills, and the
+// behind-colour recurrence is applied eagerly (A <- alpha c + (1 - alpha) A after the entry) rather than lazily before the next one.
+// ================================================================================================================
+// Ten lane-partials -> ten wave totals in ONE register: two permlane-swap levels fold ten registers into three (10 -> 5 across the
+// 32-lane halves, 5 (+ a zero) -> 3 across the row pairs; row k of q0 then holds value {0,2,1,3}[k], of q1 {4,6,5,7}[k], of q2 {8,-,9,-}[k]);
+// the three registers
+// are folded across the 16 lanes of a row with bank-masked DPP adds (two registers into one per level: banks 2,3 take one source's
+// shr:8 fold, banks 0,1 the other's shl:8 fold), so that the quad reduction runs on a single register: 7 DPP adds instead of 12.
+// Result: lanes with (lane & 3) == 0 of bank b in row k hold  b=2: value {0,2,1,3}[k];  b=0: value {4,6,5,7}[k];  b=3: {8,-,9,-}[k].
+__device__ inline float wave_sum10_banked(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8, float v9) {
     const float p0 = swap32_add(v0, v1), p1 = swap32_add(v2, v3), p2 = swap32_add(v4, v5), p3 = swap32_add(v6, v7), p4 = swap32_add(v8, v9);
-    q0 = swap16_add(p0, p1);
-    q1 = swap16_add(p2, p3);
-    q2 = swap16_add(p4, 0.f);
-    asm volatile("s_nop 1" : "+v"(q0), "+v"(q1), "+v"(q2));   // DPP reads of registers the VALU has just written need two wait states
-    GS_DPP3("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
-    GS_DPP3("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
-    GS_DPP3("row_shr:4 row_mask:0xf bank_mask:0xf");
-    GS_DPP3("row_shr:8 row_mask:0xf bank_mask:0xf");
+    float q0 = swap16_add(p0, p1), q1 = swap16_add(p2, p3), q2 = swap16_add(p4, 0.f);
+    float r, r2, t;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %2, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(r), "=&v"(r2), "=&v"(t)
+        : "v"(q0), "v"(q1), "v"(q2));
+    return t;
 }
 
-__global__ __launch_bounds__(64) void blend_backward_strip_kernel(BlendArgs a) {
-    // one 64-thread workgroup per (tile, strip), dispatched longest tile first: the hardware hands workgroups to CUs
-    // in index order, so sorting by list length is LPT scheduling and the kernel no longer ends on a few stragglers
-    const int tl = (int)(blockIdx.x >> 2);
+__global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
+    const int tl = (int)blockIdx.x;            // tiles are dispatched longest list first (LPT), see the forward
     if (tl >= a.n_tiles_local) return;
-    const int wave = (int)(blockIdx.x & 3);
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int tile = (int)a.order[tl];
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int lane = threadIdx.x;
     const int px = tx * TILE + (lane & 15), py = ty * TILE + wave * 4 + (lane >> 4);
     const bool inside = px < a.W && py < a.H;
     const float pfx = (float)px, pfy = (float)py;
@@ -491,10 +510,11 @@ __global__ __launch_bounds__(64) void blend_backward_strip_kernel(BlendArgs a) {
     const size_t HW = (size_t)a.W * a.H;
     const size_t pix = (size_t)py * a.W + px;
 
-    __shared__ SplatRec s_rec[SLAB];
-    __shared__ int s_pos[SLAB];
-    __shared__ uint32_t s_u[SLAB];
-    __shared__ float s_sum[SLAB][NGRAD + 1];
+    __shared__ SplatRec s_rec[4][SLAB];
+    __shared__ int s_pos[4][SLAB];
+    __shared__ __attribute__((aligned(16))) float s_part[4][SLAB][SLOT_F];
+    __shared__ uint32_t s_e[SLAB];
+    __shared__ unsigned long long s_wrote[4];
 
     const float T_final = inside ? a.final_T[pix] : 0.f;
     float T = T_final;
@@ -504,19 +524,16 @@ __global__ __launch_bounds__(64) void blend_backward_strip_kernel(BlendArgs a) {
         dp0 = a.dL_dpix[pix]; dp1 = a.dL_dpix[HW + pix]; dp2 = a.dL_dpix[2 * HW + pix];
         dpd = a.dL_ddepth ? a.dL_ddepth[pix] : 0.f;
     }
-    const float bg_dot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
-    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lcd = 0.f, last_alpha = 0.f;
-    const float ddelx_dx = 0.5f * (float)a.W, ddely_dy = 0.5f * (float)a.H;
+    const float bgT = -T_final * (a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2);
+    float A0 = 0.f, A1 = 0.f, A2 = 0.f, Ad = 0.f;     // colour / depth composited BEHIND the current entry
 
-    // where this lane's row totals of wave_sum10_rows belong in an s_sum record (only lanes 15, 31, 47, 63 store)
-    const int srow = lane >> 4;
-    const int si0 = srow == 0 ? 0 : (srow == 1 ? 2 : (srow == 2 ? 1 : 3));
-    const int si1 = 4 + si0;
-    const int si2 = srow == 0 ? 8 : (srow == 2 ? 9 : 10);   // index 10 is the record's padding word
-    const bool row_last = (lane & 15) == 15;
+    // where this lane's value of wave_sum10_banked belongs in a 12-float record (lanes with (lane & 3) == 0 of banks 0, 2, 3 store)
+    const int srow = lane >> 4, sbank = (lane >> 2) & 3;
+    const int perm = srow == 0 ? 0 : (srow == 1 ? 2 : (srow == 2 ? 1 : 3));
+    const int st_idx = sbank == 2 ? perm : (sbank == 0 ? 4 + perm : 8 + perm);      // 8 + {0,2,1,3}: 10, 11 are the record's padding words
+    const bool st_lane = (lane & 3) == 0 && sbank != 1;
 
-    // entries at positions >= the strip's largest n_contrib reach no pixel of this strip: their slots only get zeros
+    // entries at positions >= the strip's largest n_contrib reach no pixel of this strip
     int top0 = last_contributor;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -525,108 +542,81 @@ __global__ __launch_bounds__(64) void blend_backward_strip_kernel(BlendArgs a) {
     }
     const int total = (int)(range.y - range.x);
     for (int top = total; top > 0; top -= 64) {   // entries [top-64, top) back-to-front; lane 0 holds the last one
-        const int posn = top - 1 - lane;   // 0-based list position of this lane's entry
+        const int posn = top - 1 - lane;          // 0-based list position of this lane's entry
         uint32_t e = 0, gid = 0;
         if (posn >= 0) { e = a.point_list[range.x + (uint32_t)posn]; gid = a.list_gauss[range.x + (uint32_t)posn]; }
+        if (wave == 0) s_e[lane] = e;
         const bool keep = (e & strip_bit) != 0;
         const unsigned long long m = __ballot(keep);
-        if (m == 0ull) continue;
-        if (top - 64 >= top0) {   // whole batch lies behind every pixel's last contributor: zero slots, nothing to compute
+        unsigned long long wrote = 0ull;
+        if (m != 0ull && top - 64 < top0) {
+            const int n = __popcll(m);
             if (keep) {
-                float4* dst = (float4*)(a.slots + ((size_t)(e & ID_MASK) * 4 + wave) * SLOT_F);
-                dst[0] = make_float4(0.f, 0.f, 0.f, 0.f); dst[1] = dst[0]; dst[2] = dst[0];
+                const int slot = __popcll(m & ((1ull << lane) - 1ull));
+                s_pos[wave][slot] = posn;
+                s_rec[wave][slot] = a.rec[gid];
             }
-            continue;
-        }
-        const int n = __popcll(m);
-        if (keep) {
-            const int slot = __popcll(m & ((1ull << lane) - 1ull));
-            s_pos[slot] = posn;
-            s_u[slot] = e & ID_MASK;
-            s_rec[slot] = a.rec[gid];
-        }
-#pragma unroll
-        for (int c = 0; c < NGRAD; ++c) s_sum[lane][c] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-        SplatRec rn = s_rec[0];
-        int pn = s_pos[0];
-        for (int j = 0; j < n; ++j) {
-            const SplatRec r = rn;
-            const int position = pn;
-            const int jn = j + 1 < n ? j + 1 : j;
-            rn = s_rec[jn];          // prefetch the next entry's record
-            pn = s_pos[jn];
-            const float dx = r.px - pfx, dy = r.py - pfy;
-            const float power = -0.5f * (r.ca * dx * dx + r.cc * dy * dy) - r.cb * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, r.opacity * G);
-            float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f, g_r = 0.f, g_g = 0.f, g_b = 0.f, g_d = 0.f;
-            const bool valid = position < last_contributor && power <= 0.f && alpha >= 1.f / 255.f;
-            if (valid) {
-                const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);   // alpha <= 0.99: one v_rcp_f32 (1 ulp) instead of two IEEE divisions
+            __builtin_amdgcn_wave_barrier();
+            auto eval = [&](const SplatRec& r, const int position_v) {
+                const int position = __builtin_amdgcn_readfirstlane(position_v);   // wave-uniform (LDS broadcast read): keep it scalar
+                const float dx = r.px - pfx, dy = r.py - pfy;
+                const float power = -0.5f * (r.ca * dx * dx + r.cc * dy * dy) - r.cb * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, r.opacity * G);
+                const bool valid = position < last_contributor && power <= 0.f && alpha >= 1.f / 255.f;
+                if (__ballot(valid) == 0ull) return;                       // wave-uniform: no pixel of the strip blends this entry
+                const float av = valid ? alpha : 0.f;
+                const float inv_one_m = __builtin_amdgcn_rcpf(1.f - av);   // alpha <= 0.99: one v_rcp_f32 (1 ulp); rcp(1) = 1 exactly
                 T = T * inv_one_m;
-                const float w = alpha * T;
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0; lc0 = r.r;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1; lc1 = r.g;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2; lc2 = r.b;
-                accd = last_alpha * lcd + (1.f - last_alpha) * accd; lcd = r.depth;
-                float dL_dalpha = (r.r - acc0) * dp0 + (r.g - acc1) * dp1 + (r.b - acc2) * dp2 + (r.depth - accd) * dpd;
-                g_r = w * dp0; g_g = w * dp1; g_b = w * dp2; g_d = w * dpd;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final * inv_one_m) * bg_dot;
-                const float dL_dG = r.opacity * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                g_mx = dL_dG * (-gdx * r.ca - gdy * r.cb) * ddelx_dx;
-                g_my = dL_dG * (-gdy * r.cc - gdx * r.cb) * ddely_dy;
-                g_ca = -0.5f * gdx * dx * dL_dG;
-                g_cb = -gdx * dy * dL_dG;
-                g_cc = -0.5f * gdy * dy * dL_dG;
-                g_op = G * dL_dalpha;
-            }
-            if (__ballot(valid) != 0ull) {   // wave-uniform
-                float q0, q1, q2;
-                wave_sum10_rows(g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g, g_b, g_d, q0, q1, q2);
-                if (row_last) {   // three stores from four lanes instead of ten from one
-                    float* sp = s_sum[j];
-                    sp[si0] = q0; sp[si1] = q1; sp[si2] = q2;
-                }
+                const float w = av * T;
+                float dL_dalpha = ((r.r - A0) * dp0 + (r.g - A1) * dp1 + (r.b - A2) * dp2 + (r.depth - Ad) * dpd) * T + bgT * inv_one_m;
+                dL_dalpha = valid ? dL_dalpha : 0.f;
+                const float one_m = 1.f - av;
+                A0 = av * r.r + one_m * A0; A1 = av * r.g + one_m * A1; A2 = av * r.b + one_m * A2; Ad = av * r.depth + one_m * Ad;
+                // Everything that is constant per entry (conic, opacity, the pixel->NDC factors) is applied ONCE per Gaussian by
+                // preprocess_backward; the lanes only form h = G dL/dalpha and its first and second moments in (dx, dy):
+                //   dL/dopacity = S[h];  dL/dconic = -op (S[h dx dx] / 2, S[h dx dy], S[h dy dy] / 2);
+                //   dL/dmean2D = op (-ca S[h dx] - cb S[h dy], -cc S[h dy] - cb S[h dx]) * (W/2, H/2)
+                const float h = G * dL_dalpha;
+                const float hx = dx * h, hy = dy * h;
+                const float tsum = wave_sum10_banked(hx, hy, dx * hx, dx * hy, dy * hy, h, w * dp0, w * dp1, w * dp2, w * dpd);
+                const int bp = top - 1 - position;                         // position inside this batch = the lane that loaded the entry
+                if (st_lane) s_part[wave][bp][st_idx] = tsum;
+                wrote |= 1ull << bp;
+            };
+            // two entries per trip with two named register sets: the LDS reads of one are in flight while the other is evaluated,
+            // and no record has to be copied from a "next" to a "current" register set
+            SplatRec ra = s_rec[wave][0];
+            int pa = s_pos[wave][0];
+            for (int j = 0; j < n; j += 2) {
+                const int j1 = j + 1 < n ? j + 1 : j;
+                const SplatRec rb = s_rec[wave][j1];
+                const int pb = j + 1 < n ? s_pos[wave][j1] : 0x7fffffff;   // odd tail: a position no pixel can blend
+                eval(ra, pa);
+                const int j2 = j + 2 < n ? j + 2 : j1;
+                ra = s_rec[wave][j2];
+                pa = s_pos[wave][j2];
+                eval(rb, pb);
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        // flush this wave's slab: lane j owns compacted entry j and stores its sums (zeros included) into the
-        // entry's private slot for this strip — plain 16-byte stores, no atomics, bit-reproducible gradients
-        if (lane < n) {
-            const float* sp = s_sum[lane];
-            float4* dst = (float4*)(a.slots + ((size_t)s_u[lane] * 4 + wave) * SLOT_F);   // slots are indexed by emission slot
-            dst[0] = make_float4(sp[0], sp[1], sp[2], sp[3]);
-            dst[1] = make_float4(sp[4], sp[5], sp[6], sp[7]);
-            dst[2] = make_float4(sp[8], sp[9], 0.f, 0.f);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// Entry-parallel: add up each emission slot's (up to four) strip slots into one 12-float record, so that the
-// per-Gaussian pass (preprocess_backward) only streams a contiguous array.  Fully parallel, no dependent chains.
-__global__ __launch_bounds__(256) void entry_sum_kernel(const uint32_t* __restrict__ total, uint32_t cap, const uint32_t* __restrict__ entry_bits,
-                                                        const float* __restrict__ slots, float* __restrict__ entry_sum) {
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= device_R(total, cap)) return;
-    const uint32_t bits = entry_bits[u];
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+        if (lane == 0) s_wrote[wave] = wrote;
+        __syncthreads();
+        {   // merge the strips of every batch position in strip order and write the entry record once
+            const int p = (int)(threadIdx.x >> 2), q = (int)(threadIdx.x & 3);
+            if (top - 1 - p >= 0 && q < 3) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int sidx = 0; sidx < 4; ++sidx) {
-        if ((bits >> sidx) & 1u) {
-            const float4* sl = (const float4*)(slots + ((size_t)u * 4 + sidx) * SLOT_F);
-            const float4 v0 = sl[0], v1 = sl[1], v2 = sl[2];
-            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-            a2.x += v2.x; a2.y += v2.y;
+                for (int w = 0; w < 4; ++w) {
+                    if ((s_wrote[w] >> p) & 1ull) {
+                        const float4 v = *(const float4*)&s_part[w][p][4 * q];
+                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    }
+                }
+                *(float4*)(a.entry_sum + (size_t)(s_e[p] & ID_MASK) * SLOT_F + 4 * q) = acc;
+            }
         }
+        __syncthreads();
     }
-    float4* dst = (float4*)(entry_sum + (size_t)u * SLOT_F);
-    dst[0] = a0; dst[1] = a1; dst[2] = a2;
 }
 
 }  // namespace
@@ -846,7 +836,7 @@ int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsic
 size_t gsicp_raster_backward_scratch_bytes(int num_rendered, int width, int height) {
     (void)width; (void)height;
     const size_t R = num_rendered > 0 ? (size_t)num_rendered : 1;
-    return align_up(R * 4 * SLOT_F * sizeof(float)) + align_up(R * SLOT_F * sizeof(float));
+    return align_up(R * SLOT_F * sizeof(float));
 }
 
 int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* background, int width, int height,
@@ -868,8 +858,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     const ImgLayout IL = img_layout(width, height);
     // num_rendered is the list capacity the forward ran with (== R on the synchronous path); the true R is on the device
     const uint32_t* total_counter = (const uint32_t*)(img_buffer + IL.tile_count) + 2 * (size_t)T;
-    float* slots = (float*)scratch;
-    float* entry_sum = (float*)(scratch + align_up((size_t)(num_rendered > 0 ? num_rendered : 1) * 4 * SLOT_F * sizeof(float)));
+    float* entry_sum = (float*)scratch;   // (R, SLOT_F): one gradient record per emission slot
 
     BlendArgs ba;
     std::memset(&ba, 0, sizeof(ba));
@@ -884,15 +873,10 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     ba.final_T = (float*)(img_buffer + IL.final_T);
     ba.n_contrib = (uint32_t*)(img_buffer + IL.n_contrib);
     ba.dL_dpix = dL_dpix; ba.dL_ddepth = dL_ddepth;
-    ba.slots = slots;
+    ba.entry_sum = entry_sum;
     if (num_rendered > 0 && ba.n_tiles_local > 0) {
         ProfileScope ps(ST_BLEND_BWD, stream);
-        hipLaunchKernelGGL(blend_backward_strip_kernel, dim3(ba.n_tiles_local * 4), dim3(64), 0, stream, ba);
-    }
-    if (num_rendered > 0) {
-        ProfileScope ps(ST_ENTRY_SUM, stream);
-        hipLaunchKernelGGL(entry_sum_kernel, dim3((num_rendered + 255) / 256), dim3(256), 0, stream, total_counter, (uint32_t)num_rendered,
-                           (const uint32_t*)(binning_buffer + BL.entry_bits), slots, entry_sum);
+        hipLaunchKernelGGL(blend_backward_tile_kernel, dim3(ba.n_tiles_local), dim3(256), 0, stream, ba);
     }
 
     PreprocessBwdArgs pb;
@@ -902,6 +886,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     pb.campos = cam_pos; pb.tanfovx = tan_fovx; pb.tanfovy = tan_fovy; pb.radii = radii;
     pb.clamped = (const unsigned char*)(geom_buffer + GL.clamped);
     pb.entry_sum = entry_sum;
+    pb.rec = (const SplatRec*)(geom_buffer + GL.records);
     pb.slot_base = (const uint32_t*)(geom_buffer + GL.slot_base);
     pb.tiles_touched = (const uint32_t*)(geom_buffer + GL.tiles_touched);
     pb.total_counter = total_counter; pb.capacity = (uint32_t)(num_rendered > 0 ? num_rendered : 0);

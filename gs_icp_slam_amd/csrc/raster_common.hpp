@@ -23,7 +23,7 @@ struct __attribute__((aligned(16))) SplatRec {
 constexpr uint32_t ID_MASK = 0x0FFFFFFFu;
 constexpr int STRIP_SHIFT = 28;
 constexpr int NGRAD = 10;    // mean2D x,y | conic a,b,c | opacity | colour r,g,b | depth
-constexpr int SLOT_F = 12;   // floats per (entry, strip) gradient slot: NGRAD + 2 pad = three float4
+constexpr int SLOT_F = 12;   // floats per emission-slot gradient record: NGRAD + 2 pad = three float4
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
@@ -99,7 +99,8 @@ struct PreprocessBwdArgs {
     float tanfovx, tanfovy;
     const int* radii;
     const unsigned char* clamped;
-    const float* entry_sum;        // (R, SLOT_F) per-emission-slot gradient sums (strips already added)
+    const float* entry_sum;        // (R, SLOT_F) per-emission-slot moment sums [h dx, h dy, h dx dx, h dx dy, h dy dy, h, w r, w g, w b, w z]
+    const SplatRec* rec;           // conic + opacity of every Gaussian (the per-entry constants of the blend backward are applied here)
     const uint32_t *slot_base, *tiles_touched;
     const uint32_t* total_counter;  // device R; above `capacity` the forward rendered nothing (async path overflow)
     uint32_t capacity;

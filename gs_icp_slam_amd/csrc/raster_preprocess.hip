@@ -355,6 +355,17 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
             }
         }
     }
+    // gs = moment sums of h = G dL/dalpha over every pixel this Gaussian blends: [h dx, h dy, h dx dx, h dx dy, h dy dy, h, ...]
+    // (blend_backward_tile_kernel); the per-Gaussian constants turn them into the screen-space gradients
+    if (visible) {
+        const SplatRec r = a.rec[i];
+        const float hx = gs[0], hy = gs[1], hxx = gs[2], hxy = gs[3], hyy = gs[4];
+        gs[0] = r.opacity * (-hx * r.ca - hy * r.cb) * (0.5f * (float)a.W);
+        gs[1] = r.opacity * (-hy * r.cc - hx * r.cb) * (0.5f * (float)a.H);
+        gs[2] = -0.5f * hxx * r.opacity;
+        gs[3] = -hxy * r.opacity;
+        gs[4] = -0.5f * hyy * r.opacity;
+    }
     a.dL_dmean2D[3 * i] = gs[0]; a.dL_dmean2D[3 * i + 1] = gs[1]; a.dL_dmean2D[3 * i + 2] = 0.f;
     a.dL_dconic[4 * i] = gs[2]; a.dL_dconic[4 * i + 1] = gs[3]; a.dL_dconic[4 * i + 2] = gs[4]; a.dL_dconic[4 * i + 3] = 0.f;
     a.dL_dopacity[i] = gs[5];
