@@ -400,32 +400,38 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
             s_rec[slot] = a.rec[id];
         }
         __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order; this only stops compiler reordering
-        SplatRec rn = s_rec[0];
-        uint32_t pn = s_pos[0];
-        unsigned long long used = 0ull;
-        for (int j = 0; j < n; ++j) {
-            const SplatRec r = rn;
-            const uint32_t pos_j = pn;
-            const int jn = j + 1 < n ? j + 1 : j;
-            rn = s_rec[jn];          // LDS reads for the next entry are in flight while this one is evaluated
-            pn = s_pos[jn];
+        unsigned long long used = 0ull;    // wave-uniform bookkeeping in scalar registers: bit j = compacted entry j reached a pixel
+        // Branch-free per-entry body: an entry this pixel does not blend enters the sums with weight 0 and leaves T where it was;
+        // only the wave-uniform "nobody blends it" case branches.  Same arithmetic as the reference order of tests: alpha, then the
+        // transmittance test on T (1 - alpha), then the accumulation with w = alpha T.
+        auto eval = [&](const SplatRec& r, const uint32_t pos_v, const int j) {
             const float dx = r.px - pfx, dy = r.py - pfy;
             const float power = -0.5f * (r.ca * dx * dx + r.cc * dy * dy) - r.cb * dx * dy;
             const float alpha = fminf(0.99f, r.opacity * __expf(power));
-            bool contrib = false;
-            if (!done && power <= 0.f && alpha >= 1.f / 255.f) {
-                const float test_T = T * (1.f - alpha);
-                if (test_T < 0.0001f) {
-                    done = true;
-                } else {
-                    const float w = alpha * T;
-                    C0 += r.r * w; C1 += r.g * w; C2 += r.b * w; Dz += r.depth * w;
-                    T = test_T;
-                    last_contributor = pos_j;
-                    contrib = true;
-                }
-            }
-            used |= (__ballot(contrib) != 0ull ? 1ull : 0ull) << j;   // wave-uniform bookkeeping in scalar registers
+            const bool valid = !done && power <= 0.f && alpha >= 1.f / 255.f;
+            const float test_T = T * (1.f - alpha);
+            const bool stop = valid && test_T < 0.0001f;
+            done = done || stop;
+            const bool contrib = valid && !stop;
+            if (__ballot(contrib) == 0ull) return;
+            const float w = contrib ? alpha * T : 0.f;
+            C0 += r.r * w; C1 += r.g * w; C2 += r.b * w; Dz += r.depth * w;
+            T = contrib ? test_T : T;
+            last_contributor = contrib ? pos_v : last_contributor;
+            used |= 1ull << j;
+        };
+        // two entries per trip with two named register sets (no "next -> current" copies; one set's LDS reads fly while the other is evaluated)
+        SplatRec ra = s_rec[0];
+        uint32_t pa = s_pos[0];
+        for (int j = 0; j < n; j += 2) {
+            const int j1 = j + 1 < n ? j + 1 : j;
+            const SplatRec rb = s_rec[j1];
+            const uint32_t pb = s_pos[j1];
+            eval(ra, pa, j);
+            const int j2 = j + 2 < n ? j + 2 : j1;
+            ra = s_rec[j2];
+            pa = s_pos[j2];
+            if (j + 1 < n) eval(rb, pb, j + 1);
         }
         // is_used: one store instruction per batch (lane j reports compacted entry j) instead of a store per visit
         if (a.is_used && lane < n && ((used >> lane) & 1ull)) a.is_used[s_id[lane]] = 1;

@@ -15,7 +15,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE_OF = {"blend_backward_strip_kernel": "blend_backward", "blend_forward_strip_kernel": "blend_forward",
+STAGE_OF = {"blend_backward_strip_kernel": "blend_backward", "blend_backward_tile_kernel": "blend_backward", "blend_forward_strip_kernel": "blend_forward",
             "entry_sum_kernel": "entry_grad_sum", "preprocess_backward_kernel": "preprocess_backward",
             "preprocess_kernel": "preprocess", "tile_scan_lpt_kernel": "tile_scan_lpt"}
 
