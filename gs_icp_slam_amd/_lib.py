@@ -25,16 +25,16 @@ SIGNATURES = {
     "gsicp_raster_forward": (c_int, [RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, c_int, c_int, c_int, c_void_p,
                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_int, c_int, c_void_p]),
+                                     c_int, c_int, c_int, c_int, c_void_p]),
     "gsicp_raster_forward_async": (c_int, [RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, c_int, c_int, c_int, c_void_p,
                                            c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+                                           c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gsicp_raster_backward_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gsicp_raster_backward": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gsicp_raster_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_raster_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "gsicp_knn_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
@@ -61,6 +61,7 @@ SIGNATURES = {
     "gsicp_gicp_set_max_iterations": (c_int, [c_void_p, c_int]),
     "gsicp_gicp_set_num_threads": (c_int, [c_void_p, c_int]),
     "gsicp_gicp_set_regularization_method": (c_int, [c_void_p, c_int]),
+    "gsicp_gicp_set_scale_semantics": (c_int, [c_void_p, c_int]),
     "gsicp_gicp_set_rotation_epsilon": (c_int, [c_void_p, c_double]),
     "gsicp_gicp_set_transformation_epsilon": (c_int, [c_void_p, c_double]),
     "gsicp_gicp_set_input_target": (c_int, [c_void_p, c_void_p, c_int, c_int]),
@@ -114,7 +115,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.gsicp_abi_version() != 1:
+        if lib.gsicp_abi_version() != 2:
             raise ImportError("libgsicp_hip.so ABI version mismatch")
         if os.environ.get("GSICP_ANNOUNCE"):   # tools/run_reference_slam.py: show which processes of the reference run loaded the library
             print(f"GSICP_LOADED {LIB_PATH} pid={os.getpid()}", flush=True)

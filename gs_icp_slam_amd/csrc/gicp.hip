@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void nn1_grid_kernel(const int* __restrict__ m
 // One THREAD per point: mean / covariance of its neighbours in fp64 (summed in rank order, as the oracle does), cyclic
 // Jacobi, quaternion (x,y,z,w), scales = sqrt(eigenvalues of the RAW covariance), regularised covariance for the cost.
 __global__ __launch_bounds__(64) void cov_eig_kernel(int n, int k, const float4* __restrict__ pts, const int* __restrict__ nbr_idx,
-                                                     const float* __restrict__ nbr_d2, float max_d2, int reg_method,
+                                                     const float* __restrict__ nbr_d2, float max_d2, int reg_method, int scale_mode,
                                                      double* __restrict__ cov, float* __restrict__ rotq, float* __restrict__ scales) {
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= n) return;
@@ -634,12 +634,12 @@ __global__ __launch_bounds__(64) void cov_eig_kernel(int n, int k, const float4*
 #pragma unroll
     for (int d = 0; d < 4; ++d) rotq[4 * (size_t)q + d] = (float)qd[d];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) scales[3 * (size_t)q + d] = (float)sqrt(fmax(ev[d], 0.0));
+    for (int d = 0; d < 3; ++d) scales[3 * (size_t)q + d] = (float)(scale_mode ? fmax(ev[d], 0.0) : sqrt(fmax(ev[d], 0.0)));   // variance | std-dev
 #pragma unroll
     for (int d = 0; d < 6; ++d) cov[6 * (size_t)q + d] = out6[d];
 }
 
-__global__ __launch_bounds__(256) void cov_fromqs_kernel(int n, int reg_method, const float* __restrict__ rots,
+__global__ __launch_bounds__(256) void cov_fromqs_kernel(int n, int reg_method, int scale_mode, const float* __restrict__ rots,
                                                          const float* __restrict__ scales, double* __restrict__ cov) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void cov_fromqs_kernel(int n, int reg_method, 
     double R[9];
     quat_to_rot(q, R);
     const double s0 = scales[3 * (size_t)i], s1 = scales[3 * (size_t)i + 1], s2 = scales[3 * (size_t)i + 2];
-    const double v[3] = {s0 * s0, s1 * s1, s2 * s2};
+    const double v[3] = {scale_mode ? s0 : s0 * s0, scale_mode ? s1 : s1 * s1, scale_mode ? s2 : s2 * s2};   // scales are variances | std-devs
     double raw[6];
     int k = 0;
 #pragma unroll
@@ -1464,6 +1464,7 @@ struct Cloud {
 struct gsicp_gicp {
     hipStream_t stream = nullptr;
     int k = 20, max_iter = 64, lm_max_iter = 10, reg = 3;
+    int scale_mode = 0;   // exported scales / fromqs input: 0 = std-devs (sqrt eigenvalues; fromqs squares them), 1 = variances (eigenvalues; used as they are)
     double max_corr = (double)FLT_MAX, max_knn = (double)FLT_MAX, rot_eps = 2e-3, trans_eps = 5e-4, lm_init = 1e-9;
     Cloud src, tgt;
     // target search structure
@@ -1609,7 +1610,7 @@ int calc_cov(gsicp_gicp* g, Cloud& c) {
                            g->knn_sorted.p, g->nbr_idx.p, g->nbr_d2.p,
                            knn_stats_on ? g->knn_params.p->ring_hist : (unsigned*)nullptr);   // same-address atomics: diagnostics only
         hipLaunchKernelGGL(cov_eig_kernel, dim3((n + 63) / 64), dim3(64), 0, g->stream, n, g->k, c.pts.p, g->nbr_idx.p, g->nbr_d2.p, maxd2,
-                           g->reg, c.cov.p, c.rotq.p, c.scales.p);
+                           g->reg, g->scale_mode, c.cov.p, c.rotq.p, c.scales.p);
         GC(hipGetLastError());
     }
     c.cov_valid = true; c.qs_valid = true;
@@ -1727,6 +1728,10 @@ int gsicp_gicp_set_regularization_method(gsicp_gicp* g, int m) {
     if (m < 0 || m > 4) { g_last_error = "unknown regularization method"; return -2; }
     g->reg = m; g->src.cov_valid = false; return 0;
 }
+int gsicp_gicp_set_scale_semantics(gsicp_gicp* g, int mode) {
+    if (mode < 0 || mode > 1) { g_last_error = "scale semantics: 0 = std-dev, 1 = variance"; return -2; }
+    g->scale_mode = mode; g->src.cov_valid = false; g->tgt.cov_valid = false; return 0;
+}
 int gsicp_gicp_set_rotation_epsilon(gsicp_gicp* g, double e) { g->rot_eps = e; return 0; }
 int gsicp_gicp_set_transformation_epsilon(gsicp_gicp* g, double e) { g->trans_eps = e; return 0; }
 
@@ -1777,7 +1782,7 @@ int gsicp_gicp_set_target_covariances_fromqs(gsicp_gicp* g, const float* rots, i
     if (t.n > 0) {
         GC(hipMemcpyAsync(t.rotq.p, rots, sizeof(float) * 4 * t.n, hipMemcpyHostToDevice, g->stream));
         GC(hipMemcpyAsync(t.scales.p, scales, sizeof(float) * 3 * t.n, hipMemcpyHostToDevice, g->stream));
-        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, t.rotq.p, t.scales.p, t.cov.p);
+        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, g->scale_mode, t.rotq.p, t.scales.p, t.cov.p);
         GC(hipGetLastError());
         if (int rc_ = drain(g)) return rc_;
     }
@@ -1828,7 +1833,7 @@ int gsicp_gicp_set_target_covariances_fromqs_device(gsicp_gicp* g, const float* 
         if (int rc = wait_for_producer(g, producer_stream)) return rc;
         hipLaunchKernelGGL(copy_f32_kernel, dim3((4 * t.n + 255) / 256), dim3(256), 0, g->stream, (size_t)4 * t.n, rots, t.rotq.p);
         hipLaunchKernelGGL(copy_f32_kernel, dim3((3 * t.n + 255) / 256), dim3(256), 0, g->stream, (size_t)3 * t.n, scales, t.scales.p);
-        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, t.rotq.p, t.scales.p, t.cov.p);
+        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, g->scale_mode, t.rotq.p, t.scales.p, t.cov.p);
         GC(hipGetLastError());
         if (wait) { if (int rc_ = drain(g)) return rc_; }
     }
@@ -1860,7 +1865,7 @@ int gsicp_gicp_set_target_from_gaussians_device(gsicp_gicp* g, int P, const floa
     total = g->mailbox->scratch_u32;
     t.n = (int)total; t.n_track = (int)total;
     if (total > 0) {
-        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, t.rotq.p, t.scales.p, t.cov.p);
+        hipLaunchKernelGGL(cov_fromqs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, g->stream, t.n, g->reg, g->scale_mode, t.rotq.p, t.scales.p, t.cov.p);
         GC(hipGetLastError());
     }
     t.cov_valid = true; t.qs_valid = true;

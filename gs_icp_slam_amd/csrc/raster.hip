@@ -329,6 +329,7 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __re
 // ------------------------------------------------------------------------------------------------ blending
 struct BlendArgs {
     int W, H, gx, n_tiles_local, tile_mod, tile_rem;
+    int depth_mode;            // 0: D = sum z alpha T;  1: alpha-normalised, D = sum z alpha T / (1 - T_final)   (include/gsicp_hip.h)
     const uint2* ranges;
     const uint32_t* order;     // local tiles, longest list first
     const uint32_t* point_list;
@@ -343,6 +344,7 @@ struct BlendArgs {
     // backward only
     const float* dL_dpix;
     const float* dL_ddepth;
+    const float* depth_out;    // forward depth image (depth_mode 1 needs it: d(N/A) involves N/A)
     float* entry_sum;    // (R, SLOT_F) per-emission-slot gradient moment sums (see blend_backward_tile_kernel)
 };
 
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
         a.out_color[pix] = C0 + T * a.bg[0];
         a.out_color[HW + pix] = C1 + T * a.bg[1];
         a.out_color[2 * HW + pix] = C2 + T * a.bg[2];
-        a.out_depth[pix] = Dz;
+        a.out_depth[pix] = a.depth_mode == 1 ? (T < 1.f ? Dz / (1.f - T) : 0.f) : Dz;
     }
 }
 
@@ -530,7 +532,14 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
         dp0 = a.dL_dpix[pix]; dp1 = a.dL_dpix[HW + pix]; dp2 = a.dL_dpix[2 * HW + pix];
         dpd = a.dL_ddepth ? a.dL_ddepth[pix] : 0.f;
     }
-    const float bgT = -T_final * (a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2);
+    float bg_dot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
+    if (a.depth_mode == 1) {
+        // D = N / A with A = 1 - T_final:  dD/dalpha_i = (dN/dalpha_i) / A - (N / A^2) T_final / (1 - alpha_i).  The first term is the
+        // un-normalised rule fed with dL/dD / A; the second has exactly the form of the background term (-T_final / (1 - alpha_i) * x).
+        const float A = 1.f - T_final;
+        if (inside && A > 0.f) { bg_dot += dpd * a.depth_out[pix] / A; dpd = dpd / A; } else dpd = 0.f;
+    }
+    const float bgT = -T_final * bg_dot;
     float A0 = 0.f, A1 = 0.f, A2 = 0.f, Ad = 0.f;     // colour / depth composited BEHIND the current entry
 
     // where this lane's value of wave_sum10_banked belongs in a 12-float record (lanes with (lane & 3) == 0 of banks 0, 2, 3 store)
@@ -673,9 +682,10 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                          const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                          float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
-                         int* is_used, int tile_mod, int tile_rem, int debug, int capacity, unsigned int* num_rendered_dev,
+                         int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode, int capacity, unsigned int* num_rendered_dev,
                          void* stream_v) {
     (void)prefiltered; (void)debug;
+    if (depth_mode < 0 || depth_mode > 1) { g_last_error = "depth_mode: 0 = sum z alpha T, 1 = alpha-normalised"; return -2; }
     const bool async = capacity > 0 && P > 0;   // capacity given: no host round trip, R stays on the device
     if (capacity > (int)ID_MASK) { g_last_error = "capacity above 2^28 duplicates is not supported"; return -2; }
     hipStream_t stream = (hipStream_t)stream_v;
@@ -797,7 +807,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
 
     BlendArgs ba;
     std::memset(&ba, 0, sizeof(ba));
-    ba.W = width; ba.H = height; ba.gx = gx; ba.tile_mod = tile_mod; ba.tile_rem = tile_rem;
+    ba.W = width; ba.H = height; ba.gx = gx; ba.tile_mod = tile_mod; ba.tile_rem = tile_rem; ba.depth_mode = depth_mode;
     ba.n_tiles_local = (T - tile_rem + tile_mod - 1) / tile_mod;
     ba.ranges = ranges; ba.point_list = point_list; ba.rec = rec; ba.list_gauss = (const uint32_t*)(bin + BL.list_gauss);
     ba.order = order;
@@ -817,11 +827,11 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
                          const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                          float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
-                         int* is_used, int tile_mod, int tile_rem, int debug, void* stream) {
+                         int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode, void* stream) {
     return raster_forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width, height,
                                means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
                                projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, radii, is_used, tile_mod,
-                               tile_rem, debug, 0, nullptr, stream);
+                               tile_rem, debug, depth_mode, 0, nullptr, stream);
 }
 
 int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
@@ -830,13 +840,13 @@ int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
-                               int* is_used, int tile_mod, int tile_rem, int debug, int capacity, unsigned int* num_rendered_dev,
-                               void* stream) {
+                               int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode, int capacity,
+                               unsigned int* num_rendered_dev, void* stream) {
     if (capacity <= 0) { g_last_error = "gsicp_raster_forward_async: capacity must be positive"; return -2; }
     return raster_forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width, height,
                                means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
                                projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, radii, is_used, tile_mod,
-                               tile_rem, debug, capacity, num_rendered_dev, stream);
+                               tile_rem, debug, depth_mode, capacity, num_rendered_dev, stream);
 }
 
 size_t gsicp_raster_backward_scratch_bytes(int num_rendered, int width, int height) {
@@ -852,8 +862,12 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
                           const char* geom_buffer, const char* binning_buffer, const char* img_buffer, char* scratch,
                           const float* dL_dpix, const float* dL_ddepth, float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity,
                           float* dL_dcolors, float* dL_ddepths, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                          float* dL_dscales, float* dL_drots, int tile_mod, int tile_rem, int debug, void* stream_v) {
+                          float* dL_dscales, float* dL_drots, int tile_mod, int tile_rem, int debug, int depth_mode, const float* out_depth,
+                          void* stream_v) {
     (void)debug;
+    if (depth_mode < 0 || depth_mode > 1 || (depth_mode == 1 && dL_ddepth && !out_depth)) {
+        g_last_error = "gsicp_raster_backward: depth_mode 1 needs the forward's depth image"; return -2;
+    }
     hipStream_t stream = (hipStream_t)stream_v;
     if (P <= 0) return 0;
     if (tile_mod < 1 || tile_rem < 0 || tile_rem >= tile_mod) { g_last_error = "bad tile_mod / tile_rem"; return -2; }
@@ -878,7 +892,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     ba.bg = background;
     ba.final_T = (float*)(img_buffer + IL.final_T);
     ba.n_contrib = (uint32_t*)(img_buffer + IL.n_contrib);
-    ba.dL_dpix = dL_dpix; ba.dL_ddepth = dL_ddepth;
+    ba.dL_dpix = dL_dpix; ba.dL_ddepth = dL_ddepth; ba.depth_mode = dL_ddepth ? depth_mode : 0; ba.depth_out = out_depth;
     ba.entry_sum = entry_sum;
     if (num_rendered > 0 && ba.n_tiles_local > 0) {
         ProfileScope ps(ST_BLEND_BWD, stream);

@@ -104,6 +104,13 @@ class FastGICP:
         m = _REG[method.upper()] if isinstance(method, str) else int(method)
         self._ck(self._lib.gsicp_gicp_set_regularization_method(self._h, m), "set_regularization_method")
 
+    def set_scale_semantics(self, mode):
+        """Extension (SURVEY 8a unknown): "stddev" (default) — get_*_scales() are sqrt(eigenvalues) and set_target_covariances_fromqs
+        squares its scales; "variance" — eigenvalues are exported / consumed as they are."""
+        self._config["set_scale_semantics"] = mode
+        m = {"stddev": 0, "variance": 1}[mode] if isinstance(mode, str) else int(mode)
+        self._ck(self._lib.gsicp_gicp_set_scale_semantics(self._h, m), "set_scale_semantics")
+
     def set_rotation_epsilon(self, e):
         self._config["set_rotation_epsilon"] = e
         self._ck(self._lib.gsicp_gicp_set_rotation_epsilon(self._h, float(e)), "set_rotation_epsilon")

@@ -39,6 +39,9 @@ class GaussianRasterizationSettings(NamedTuple):
     # behaviour); > 0 = sync-free forward (HIP-graph capturable); GaussianRasterizer.num_rendered then holds the true
     # count on the device, and a count above the capacity renders nothing (see include/gsicp_hip.h).
     capacity: int = 0
+    # Extension: depth compositing rule (the fork's rule cannot be read off the reference tree).  0 = sum z alpha T
+    # (default), 1 = alpha-normalised (divided by the accumulated alpha 1 - T_final).  Both have exact backward passes.
+    depth_mode: int = 0
 
 
 def _ptr(t):
@@ -106,7 +109,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             args = (geom.cb, None, binning.cb, None, img.cb, None, P, int(rs.sh_degree), int(M), _ptr(bg), W, H, _ptr(means3D),
                     _ptr(sh_c), _ptr(col_c), _ptr(op_c), _ptr(sc_c), float(rs.scale_modifier), _ptr(rot_c), _ptr(cov_c), _ptr(view),
                     _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)), _ptr(color),
-                    _ptr(depth), _ptr(radii), _ptr(is_used), int(rs.tile_mod), int(rs.tile_rem), int(bool(rs.debug)))
+                    _ptr(depth), _ptr(radii), _ptr(is_used), int(rs.tile_mod), int(rs.tile_rem), int(bool(rs.debug)),
+                    int(getattr(rs, "depth_mode", 0) or 0))
             capacity = int(getattr(rs, "capacity", 0) or 0)
             if capacity > 0 and P > 0:
                 n = lib.gsicp_raster_forward_async(*args, capacity, _ptr(count_out), stream)
@@ -120,8 +124,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = n
         ctx.M = int(M)
         ctx.have = (sh_c is not None, col_c is not None, sc_c is not None, rot_c is not None, cov_c is not None)
+        ctx.depth_mode = int(getattr(rs, "depth_mode", 0) or 0)
         ctx.save_for_backward(means3D, sh_c, col_c, sc_c, rot_c, cov_c, radii, geom.tensor, binning.tensor, img.tensor, bg, view,
-                              proj, campos)
+                              proj, campos, depth if ctx.depth_mode == 1 else None)
         ctx.mark_non_differentiable(radii, is_used)
         return depth, color, radii, is_used
 
@@ -129,7 +134,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @_lib.traced("raster.backward")
     def backward(ctx, grad_depth, grad_color, _grad_radii, _grad_used):
         lib = _lib.load()
-        (means3D, sh_c, col_c, sc_c, rot_c, cov_c, radii, geom, binning, img, bg, view, proj, campos) = ctx.saved_tensors
+        (means3D, sh_c, col_c, sc_c, rot_c, cov_c, radii, geom, binning, img, bg, view, proj, campos, depth_out) = ctx.saved_tensors
         rs = ctx.rs
         dev = means3D.device
         P = means3D.shape[0]
@@ -157,7 +162,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 float(rs.tanfovy), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img), _ptr(scratch), _ptr(g_color), _ptr(g_depth),
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), _ptr(dL_dmeans3D),
                 _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drots), int(rs.tile_mod), int(rs.tile_rem),
-                int(bool(rs.debug)), stream)
+                int(bool(rs.debug)), ctx.depth_mode, _ptr(depth_out.detach() if depth_out is not None else None), stream)
             _lib.check(rc, "gsicp_raster_backward")
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors if col_c is not None else None, dL_dopacity, dL_dscales, dL_drots,
                 dL_dcov3D if cov_c is not None else None, None, None)

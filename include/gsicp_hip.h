@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GSICP_ABI_VERSION 1
+#define GSICP_ABI_VERSION 2
 
 int gsicp_abi_version(void);
 const char* gsicp_last_error(void);
@@ -54,7 +54,10 @@ typedef char* (*gsicp_resize_fn)(void* user, size_t bytes);
  *   (scales, rotations) / cov3D_precomp must be non-NULL.  rotations are quaternions in (x,y,z,w) order
  *   [REF utils/general_utils.py:89-99]; viewmatrix / projmatrix are the row-vector (pre-transposed) 4x4s of
  *   [REF scene/shared_objs.py:163-166].
- *   Outputs: out_color (3,H,W), out_depth (1,H,W) = sum z*alpha*T, radii (P) int32, is_used (P) int32.
+ *   Outputs: out_color (3,H,W), out_depth (1,H,W), radii (P) int32, is_used (P) int32.
+ *   depth_mode selects the depth compositing rule — one of the three fork semantics the reference tree cannot settle (its rasteriser
+ *   fork is an empty submodule): 0 = sum_i z_i alpha_i T_i (default; no normalisation, no background term),
+ *   1 = alpha-normalised, sum_i z_i alpha_i T_i / (1 - T_final) (0 where nothing was blended).  Every reported number names the variant.
  *   tile_mod / tile_rem: this call blends only tiles with (tile_id % tile_mod) == tile_rem and leaves the other
  *   tiles' pixels untouched (multi-GPU tile sharding; pass 1, 0 for the whole image).
  * Returns the number of (Gaussian, tile) duplicates binned for this call (the reference's `num_rendered`).
@@ -65,7 +68,8 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
                          const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                          const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-                         float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug, void* stream);
+                         float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode,
+                         void* stream);
 
 /* Same forward without the host round trip (extension; no reference counterpart — the reference always reads
  * num_rendered back, [REF submodules/diff-gaussian-rasterization: rasterizer_impl forward] behind
@@ -82,16 +86,17 @@ int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-                               float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug,
+                               float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode,
                                int capacity, unsigned int* num_rendered_dev, void* stream);
 
-/* Bytes of DEVICE scratch gsicp_raster_backward needs (per-(list entry, strip) gradient slots; contents need no
+/* Bytes of DEVICE scratch gsicp_raster_backward needs (one 48-byte gradient record per (Gaussian, tile) duplicate; contents need no
  * initialisation and are dead after the call). */
 size_t gsicp_raster_backward_scratch_bytes(int num_rendered, int width, int height);
 
 /* Backward of the call above.  geom/binning/img buffers are the ones the forward call filled; num_rendered its
  * return value; `scratch` is a DEVICE buffer of gsicp_raster_backward_scratch_bytes() bytes.
- * dL_dpix (3,H,W) and dL_ddepth (1,H,W; may be NULL) are the incoming image gradients.
+ * dL_dpix (3,H,W) and dL_ddepth (1,H,W; may be NULL) are the incoming image gradients; depth_mode as in the forward, and with
+ * depth_mode 1 `out_depth` must be the depth image that forward produced (may be NULL otherwise).
  * No atomics are used: gradients are bit-reproducible from run to run.
  * Gradient outputs (all DEVICE, all fully overwritten): dL_dmeans2D (P,3) [x,y in NDC-scaled units, z = 0],
  * dL_dconic (P,4) scratch, dL_dopacity (P), dL_dcolors (P,3), dL_ddepths (P) scratch, dL_dmeans3D (P,3),
@@ -105,7 +110,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
                           const char* img_buffer, char* scratch, const float* dL_dpix, const float* dL_ddepth,
                           float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_ddepths,
                           float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, int tile_mod,
-                          int tile_rem, int debug, void* stream);
+                          int tile_rem, int debug, int depth_mode, const float* out_depth, void* stream);
 
 /* present[i] = 1 iff Gaussian i passes the frustum test (view-space z > 0.2).  Asynchronous. */
 int gsicp_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -140,6 +145,12 @@ int gsicp_gicp_set_max_iterations(gsicp_gicp*, int n);                     /* up
 int gsicp_gicp_set_num_threads(gsicp_gicp*, int n);                        /* upstream API; accepted, ignored */
 /* method: 0 NONE, 1 MIN_EIG, 2 NORMALIZED_MIN_EIG, 3 PLANE (default), 4 FROBENIUS */
 int gsicp_gicp_set_regularization_method(gsicp_gicp*, int method);
+/* One of the three fork semantics that cannot be read off the reference (its fast_gicp fork is an empty submodule): what the
+ * numbers of get_*_scales() / set_target_covariances_fromqs() ARE.  0 (default) = standard deviations: exported scales are the square
+ * roots of the k-NN covariance eigenvalues and fromqs builds R diag(s^2) R^T — the mapper uses the exported values as 3DGS scales
+ * [REF scene/gaussian_model.py:143-145].  1 = variances: eigenvalues are exported as they are and fromqs builds R diag(s) R^T.  Both
+ * round-trip a covariance through the map; every reported number names the variant. */
+int gsicp_gicp_set_scale_semantics(gsicp_gicp* g, int mode);
 int gsicp_gicp_set_rotation_epsilon(gsicp_gicp*, double eps);
 int gsicp_gicp_set_transformation_epsilon(gsicp_gicp*, double eps);
 

@@ -55,6 +55,11 @@ def _arr(a, dt, shape=None):
 
 
 # ------------------------------------------------------------------------------------------ rasteriser
+def raster_set_depth_mode(mode):
+    """0 = sum z alpha T (default), 1 = alpha-normalised (divided by 1 - T_final).  Process-global; restore 0 after use."""
+    _lib("raster").oracle_raster_set_depth_mode(int(mode))
+
+
 def raster_forward(means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, W, H, bg,
                    shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
                    scale_modifier=1.0, sh_degree=0, prefiltered=False, dtype=np.float32):
@@ -177,6 +182,7 @@ class OracleGICP:
     def set_regularization_method(self, m): self._set(5, m)
     def set_rotation_epsilon(self, e): self._set(6, e)
     def set_transformation_epsilon(self, e): self._set(7, e)
+    def set_scale_semantics(self, mode): self._set(8, {"stddev": 0, "variance": 1}[mode] if isinstance(mode, str) else int(mode))
 
     def _input(self, is_target, pts):
         pts = np.asarray(pts)

@@ -273,6 +273,7 @@ struct Cloud {
 
 struct Gicp {
     int k = 20, max_iter = 64, lm_max_iter = 10, reg = 3, threads = 0;
+    int scale_mode = 0;           // 0: exported scales = sqrt(eigenvalues), fromqs squares them; 1: variances both ways (SURVEY 8a unknown)
     double max_corr = (double)FLT_MAX, max_knn = (double)FLT_MAX, rot_eps = 2e-3, trans_eps = 5e-4, lm_init = 1e-9;
     Cloud src, tgt;
     std::vector<int> corr;        // per trackable source point: target ORIGINAL index or -1
@@ -359,7 +360,7 @@ void calc_cov(Gicp& g, Cloud& c) {
             eig_sym3(raw, ev, V);
             rot_to_quat_xyzw(V, q);
             for (int d = 0; d < 4; ++d) c.rotq[4 * i + d] = (float)q[d];
-            for (int d = 0; d < 3; ++d) c.scales[3 * i + d] = (float)std::sqrt(std::max(ev[d], 0.0));
+            for (int d = 0; d < 3; ++d) c.scales[3 * i + d] = (float)(g.scale_mode ? std::max(ev[d], 0.0) : std::sqrt(std::max(ev[d], 0.0)));
             regularise(g.reg, ev, V, raw, c.cov.data() + 6 * i);
         }
     }
@@ -526,6 +527,7 @@ void oracle_gicp_set_param(void* h, int which, double v) {
         case 5: g.reg = (int)v; break;
         case 6: g.rot_eps = v; break;
         case 7: g.trans_eps = v; break;
+        case 8: g.scale_mode = (int)v; g.src.cov_valid = g.tgt.cov_valid = false; break;
     }
 }
 void oracle_gicp_set_input(void* h, int is_target, const void* p, int n, int is_f64) {
@@ -571,8 +573,9 @@ int oracle_gicp_set_target_cov_fromqs(void* h, const float* rots, int n_rots, co
         if (nrm > 0) for (int d = 0; d < 4; ++d) q[d] /= nrm; else { q[0] = q[1] = q[2] = 0; q[3] = 1; }
         double R[9];
         quat_xyzw_to_rot(q, R);
-        const double s2[3] = {(double)scales[3 * i] * scales[3 * i], (double)scales[3 * i + 1] * scales[3 * i + 1],
-                              (double)scales[3 * i + 2] * scales[3 * i + 2]};
+        const double s2[3] = {g.scale_mode ? (double)scales[3 * i] : (double)scales[3 * i] * scales[3 * i],
+                              g.scale_mode ? (double)scales[3 * i + 1] : (double)scales[3 * i + 1] * scales[3 * i + 1],
+                              g.scale_mode ? (double)scales[3 * i + 2] : (double)scales[3 * i + 2] * scales[3 * i + 2]};
         double raw[6];
         int k = 0;
         for (int r = 0; r < 3; ++r)

@@ -258,6 +258,12 @@ void bin_and_sort(const Problem<R>& pb, const std::vector<Splat<R>>& sp, std::ve
 
 template <class R> inline R rel_margin(R v, R th) { return std::fabs(v - th) / th; }
 
+// Depth compositing rule — one of the three fork semantics SURVEY 8(a) could not settle (the fork's rasteriser is an empty submodule):
+//   0 (default): D = sum_i z_i alpha_i T_i                       (what the common depth forks render; no background term)
+//   1          : D = sum_i z_i alpha_i T_i / (1 - T_final)       (alpha-normalised expected depth; 0 where nothing was blended)
+// A process-global knob of the test oracle (set by oracle.raster_set_depth_mode) so that the long entry-point signatures stay put.
+static int g_depth_mode = 0;
+
 template <class R>
 void blend_forward(const Problem<R>& pb, const std::vector<Splat<R>>& sp, const std::vector<uint32_t>& vals,
                    const std::vector<uint32_t>& ranges, R* out_color, R* out_depth, R* final_T, uint32_t* n_contrib,
@@ -295,7 +301,7 @@ void blend_forward(const Problem<R>& pb, const std::vector<Splat<R>>& sp, const 
             }
             const int pix = py * pb.W + px;
             for (int c = 0; c < 3; ++c) out_color[c * HW + pix] = C[c] + T * pb.bg[c];
-            out_depth[pix] = Dz;
+            out_depth[pix] = g_depth_mode == 1 ? (T < R(1) ? Dz / (R(1) - T) : R(0)) : Dz;
             final_T[pix] = T;
             n_contrib[pix] = last;
             if (margin) margin[pix] = mg;
@@ -312,7 +318,7 @@ template <class R> struct Grads {
 template <class R>
 void blend_backward(const Problem<R>& pb, const std::vector<Splat<R>>& sp, const std::vector<uint32_t>& vals,
                     const std::vector<uint32_t>& ranges, const R* final_T, const uint32_t* n_contrib,
-                    const R* dL_dpix /*3HW*/, const R* dL_ddepth /*HW or null*/, Grads<R>& g) {
+                    const R* dL_dpix /*3HW*/, const R* dL_ddepth /*HW or null*/, const R* out_depth /*HW, forward output*/, Grads<R>& g) {
     const int gx = (pb.W + TILE - 1) / TILE;
     const int HW = pb.W * pb.H;
     g.mean2D.assign((size_t)2 * pb.P, 0); g.conic.assign((size_t)3 * pb.P, 0);
@@ -331,6 +337,12 @@ void blend_backward(const Problem<R>& pb, const std::vector<Splat<R>>& sp, const
             const R pfx = R(px), pfy = R(py);
             R bg_dot = 0;
             for (int c = 0; c < 3; ++c) bg_dot += pb.bg[c] * dpix[c];
+            if (g_depth_mode == 1) {
+                // D = N / A, A = 1 - T_final: dD/dalpha_i = (dN/dalpha_i) / A - (N / A^2) T_final / (1 - alpha_i).  The first term is the
+                // un-normalised rule with the incoming gradient divided by A; the second has the form of the background term.
+                const R A = R(1) - T_final;
+                if (A > R(0)) { bg_dot += dpix[3] * out_depth[pix] / A; dpix[3] = dpix[3] / A; } else dpix[3] = 0;
+            }
             for (uint32_t kk = last; kk-- > 0;) {
                 const uint32_t id = vals[b + kk];
                 const Splat<R>& s = sp[id];
@@ -602,7 +614,7 @@ int backward_impl(int P, int D, int M, const R* bg, int W, int H, const R* means
     std::vector<R> color(3 * (size_t)HW), depth(HW), fT(HW); std::vector<uint32_t> nc(HW);
     blend_forward(pb, sp, vals, ranges, color.data(), depth.data(), fT.data(), nc.data(), (int*)nullptr, (R*)nullptr);
     Grads<R> g;
-    blend_backward(pb, sp, vals, ranges, fT.data(), nc.data(), dL_dpix, dL_ddepth, g);
+    blend_backward(pb, sp, vals, ranges, fT.data(), nc.data(), dL_dpix, dL_ddepth, depth.data(), g);
     for (int i = 0; i < P; ++i) {
         if (dL_dmeans2D) { dL_dmeans2D[3 * i] = (R)g.mean2D[2 * i]; dL_dmeans2D[3 * i + 1] = (R)g.mean2D[2 * i + 1]; dL_dmeans2D[3 * i + 2] = 0; }
         if (dL_dconic) for (int k = 0; k < 3; ++k) dL_dconic[3 * i + k] = (R)g.conic[3 * i + k];
@@ -617,6 +629,7 @@ int backward_impl(int P, int D, int M, const R* bg, int W, int H, const R* means
 }  // namespace
 
 extern "C" {
+void oracle_raster_set_depth_mode(int m) { g_depth_mode = m; }
 
 #define FWD_ARGS(R)                                                                                                        \
     int P, int D, int M, const R *bg, int W, int H, const R *means3D, const R *shs, const R *colors_precomp,               \

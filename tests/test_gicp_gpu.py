@@ -158,6 +158,28 @@ def test_non_plane_regularisation_matches_oracle(method, fromqs):
     np.testing.assert_allclose(pp["T"], po["T"], rtol=0, atol=2e-6)
 
 
+def test_variance_scale_semantics_round_trips_and_matches_oracle():
+    """set_scale_semantics("variance") (SURVEY 8a unknown, exposed as an option): exported scales are eigenvalues, fromqs consumes
+    them as they are.  The covariance that round-trips through (rotationsq, scales) -> fromqs must be the one the std-dev semantics
+    round-trips, so poses agree between the two semantics; and each semantics agrees with the oracle's instance of it."""
+    import oracle
+    import pygicp
+    cfg = synth.TUM
+    sp = synth.s_pair(cfg, noise=True)
+    out = {}
+    for mode in ("stddev", "variance"):
+        oreg, reg = oracle.OracleGICP(), pygicp.FastGICP()
+        oreg.set_scale_semantics(mode)
+        reg.set_scale_semantics(mode)
+        out[mode] = (drive(oreg, sp, cfg, True), drive(reg, sp, cfg, True))
+        po, pp = out[mode]
+        np.testing.assert_allclose(pp["scales"], po["scales"], rtol=4e-5, atol=1e-9)
+        assert np.array_equal(pp["idx"], po["idx"]) and np.array_equal(pp["d2"], po["d2"])
+        np.testing.assert_allclose(pp["T"], po["T"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["variance"][1]["scales"], out["stddev"][1]["scales"].astype(np.float64) ** 2, rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(out["variance"][1]["T"], out["stddev"][1]["T"], rtol=0, atol=2e-5)   # float32 export of s vs s^2 rounds differently
+
+
 def test_known_answer_rigid_motion():
     """Source = target moved by a known SE(3): GICP must recover it (no sampling difference, wide gate)."""
     import pygicp

@@ -94,3 +94,38 @@ def test_quaternion_order_is_xyzw():
     assert abs((xs.max() - xs.min()) - (ys.max() - ys.min())) <= 2
     ys, xs = np.nonzero(edge > 0.05)
     assert (xs.max() - xs.min()) > 4 * (ys.max() - ys.min())
+
+
+def test_alpha_normalised_depth_rule_backward_matches_finite_differences():
+    """The oracle's instance of the optional depth rule D = sum z alpha T / (1 - T_final) (depth_mode 1): analytic gradients in fp64
+    against central differences."""
+    import oracle
+    from gs_icp_slam_amd import synth
+    from tests import util
+    cam = synth.make_camera(48, 32, 40.0, 40.0)
+    g = {k: v.astype(np.float64) for k, v in synth.random_gaussians(12, seed=3, spread=0.5, zmin=1.5, zmax=3.0).items()}
+    rng = np.random.default_rng(0)
+    gc, gd = rng.normal(size=(3, 32, 48)), rng.normal(size=(32, 48))
+    bg = [0.1, 0.2, 0.3]
+    oracle.raster_set_depth_mode(1)
+    try:
+        def loss(gg):
+            o = util.oracle_forward(gg, cam, bg, 0, dtype=np.float64)
+            return (o["color"] * gc).sum() + (o["depth"] * gd).sum()
+        b = util.oracle_backward(g, cam, bg, gc, gd, 0, dtype=np.float64)
+        plain = util.oracle_forward(g, cam, bg, 0, dtype=np.float64)
+        for name, key, picks in (("opacities", "dL_dopacity", [(0, 0), (3, 0), (7, 0)]), ("means3D", "dL_dmeans3D", [(0, 0), (3, 2), (7, 1)]),
+                                 ("scales", "dL_dscales", [(1, 0), (5, 2)]), ("rotations", "dL_drots", [(2, 1), (9, 3)])):
+            for idx in picks:
+                h = 1e-6
+                gp, gm = {k: v.copy() for k, v in g.items()}, {k: v.copy() for k, v in g.items()}
+                gp[name][idx] += h
+                gm[name][idx] -= h
+                fd = (loss(gp) - loss(gm)) / (2 * h)
+                an = b[key].reshape(g[name].shape)[idx]
+                assert abs(fd - an) <= 1e-5 * (abs(an) + 1e-3), (name, idx, fd, an)
+    finally:
+        oracle.raster_set_depth_mode(0)
+    zero = util.oracle_forward(g, cam, bg, 0, dtype=np.float64)
+    cover = zero["final_T"] < 1.0
+    np.testing.assert_allclose(plain["depth"][cover], (zero["depth"] / (1.0 - zero["final_T"] + (~cover)))[cover], rtol=1e-12)

@@ -16,11 +16,11 @@ TOL = 1e-5
 FRAGILE = 1e-5
 
 
-def run_product(g, cam, bg, sh_degree=0, grads=None, tile_mod=1, tile_rem=0):
+def run_product(g, cam, bg, sh_degree=0, grads=None, tile_mod=1, tile_rem=0, depth_mode=0):
     import torch
     from diff_gaussian_rasterization import GaussianRasterizer
     t = util.torch_inputs(g, requires_grad=grads is not None)
-    rs = util.make_settings(cam, bg, sh_degree, tile_mod=tile_mod, tile_rem=tile_rem)
+    rs = util.make_settings(cam, bg, sh_degree, tile_mod=tile_mod, tile_rem=tile_rem, depth_mode=depth_mode)
     means2D = torch.zeros_like(t["means3D"], requires_grad=True)
     rast = GaussianRasterizer(raster_settings=rs)
     depth, color, radii, is_used = rast(means3D=t["means3D"], means2D=means2D, shs=t.get("shs"), colors_precomp=t.get("colors_precomp"),
@@ -299,6 +299,40 @@ def test_full_size_smap_backward(hip_lib, res):
     depth = int(max(tile_len[ty * gx + tx] for ty in range(ty0, ty1 + 1) for tx in range(tx0, tx1 + 1)))
     print(f"S-map backward {res}: fragile px {len(fy)}, Gaussians near them {int(near.sum())}/{n_vis}, worst Gaussian {wg} "
           f"(longest tile list it sits in: {depth}), per-gradient {report}")
+
+
+def test_alpha_normalised_depth_mode_forward_and_backward(hip_lib):
+    """depth_mode = 1 (SURVEY 8a unknown, exposed as an option): D = sum z alpha T / (1 - T_final).  Forward image and all six
+    gradients against the oracle's instance of the same rule; colours are untouched by the option."""
+    import oracle
+    cam = synth.make_camera(160, 96, 120.0, 120.0)
+    g = synth.random_gaussians(400, seed=41)
+    rng = np.random.default_rng(3)
+    gc = rng.normal(size=(3, 96, 160)).astype(np.float32)
+    gd = rng.normal(size=(96, 160)).astype(np.float32)
+    bg = [0.2, 0.1, 0.3]
+    base = run_product(g, cam, bg, 0, grads=(gc, gd))
+    oracle.raster_set_depth_mode(1)
+    try:
+        of = util.oracle_forward(g, cam, bg, 0)
+        o = util.oracle_backward(g, cam, bg, gc, gd, 0)
+        o64 = util.oracle_backward({k: v.astype(np.float64) for k, v in g.items()}, cam, bg, gc, gd, 0, dtype=np.float64)
+    finally:
+        oracle.raster_set_depth_mode(0)
+    p = run_product(g, cam, bg, 0, grads=(gc, gd), depth_mode=1)
+    ok = of["margin"] > FRAGILE
+    assert np.array_equal(p["color"], base["color"])
+    assert np.abs(p["depth"] - of["depth"])[ok].max() <= 1e-5 * max(1.0, float(of["depth"].max()))
+    assert np.abs(p["depth"] - base["depth"]).max() > 0.1          # the option changes the image
+    covered = of["final_T"] < 0.5
+    assert np.all(p["depth"][covered] >= base["depth"][covered] - 1e-6)   # dividing by accumulated alpha <= 1 can only raise it
+    for name, key in [("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"), ("rotations", "dL_drots"),
+                      ("shs", "dL_dsh"), ("means2D", "dL_dmeans2D")]:
+        a, b, b64 = p["grads"][name].reshape(-1).astype(np.float64), o[key].reshape(-1).astype(np.float64), o64[key].reshape(-1)
+        mx = np.abs(b).max()
+        err = np.abs(a - b)
+        assert (err <= 2e-4 * mx + 1e-4 * np.abs(b) + 2 * np.abs(b - b64)).all(), f"{name}: {err.max() / mx:.3e} of max"
+        assert np.abs(a - base["grads"][name].reshape(-1)).max() > 1e-3 * mx or name == "shs"   # depth gradients differ from mode 0
 
 
 def test_long_tile_lists_use_the_fallback_sort(hip_lib):

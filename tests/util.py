@@ -14,7 +14,7 @@ def torch_inputs(g, device="cuda", requires_grad=False):
     return out
 
 
-def make_settings(cam, bg, sh_degree=0, device="cuda", tile_mod=1, tile_rem=0):
+def make_settings(cam, bg, sh_degree=0, device="cuda", tile_mod=1, tile_rem=0, depth_mode=0):
     import torch
     from diff_gaussian_rasterization import GaussianRasterizationSettings
     return GaussianRasterizationSettings(
@@ -22,7 +22,7 @@ def make_settings(cam, bg, sh_degree=0, device="cuda", tile_mod=1, tile_rem=0):
         bg=torch.tensor(bg, dtype=torch.float32, device=device), scale_modifier=1.0,
         viewmatrix=torch.from_numpy(cam["viewmatrix"]).to(device), projmatrix=torch.from_numpy(cam["projmatrix"]).to(device),
         sh_degree=sh_degree, campos=torch.from_numpy(cam["campos"]).to(device), prefiltered=False, debug=False,
-        tile_mod=tile_mod, tile_rem=tile_rem)
+        tile_mod=tile_mod, tile_rem=tile_rem, depth_mode=depth_mode)
 
 
 def oracle_forward(g, cam, bg, sh_degree=0, dtype=np.float32, **kw):
