@@ -19,7 +19,7 @@ def _p(t):
 
 class _Activate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, opacity_raw, scaling_raw, rotation_raw):
+    def forward(ctx, opacity_raw, scaling_raw, rotation_raw, live_rows=None):
         lib = _lib.load()
         if not opacity_raw.is_cuda:
             raise RuntimeError("activate (gfx950): tensors must live on the HIP device; there is no CPU path")
@@ -32,15 +32,15 @@ class _Activate(torch.autograd.Function):
         o, s, q = torch.empty_like(o_r), torch.empty_like(s_r), torch.empty_like(q_r)
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.gsicp_mapper_activations_forward(P, _p(o_r), _p(s_r), _p(q_r), _p(o), _p(s), _p(q), stream),
+            _lib.check(lib.gsicp_mapper_activations_forward(P, _p(o_r), _p(s_r), _p(q_r), _p(o), _p(s), _p(q), _p(live_rows), stream),
                        "gsicp_mapper_activations_forward")
-        ctx.save_for_backward(o, s, q_r)
+        ctx.save_for_backward(o, s, q_r, live_rows)
         return o, s, q
 
     @staticmethod
     def backward(ctx, g_o, g_s, g_q):
         lib = _lib.load()
-        o, s, q_r = ctx.saved_tensors
+        o, s, q_r, live_rows = ctx.saved_tensors
         dev = o.device
         P = q_r.shape[0]
         need = ctx.needs_input_grad
@@ -52,10 +52,13 @@ class _Activate(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(lib.gsicp_mapper_activations_backward(P, _p(o), _p(s), _p(q_r), _p(g_o), _p(g_s), _p(g_q), _p(d_o), _p(d_s), _p(d_q),
-                                                             stream), "gsicp_mapper_activations_backward")
-        return d_o, d_s, d_q
+                                                             _p(live_rows), stream), "gsicp_mapper_activations_backward")
+        return d_o, d_s, d_q, None
 
 
-def activate(opacity_raw, scaling_raw, rotation_raw):
-    """-> (sigmoid(opacity_raw), exp(scaling_raw), normalize(rotation_raw)), differentiable."""
-    return _Activate.apply(opacity_raw, scaling_raw, rotation_raw)
+def activate(opacity_raw, scaling_raw, rotation_raw, live_rows=None):
+    """-> (sigmoid(opacity_raw), exp(scaling_raw), normalize(rotation_raw)), differentiable.
+    live_rows: optional int32[1] DEVICE tensor — only the first live_rows[0] rows are Gaussians (capacity-backed map: the inputs are
+    the full-capacity buffers, their live count changes on the device without changing any pointer; outputs of the other rows are
+    unspecified, their gradients zero)."""
+    return _Activate.apply(opacity_raw, scaling_raw, rotation_raw, live_rows)

@@ -383,6 +383,7 @@ struct AdamTable {
     long long end[ADAM_MAX_GROUPS];    // exclusive prefix end of each group in the flattened index space
     float step_size[ADAM_MAX_GROUPS];  // lr / (1 - beta1^t)
     int src[ADAM_MAX_GROUPS];          // index of the group in the caller's arrays (empty tensors are squeezed out)
+    int row_width[ADAM_MAX_GROUPS];    // elements per map row (live-row mode), 0 = whole tensor
     int n;
 };
 
@@ -408,7 +409,8 @@ __device__ inline AdamPMV adam_update(float p, float m, float v, float g, float 
 template <bool CAPTURABLE>
 __global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const double* __restrict__ lr_dev, const int* __restrict__ step_dev,
                                                           float beta1, float beta2, float eps, float inv_bc2_sqrt_host,
-                                                          const unsigned* __restrict__ guard_count, unsigned guard_limit) {
+                                                          const unsigned* __restrict__ guard_count, unsigned guard_limit,
+                                                          const int* __restrict__ live_rows) {
     __shared__ double s_bc1;
     __shared__ float s_inv_bc2_sqrt;
     if (CAPTURABLE && guard_count && *guard_count > guard_limit) return;   // wave-uniform (one scalar load)
@@ -425,7 +427,11 @@ __global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const dou
     const float inv_bc2_sqrt = CAPTURABLE ? s_inv_bc2_sqrt : inv_bc2_sqrt_host;
     const float step_size = CAPTURABLE ? (float)(lr_dev[t.src[gidx]] / s_bc1)   // the host path's formula, in double like torch's
                                        : t.step_size[gidx];
-    const long long numel = t.end[gidx] - (gidx ? t.end[gidx - 1] : 0);
+    long long numel = t.end[gidx] - (gidx ? t.end[gidx - 1] : 0);
+    if (live_rows && t.row_width[gidx] > 0) {                  // capacity-backed map: only the live rows are parameters
+        const long long live = (long long)*live_rows * t.row_width[gidx];
+        numel = live < numel ? live : numel;
+    }
     float* __restrict__ P = t.p[gidx];
     const float* __restrict__ G = t.g[gidx];
     float* __restrict__ M = t.m[gidx];
@@ -463,9 +469,9 @@ __global__ void adam_bump_step_kernel(int* step_dev, const unsigned* __restrict_
 // launch for the three of them (the torch chain is ~8 launches forward and ~12 backward at ~5 us each).
 __global__ __launch_bounds__(256) void activations_forward_kernel(int P, const float* __restrict__ o_raw, const float* __restrict__ s_raw,
                                                                   const float4* __restrict__ q_raw, float* __restrict__ o,
-                                                                  float* __restrict__ s, float4* __restrict__ q) {
+                                                                  float* __restrict__ s, float4* __restrict__ q, const int* __restrict__ live_rows) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
+    if (i >= P || (live_rows && i >= *live_rows)) return;     // rows behind the live count are not Gaussians: outputs left alone
     o[i] = 1.f / (1.f + expf(-o_raw[i]));
 #pragma unroll
     for (int d = 0; d < 3; ++d) s[3 * (size_t)i + d] = expf(s_raw[3 * (size_t)i + d]);
@@ -478,9 +484,15 @@ __global__ __launch_bounds__(256) void activations_backward_kernel(int P, const 
                                                                    const float4* __restrict__ q_raw, const float* __restrict__ g_o,
                                                                    const float* __restrict__ g_s, const float4* __restrict__ g_q,
                                                                    float* __restrict__ d_o_raw, float* __restrict__ d_s_raw,
-                                                                   float4* __restrict__ d_q_raw) {
+                                                                   float4* __restrict__ d_q_raw, const int* __restrict__ live_rows) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
+    if (live_rows && i >= *live_rows) {                        // not a Gaussian: zero gradient (its activations were never computed)
+        if (d_o_raw) d_o_raw[i] = 0.f;
+        if (d_s_raw) { d_s_raw[3 * (size_t)i] = 0.f; d_s_raw[3 * (size_t)i + 1] = 0.f; d_s_raw[3 * (size_t)i + 2] = 0.f; }
+        if (d_q_raw) d_q_raw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     if (d_o_raw) { const float ov = o[i]; d_o_raw[i] = g_o ? g_o[i] * ov * (1.f - ov) : 0.f; }
     if (d_s_raw) {
 #pragma unroll
@@ -602,25 +614,25 @@ int gsicp_mapper_set_view(int width, int height, const float* viewmatrix, const 
 }
 
 int gsicp_mapper_activations_forward(int P, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* opacity,
-                                     float* scaling, float* rotation, void* stream) {
+                                     float* scaling, float* rotation, const int* live_rows_dev, void* stream) {
     if (P < 0 || (P > 0 && (!opacity_raw || !scaling_raw || !rotation_raw || !opacity || !scaling || !rotation))) {
         g_last_error = "gsicp_mapper_activations_forward: bad arguments"; return -2;
     }
     if (P == 0) return 0;
     hipLaunchKernelGGL(activations_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, opacity_raw, scaling_raw,
-                       (const float4*)rotation_raw, opacity, scaling, (float4*)rotation);
+                       (const float4*)rotation_raw, opacity, scaling, (float4*)rotation, live_rows_dev);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_activations_forward: kernel launch failed"; return -1; }
     return 0;
 }
 
 int gsicp_mapper_activations_backward(int P, const float* opacity, const float* scaling, const float* rotation_raw, const float* dL_dopacity,
                                       const float* dL_dscaling, const float* dL_drotation, float* dL_dopacity_raw, float* dL_dscaling_raw,
-                                      float* dL_drotation_raw, void* stream) {
+                                      float* dL_drotation_raw, const int* live_rows_dev, void* stream) {
     if (P < 0 || (P > 0 && (!opacity || !scaling || !rotation_raw))) { g_last_error = "gsicp_mapper_activations_backward: bad arguments"; return -2; }
     if (P == 0) return 0;
     hipLaunchKernelGGL(activations_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, opacity, scaling,
                        (const float4*)rotation_raw, dL_dopacity, dL_dscaling, (const float4*)dL_drotation, dL_dopacity_raw, dL_dscaling_raw,
-                       (float4*)dL_drotation_raw);
+                       (float4*)dL_drotation_raw, live_rows_dev);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_activations_backward: kernel launch failed"; return -1; }
     return 0;
 }
@@ -636,10 +648,12 @@ static long long adam_table(AdamTable& t, int n_groups, float* const* params, co
         t.end[t.n] = total;
         t.step_size[t.n] = lr ? (float)((double)lr[k] / bc1) : 0.f;
         t.src[t.n] = k;
+        t.row_width[t.n] = 0;
         ++t.n;
     }
     for (int k = t.n; k < ADAM_MAX_GROUPS; ++k) {
         t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.end[k] = total; t.step_size[k] = 0.f; t.src[k] = 0;
+        t.row_width[k] = 0;
     }
     return total;
 }
@@ -662,7 +676,7 @@ int gsicp_adam_step(int n_groups, float* const* params, const float* const* grad
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, bc1);
     if (total == 0) return 0;
     hipLaunchKernelGGL(adam_tensor_kernel<false>, adam_grid(t), dim3(256), 0, stream, t, (const double*)nullptr, (const int*)nullptr, beta1, beta2, eps,
-                       (float)(1.0 / std::sqrt(bc2)), (const unsigned*)nullptr, 0u);
+                       (float)(1.0 / std::sqrt(bc2)), (const unsigned*)nullptr, 0u, (const int*)nullptr);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step: kernel launch failed"; return -1; }
     return 0;
 }
@@ -670,16 +684,18 @@ int gsicp_adam_step(int n_groups, float* const* params, const float* const* grad
 int gsicp_adam_step_guarded(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
                             float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
                             float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
-                            unsigned int* skipped_dev, void* stream_v) {
+                            unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, void* stream_v) {
     hipStream_t stream = (hipStream_t)stream_v;
     if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || !lr_dev || !step_dev) {
         g_last_error = "gsicp_adam_step_capturable: 1..8 tensors, device lr array and device step counter"; return -2;
     }
     AdamTable t;
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, nullptr, 1.0);
+    if (live_rows_dev && row_width)
+        for (int k = 0; k < t.n; ++k) t.row_width[k] = row_width[t.src[k]];
     if (total > 0)
         hipLaunchKernelGGL(adam_tensor_kernel<true>, adam_grid(t), dim3(256), 0, stream, t, lr_dev, (const int*)step_dev, beta1, beta2, eps, 0.f,
-                           guard_count, guard_limit);
+                           guard_count, guard_limit, (live_rows_dev && row_width) ? live_rows_dev : (const int*)nullptr);
     if (bump_step)
         hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, stream, step_dev, guard_count, guard_limit, skipped_dev);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step_capturable: kernel launch failed"; return -1; }
@@ -690,7 +706,7 @@ int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* 
                                float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
                                float eps, int* step_dev, void* stream_v) {
     return gsicp_adam_step_guarded(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr_dev, beta1, beta2, eps, step_dev, 1, nullptr, 0u,
-                                   nullptr, stream_v);
+                                   nullptr, nullptr, nullptr, stream_v);
 }
 
 }  // extern "C"

@@ -77,6 +77,7 @@ inline ImgLayout img_layout(int W, int H) {
 
 struct PreprocessArgs {
     int P, D, M, W, H;
+    const int* live_rows;      // DEVICE, optional: only rows [0, min(P, *live_rows)) are Gaussians (capacity-backed map, captured graphs)
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     float scale_modifier;
     const float *view, *proj, *campos;
@@ -93,6 +94,7 @@ static_assert(sizeof(SplatRec) == 48, "SplatRec must stay 48 bytes");
 
 struct PreprocessBwdArgs {
     int P, D, M, W, H;
+    const int* live_rows;      // DEVICE, optional (see PreprocessArgs)
     const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;
     float scale_modifier;
     const float *view, *proj, *campos;

@@ -139,6 +139,7 @@ __device__ inline void sh_to_rgb(int deg, const float* mean, const float* campos
 __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool in_range = idx < a.P;
+    const bool live = in_range && (a.live_rows == nullptr || idx < *a.live_rows);   // rows behind the live count are culled Gaussians
     uint32_t mine = 0;    // emission slots this Gaussian needs (tiles of this rank it touches)
     if (in_range) {
     Cam cam;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
     pv[0] = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
     pv[1] = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
     pv[2] = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
-    bool ok = pv[2] > 0.2f;
+    bool ok = live && pv[2] > 0.2f;
     if (ok) {
         const float ph0 = cam.p[0] * p[0] + cam.p[4] * p[1] + cam.p[8] * p[2] + cam.p[12];
         const float ph1 = cam.p[1] * p[0] + cam.p[5] * p[1] + cam.p[9] * p[2] + cam.p[13];
@@ -327,14 +328,14 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     float dm[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool visible = a.radii[i] > 0;
+    const bool visible = a.radii[i] > 0 && (a.live_rows == nullptr || i < *a.live_rows);
     const bool use_sh = (a.colors_precomp == nullptr) && (a.dL_dsh != nullptr);
     // screen-space gradient sums of this Gaussian: its emission slots are one contiguous run of entry_sum
     float gs[NGRAD];
 #pragma unroll
     for (int c = 0; c < NGRAD; ++c) gs[c] = 0.f;
     {
-        const uint32_t n_slots = (*a.total_counter > a.capacity) ? 0u : a.tiles_touched[i];
+        const uint32_t n_slots = (!visible || *a.total_counter > a.capacity) ? 0u : a.tiles_touched[i];
         const float4* es = (const float4*)a.entry_sum + 3 * (size_t)a.slot_base[i];
         // four records (twelve 16-byte loads) in flight per round: the Gaussian with the longest run sets the pace of its wave;
         // the additions stay in slot order, so the sums are bit-identical to the one-at-a-time loop

@@ -15,6 +15,12 @@ the per-Gaussian statistics.  The live tensors are views `[:n]` of the current s
     (same `state[p] = {"step", "exp_avg", "exp_avg_sq"}` layout), so `torch.optim.Adam` and `FusedAdam` both keep working.
 
 The values equal the reference's cat / mask results bit for bit (tests/test_store_gpu.py).
+
+`GaussianStore(stable=True)` additionally keeps every ADDRESS fixed for the lifetime of the store: `params` are Parameters over the
+full-capacity buffers (never re-created), the optimiser's moments are the full-capacity moment buffers, and the live count lives in a
+device int (`live_count`).  `append` writes rows in place and bumps the count; `prune` compacts into the second buffer set and copies the
+survivors back.  Kernels that take `live_count` (rasteriser, activations, FusedAdam — include/gsicp_hip.h `live_rows_dev`) ignore the
+rows behind it, so a captured mapper iteration (gs_icp_slam_amd/graph.py) survives keyframes and pruning without being re-captured.
 """
 import ctypes
 
@@ -48,8 +54,9 @@ def rows_from_gicp(points, colors, rots, scales, z_values, trackable_idxs=None, 
 
 
 class GaussianStore:
-    def __init__(self, capacity, n_rest=0, device="cuda"):
+    def __init__(self, capacity, n_rest=0, device="cuda", stable=False):
         self.capacity, self.n_rest, self.device = int(capacity), int(n_rest), torch.device(device)
+        self.stable = bool(stable)
         self.n = 0
         shapes = {"xyz": (3,), "f_dc": (1, 3), "f_rest": (self.n_rest, 3), "opacity": (1,), "scaling": (3,), "rotation": (4,)}
         self._shapes = shapes
@@ -84,9 +91,22 @@ class GaussianStore:
     def trackable_mask(self):
         return self.view("aux", "trackable_mask").bool()
 
+    @property
+    def live_count(self):
+        """int32[1] device tensor holding n (stable mode: what the kernels read instead of a host-side P)."""
+        return self._n_dev
+
+    def live(self, name):
+        """Detached [:n] view of a parameter buffer, whatever the mode (for reading: hand-off to the tracker, statistics)."""
+        return self._buf("p", name)[: self.n]
+
     def _rebind(self):
         """New Parameter views of the current set / length, re-keyed into the optimiser the way the reference does it
         [REF scene/gaussian_model.py:399-406, 415-424, 461-471]."""
+        if self.stable:
+            if not self.params:   # once: Parameters over the full-capacity buffers of set 0; nothing is ever re-created or re-keyed
+                self.params = {k: nn.Parameter(self._sets[0][("p", k)], requires_grad=True) for k in PARAM_NAMES}
+            return
         old = self.params
         self.params = {k: nn.Parameter(self.view("p", k), requires_grad=True) for k in PARAM_NAMES}
         if self.optimizer is None:
@@ -118,7 +138,10 @@ class GaussianStore:
                 step = shared_step if shared_step is not None else 0
             else:
                 step = torch.tensor(0.0)                           # torch.optim.Adam keeps a float32 CPU scalar
-            self.optimizer.state[self.params[k]] = {"step": step, "exp_avg": self.view("m", k), "exp_avg_sq": self.view("v", k)}
+            m, v = (self._sets[0][("m", k)], self._sets[0][("v", k)]) if self.stable else (self.view("m", k), self.view("v", k))
+            self.optimizer.state[self.params[k]] = {"step": step, "exp_avg": m, "exp_avg_sq": v}
+        if self.stable and hasattr(self.optimizer, "set_live_rows"):
+            self.optimizer.set_live_rows(self._n_dev)
         return self.optimizer
 
     # ------------------------------------------------------------------------------------------------ growth
@@ -145,6 +168,7 @@ class GaussianStore:
             if keyframe_idx is not None:
                 self._buf("aux", "keyframe_idx")[lo:hi].copy_(keyframe_idx.reshape(-1).to(torch.int32))
         self.n = hi
+        self._n_dev.fill_(hi)          # a launch with the scalar in its arguments: no host synchronisation
         self._rebind()
         return self.params
 
@@ -175,7 +199,18 @@ class GaussianStore:
             _lib.check(lib.gsicp_store_compact(self.n, ctypes.c_void_p(keep.data_ptr()), len(live), S, D, RB,
                                                ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_void_p(self._n_dev.data_ptr()), stream),
                        "gsicp_store_compact")
+        n_old = self.n
         self.n = int(self._n_dev.item())
+        if self.stable:
+            # addresses must not move: the survivors go back into set 0 (the compaction cannot run in place: a parallel scatter would
+            # overwrite rows other threads have not read yet).  Rows [n, n_old) keep stale values; nothing reads them, and append()
+            # rewrites parameters and zeroes moments of the rows it claims.
+            with torch.no_grad():
+                for k in keys:
+                    if src[k][0].numel() > 0 and self.n > 0:
+                        src[k][: self.n].copy_(dst[k][: self.n])
+            del n_old
+            return self.params
         self._cur ^= 1
         self._rebind()
         return self.params

@@ -23,13 +23,13 @@ from .optim import FusedAdam
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
-def default_activations(p):
+def default_activations(p, live_rows=None):
     """GaussianModel's property getters [REF scene/gaussian_model.py:105-125] on the raw parameter tensors (one fused launch)."""
-    opacities, scales, rotations = activate(p["opacities"], p["scales"], p["rotations"])
+    opacities, scales, rotations = activate(p["opacities"], p["scales"], p["rotations"], live_rows)
     return dict(means3D=p["means3D"], shs=p["shs"], opacities=opacities, scales=scales, rotations=rotations)
 
 
-def torch_activations(p):
+def torch_activations(p, live_rows=None):
     """The same with the reference's torch ops (sigmoid / exp / normalize)."""
     return dict(means3D=p["means3D"], shs=p["shs"], opacities=torch.sigmoid(p["opacities"]), scales=torch.exp(p["scales"]),
                 rotations=torch.nn.functional.normalize(p["rotations"]))
@@ -41,7 +41,8 @@ class MapperIterationGraph:
     (e.g. 1.5x the count of an eager forward; `overflowed()` tells when it was too small)."""
 
     def __init__(self, params, optimizer, image_height, image_width, tanfovx, tanfovy, sh_degree, capacity, bg=None, lambda_dssim=0.2,
-                 depth_weight=0.1, d_max=10.0, activations=default_activations, rasterizer_factory=None, warmup=2):
+                 depth_weight=0.1, d_max=10.0, activations=default_activations, rasterizer_factory=None, warmup=2, live_count=None,
+                 depth_mode=0):
         if not isinstance(optimizer, FusedAdam) or not optimizer.capturable:
             raise RuntimeError("MapperIterationGraph needs FusedAdam(capturable=True): a host-side step count cannot be replayed")
         if capacity <= 0:
@@ -62,7 +63,13 @@ class MapperIterationGraph:
         rs = GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=float(tanfovx), tanfovy=float(tanfovy), bg=self.bg, scale_modifier=1.0,
             viewmatrix=self.viewmatrix, projmatrix=self.projmatrix, sh_degree=int(sh_degree), campos=self.campos, prefiltered=False,
-            debug=False, capacity=self.capacity)
+            debug=False, capacity=self.capacity, live_count=live_count, depth_mode=int(depth_mode))
+        # live_count (int32[1] device tensor): `params` are the FULL-CAPACITY buffers of a GaussianStore(stable=True) and only the first
+        # live_count[0] rows are Gaussians.  Growth and pruning then change that number and rows in place — no pointer, shape or launch grid
+        # of the captured iteration changes, so ONE capture serves the whole run [REF mp_Mapper.py:161-195, 244-245 append / prune].
+        self.live_count = live_count
+        if live_count is not None:
+            optimizer.set_live_rows(live_count)
         self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
         self._warmup = int(warmup)
         # device-side overflow guard: a replay whose duplicate count exceeds the capacity renders nothing; the Adam kernels
@@ -105,7 +112,7 @@ class MapperIterationGraph:
         self.gt_depth.copy_(gt_depth.reshape(self.gt_depth.shape), non_blocking=True)
 
     def _iteration(self):
-        a = self.activations(self.params)
+        a = self.activations(self.params, self.live_count) if self.live_count is not None else self.activations(self.params)
         depth, color, radii, used = self.rasterizer(means3D=a["means3D"], means2D=self._means2D, shs=a["shs"], opacities=a["opacities"],
                                                     scales=a["scales"], rotations=a["rotations"])
         # the loss kernels produce dL/dimage and dL/ddepth directly: no autograd node, no ones_like / multiply launches

@@ -26,6 +26,14 @@ class FusedAdam(torch.optim.Optimizer):
         self._lr_dev = {}       # (group index, position, betas, eps) bucket key -> [device double tensor, host lr values it holds]
         self._guard = None      # (count tensor uint32/int32[1], limit): skip the step when count > limit (capturable path)
         self.skipped_steps = None   # device int32[1], sticky: steps skipped by the guard since construction (read it whenever convenient)
+        self._live_rows = None      # device int32[1]: parameters are capacity-backed, only this many leading rows are updated
+
+    def set_live_rows(self, n_dev):
+        """Capturable path: the parameter tensors are the full-capacity buffers of a preallocated map (GaussianStore); update only the
+        first n_dev[0] rows of each.  n_dev changes on the device (append / prune) without any pointer or launch changing."""
+        if n_dev is not None and (not n_dev.is_cuda or n_dev.dtype != torch.int32 or n_dev.numel() != 1):
+            raise RuntimeError("FusedAdam.set_live_rows: expected an int32[1] device tensor")
+        self._live_rows = n_dev
 
     def set_overflow_guard(self, count, limit):
         """Capturable path: skip the whole step (parameters, moments and step count untouched) whenever `count` (a DEVICE int32[1],
@@ -106,9 +114,13 @@ class FusedAdam(torch.optim.Optimizer):
                 M = (ctypes.c_void_p * n)(*[t[2].data_ptr() for t in items])
                 V = (ctypes.c_void_p * n)(*[t[3].data_ptr() for t in items])
                 N = (ctypes.c_longlong * n)(*[t[0].numel() for t in items])
+                live_ptr, RW = None, None
+                if self._live_rows is not None and self._live_rows.device == dev:
+                    live_ptr = ctypes.c_void_p(self._live_rows.data_ptr())
+                    RW = (ctypes.c_int * n)(*[(t[0].numel() // t[0].shape[0]) if t[0].dim() > 0 and t[0].shape[0] > 0 else 0 for t in items])
                 _lib.check(lib.gsicp_adam_step_guarded(n, P, G, M, V, N, ctypes.c_void_p(lr_dev.data_ptr()), b1, b2, eps,
                                                        ctypes.c_void_p(items[0][5].data_ptr()), int(last_of[sp] == li), guard_ptr, guard_lim,
-                                                       skip_ptr, stream), "gsicp_adam_step_guarded")
+                                                       skip_ptr, live_ptr, RW, stream), "gsicp_adam_step_guarded")
         if not capturing:
             for key in [k for k in self._lr_dev if k not in live_keys]:
                 del self._lr_dev[key]

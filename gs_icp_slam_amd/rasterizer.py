@@ -42,6 +42,9 @@ class GaussianRasterizationSettings(NamedTuple):
     # Extension: depth compositing rule (the fork's rule cannot be read off the reference tree).  0 = sum z alpha T
     # (default), 1 = alpha-normalised (divided by the accumulated alpha 1 - T_final).  Both have exact backward passes.
     depth_mode: int = 0
+    # Extension: int32[1] DEVICE tensor holding the number of live Gaussians when the input tensors are the full-capacity buffers of a
+    # preallocated map (gs_icp_slam_amd/gaussian_store.py): rows behind it are ignored.  Needs capacity > 0 (the sync-free forward).
+    live_count: object = None
 
 
 def _ptr(t):
@@ -112,8 +115,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _ptr(depth), _ptr(radii), _ptr(is_used), int(rs.tile_mod), int(rs.tile_rem), int(bool(rs.debug)),
                     int(getattr(rs, "depth_mode", 0) or 0))
             capacity = int(getattr(rs, "capacity", 0) or 0)
+            live = getattr(rs, "live_count", None)
+            if live is not None and not (capacity > 0 and P > 0):
+                raise RuntimeError("GaussianRasterizationSettings.live_count needs capacity > 0 (the sync-free forward)")
+            if live is not None and (not live.is_cuda or live.dtype != torch.int32 or live.numel() != 1):
+                raise RuntimeError("GaussianRasterizationSettings.live_count must be an int32[1] device tensor")
             if capacity > 0 and P > 0:
-                n = lib.gsicp_raster_forward_async(*args, capacity, _ptr(count_out), stream)
+                n = lib.gsicp_raster_forward_async(*args, capacity, _ptr(count_out), _ptr(live), stream)
             else:
                 n = lib.gsicp_raster_forward(*args, stream)
                 if count_out is not None:
@@ -162,7 +170,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 float(rs.tanfovy), _ptr(radii), _ptr(geom), _ptr(binning), _ptr(img), _ptr(scratch), _ptr(g_color), _ptr(g_depth),
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), _ptr(dL_dmeans3D),
                 _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drots), int(rs.tile_mod), int(rs.tile_rem),
-                int(bool(rs.debug)), ctx.depth_mode, _ptr(depth_out.detach() if depth_out is not None else None), stream)
+                int(bool(rs.debug)), ctx.depth_mode, _ptr(depth_out.detach() if depth_out is not None else None),
+                _ptr(getattr(rs, "live_count", None)), stream)
             _lib.check(rc, "gsicp_raster_backward")
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors if col_c is not None else None, dL_dopacity, dL_dscales, dL_drots,
                 dL_dcov3D if cov_c is not None else None, None, None)

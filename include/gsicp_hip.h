@@ -79,6 +79,10 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
  *   num_rendered_dev: DEVICE uint32 that receives R (may be NULL).  If R > capacity the call renders nothing
  *   (background colour, zero depth, zero gradients) — the caller detects it by reading num_rendered_dev later and
  *   repeats with a larger capacity.
+ *   live_rows_dev: optional DEVICE int.  When non-NULL only rows [0, min(P, *live_rows_dev)) are Gaussians and the rest of the P-row
+ *   arrays is ignored (treated as culled; zero gradients): P is then the CAPACITY of a preallocated map whose live count changes on the
+ *   device — every pointer and launch grid stays what it was, so a captured graph survives map growth and pruning (pass the same
+ *   pointer to gsicp_raster_backward, the activation operators and gsicp_adam_step_guarded).
  * Returns `capacity`; pass that value as `num_rendered` to gsicp_raster_backward_scratch_bytes / gsicp_raster_backward. */
 int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
                                gsicp_resize_fn img_alloc, void* img_user, int P, int D, int M, const float* background,
@@ -87,7 +91,7 @@ int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                                float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode,
-                               int capacity, unsigned int* num_rendered_dev, void* stream);
+                               int capacity, unsigned int* num_rendered_dev, const int* live_rows_dev, void* stream);
 
 /* Bytes of DEVICE scratch gsicp_raster_backward needs (one 48-byte gradient record per (Gaussian, tile) duplicate; contents need no
  * initialisation and are dead after the call). */
@@ -110,7 +114,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
                           const char* img_buffer, char* scratch, const float* dL_dpix, const float* dL_ddepth,
                           float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_ddepths,
                           float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, int tile_mod,
-                          int tile_rem, int debug, int depth_mode, const float* out_depth, void* stream);
+                          int tile_rem, int debug, int depth_mode, const float* out_depth, const int* live_rows_dev, void* stream);
 
 /* present[i] = 1 iff Gaussian i passes the frustum test (view-space z > 0.2).  Asynchronous. */
 int gsicp_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -244,12 +248,12 @@ int gsicp_mapper_set_view(int width, int height, const float* viewmatrix, const 
  * render_3 at [REF gaussian_renderer/__init__.py:263, 273-274]: opacity = sigmoid(opacity_raw) (P), scaling =
  * exp(scaling_raw) (P,3), rotation = rotation_raw / max(||rotation_raw||, 1e-12) (P,4).  All DEVICE float arrays. */
 int gsicp_mapper_activations_forward(int P, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* opacity,
-                                     float* scaling, float* rotation, void* stream);
+                                     float* scaling, float* rotation, const int* live_rows_dev, void* stream);
 /* Chain rule of the above.  `opacity` / `scaling` are the forward OUTPUTS, rotation_raw the forward input; any dL_d*
  * input may be NULL (treated as zero) and any dL_d*_raw output may be NULL (skipped). */
 int gsicp_mapper_activations_backward(int P, const float* opacity, const float* scaling, const float* rotation_raw, const float* dL_dopacity,
                                       const float* dL_dscaling, const float* dL_drotation, float* dL_dopacity_raw, float* dL_dscaling_raw,
-                                      float* dL_drotation_raw, void* stream);
+                                      float* dL_drotation_raw, const int* live_rows_dev, void* stream);
 
 /* One torch.optim.Adam step (amsgrad off, weight decay 0) over up to 8 tensors in one launch — the six parameter
  * groups of GaussianModel [REF scene/gaussian_model.py:222-231], stepped at [REF mp_Mapper.py:247].  Arrays are HOST
@@ -272,11 +276,13 @@ int gsicp_adam_step_capturable(int n_groups, float* const* params, const float* 
  *  - guard: when guard_count (DEVICE) is non-NULL and *guard_count > guard_limit, nothing is updated and the step is not counted;
  *    *skipped_dev (DEVICE, optional, sticky) is incremented instead.  Pass the rasteriser's num_rendered_dev and its list capacity:
  *    a sync-free forward whose duplicate lists overflowed rendered nothing, and its all-zero gradients must not move the parameters on
- *    stale momentum. */
+ *    stale momentum;
+ *  - live rows: when live_rows_dev (DEVICE int) is non-NULL, tensor k is updated only in its first *live_rows_dev * row_width[k]
+ *    elements (row_width: HOST array of n_groups ints) — the parameters of a capacity-backed map whose live count changes on the device. */
 int gsicp_adam_step_guarded(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
                             float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
                             float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
-                            unsigned int* skipped_dev, void* stream);
+                            unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, void* stream);
 
 /* Map pruning without reallocation: GaussianModel.prune_points / _prune_optimizer
  * [REF scene/gaussian_model.py:409-447] apply one boolean mask to every parameter, both Adam moments and the per-Gaussian

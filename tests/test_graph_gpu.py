@@ -208,3 +208,88 @@ def test_graph_rejects_host_step_optimizer():
     g, cam, params, opt = _mapper_setup(1000, 64, 48, capturable=False)
     with pytest.raises(RuntimeError):
         MapperIterationGraph(params, opt, 48, 64, cam["tanfovx"], cam["tanfovy"], 0, capacity=1000)
+
+
+def test_one_capture_survives_map_growth_and_pruning():
+    """the map's parameters and Adam moments live in a GaussianStore(stable=True) (full-capacity buffers, live count on
+    the device).  ONE captured MapperIterationGraph then keeps replaying across append (keyframes) and prune with zero re-captures, and every
+    replay equals the eager iteration on the live rows of a reference-style (re-created tensors) map."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gs_icp_slam_amd.gaussian_store import GaussianStore, PARAM_NAMES
+    from gs_icp_slam_amd.graph import MapperIterationGraph, default_activations
+    from gs_icp_slam_amd.loss import mapper_loss_parts
+    from gs_icp_slam_amd.optim import FusedAdam
+    P0, W, H = 12000, 320, 200
+    g, cam = _scene(P0 + 8000, W, H)
+    lrs = {"xyz": 4e-6, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
+
+    def rows(lo, hi):
+        return dict(xyz=torch.from_numpy(g["means3D"][lo:hi]).cuda(), f_dc=torch.from_numpy(g["shs"][lo:hi]).cuda(),
+                    f_rest=torch.zeros((hi - lo, 0, 3), device="cuda"),
+                    opacity=torch.logit(torch.from_numpy(g["opacities"][lo:hi]).clamp(1e-4, 1 - 1e-4)).cuda(),
+                    scaling=torch.log(torch.from_numpy(g["scales"][lo:hi])).cuda(), rotation=torch.from_numpy(g["rotations"][lo:hi]).cuda())
+
+    # graph side: stable store, ONE capture
+    store = GaussianStore(40000, n_rest=0, stable=True)
+    store.append(rows(0, P0))
+    opt_g = store.attach(FusedAdam, lrs, lr=0.0, eps=1e-15, capturable=True)
+    pg = {"means3D": store.params["xyz"], "shs": store.params["f_dc"], "opacities": store.params["opacity"], "scales": store.params["scaling"],
+          "rotations": store.params["rotation"]}
+    ptrs = {k: v.data_ptr() for k, v in pg.items()}
+    # eager side: plain store (tensors re-created on every append / prune, as the reference does), host-step FusedAdam
+    ref = GaussianStore(40000, n_rest=0)
+    ref.append(rows(0, P0))
+    opt_e = ref.attach(FusedAdam, lrs, lr=0.0, eps=1e-15)
+
+    rs = make_settings(cam, [0.0, 0.0, 0.0])
+    g2 = synth.s_map(P0 + 8000, seed=5, perturb_seed=7)
+    t2 = torch_inputs(g2)
+    with torch.no_grad():
+        gt_d, gt_c, _, _ = GaussianRasterizer(rs)(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"],
+                                                  opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
+    mg = MapperIterationGraph(pg, opt_g, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=2_000_000, warmup=1,
+                              live_count=store.live_count)
+    mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_c, gt_d)
+    mg.capture()
+    graph_obj = mg.graph
+
+    def eager_step():
+        pe = {"means3D": ref.params["xyz"], "shs": ref.params["f_dc"], "opacities": ref.params["opacity"], "scales": ref.params["scaling"],
+              "rotations": ref.params["rotation"]}
+        a = default_activations(pe)
+        m2 = torch.zeros_like(a["means3D"], requires_grad=True)
+        depth, color, _, _ = GaussianRasterizer(rs)(means3D=a["means3D"], means2D=m2, shs=a["shs"], opacities=a["opacities"],
+                                                    scales=a["scales"], rotations=a["rotations"])
+        loss, _ = mapper_loss_parts(color, depth, gt_c, gt_d)
+        loss.backward()
+        opt_e.step()
+        opt_e.zero_grad(set_to_none=True)
+        return float(loss.detach())
+
+    def both(n_it):
+        for _ in range(n_it):
+            le = eager_step()
+            lg = float(mg.step())
+            assert not mg.overflowed()
+            np.testing.assert_allclose(lg, le, rtol=2e-5)
+
+    both(3)
+    for lo, hi in ((P0, P0 + 3000), (P0 + 3000, P0 + 8000)):           # two keyframes: new rows in place, live count bumped on the device
+        store.append(rows(lo, hi))
+        ref.append(rows(lo, hi))
+        both(3)
+    remove = torch.rand(store.n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) < 0.25
+    store.prune(remove)                                                 # survivors compacted and copied back: same addresses
+    ref.prune(remove)
+    assert store.n == ref.n and int(store.live_count.item()) == store.n
+    both(3)
+    store.append(rows(0, 1000))                                         # growth after a prune: claimed rows start with zero moments
+    ref.append(rows(0, 1000))
+    both(2)
+    assert mg.graph is graph_obj, "the graph was re-captured"
+    assert all(pg[k].data_ptr() == ptrs[k] for k in pg), "a parameter buffer moved"
+    for name in PARAM_NAMES:
+        if name == "f_rest":
+            continue
+        torch.testing.assert_close(store.live(name), ref.params[name].detach(), rtol=1e-4, atol=1e-6, msg=lambda m, n=name: f"{n}: {m}")
+        torch.testing.assert_close(store._sets[0][("m", name)][: store.n], ref.view("m", name), rtol=1e-3, atol=1e-9)
