@@ -1,7 +1,9 @@
-"""End-to-end functional test: tools/slam_demo.py — front-end kernel, device-tensor tracker inputs, align, overlap statistics,
-keyframe map growth through GaussianStore, mapper iterations as hipGraph replays, device-side map -> tracker hand-off — on synthetic
-frames with a known trajectory.  The script asserts sub-millimetre tracking and a falling mapper loss itself."""
+"""End-to-end functional test: tools/slam_demo.py — front-end kernel, device-tensor tracker inputs, align, overlap statistics, the
+reference's keyframe rules, map growth / pruning through GaussianStore(stable=True), mapper iterations as replays of ONE captured hipGraph
+for the whole run, device-side map -> tracker hand-off — on synthetic frames with a known trajectory.  The script asserts sub-1.5 mm
+tracking, a falling mapper loss and zero graph re-captures itself."""
 import os
+import re
 import subprocess
 import sys
 
@@ -11,8 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_device_resident_slam_loop_tracks_a_known_trajectory():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slam_demo.py"), "5"], capture_output=True, text=True, timeout=300, cwd=ROOT)
-    tail = (r.stdout + r.stderr)[-3000:]
+def test_device_resident_slam_loop_one_graph_for_the_whole_run():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slam_demo.py"), "52", "--iters", "5", "--prune-every", "120"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    tail = (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0 and "slam demo OK" in r.stdout, tail
-    assert r.stdout.count("keyframe:") == 2, tail
+    m = re.search(r"(\d+) tracking \+ (\d+) mapping keyframes, (\d+) prune\(s\), (\d+) mapper iterations, (\d+) Gaussians, graph captures (\d+), re-captures (\d+)", r.stdout)
+    assert m, tail
+    n_tr, n_map, prunes, iters, n_g, captures, recaptures = map(int, m.groups())
+    assert n_tr + n_map >= 5 and prunes >= 1 and captures == 1 and recaptures == 0, tail
+    print(r.stdout[-1500:])
