@@ -738,7 +738,8 @@ struct HostMailbox {
 };
 
 constexpr int AL_T = 256;        // threads per workgroup
-constexpr int AL_MAX_WG = 240;   // <= one workgroup per CU, so every workgroup is resident and the grid barrier is safe
+constexpr int AL_MAX_WG = 240;   // partial-sum table size; the launch is further bounded by the device's occupancy (gsicp_gicp_create) so that
+                                 // every workgroup is resident and the grid barrier is safe; a barrier that still times out re-runs as 1 workgroup
 
 struct AlignSync {               // zeroed once at creation; every launch leaves it zeroed again (the last workgroup out resets it)
     unsigned counter;
@@ -1494,6 +1495,9 @@ struct gsicp_gicp {
     HostMailbox* mailbox = nullptr;        // pinned
     unsigned seq = 0;
     bool stats_pending = false;            // device_us of the last align not read from the events yet
+    int max_resident_wg = 0;               // occupancy bound of the persistent align kernel on this device (grid barrier needs co-residency)
+    bool inject_abort = false;             // test hook: make the next align's first barrier abort (gsicp_gicp_debug_abort_next_align)
+    int barrier_retries = 0;               // aligns that lost their grid barrier and were re-run as one workgroup
     PinnedBuf<int> h_corr;
     PinnedBuf<float> h_sqd;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr, ev_xs = nullptr, ev_xs2 = nullptr;
@@ -1703,6 +1707,15 @@ gsicp_gicp* gsicp_gicp_create(void) {
         g_last_error = "device / pinned allocation failed"; gsicp_gicp_destroy(g); return nullptr;
     }
     std::memset(g->mailbox, 0, sizeof(HostMailbox));
+    {   // the align kernel's grid barrier needs every workgroup resident at once: bound the grid by what this device can hold
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gicp_align_kernel, AL_T, 0) == hipSuccess && per_cu > 0 &&
+            hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            g->max_resident_wg = per_cu * prop.multiProcessorCount;
+        else
+            g->max_resident_wg = 1;   // unknown occupancy: a single workgroup needs no grid barrier
+    }
     return g;
 }
 void gsicp_gicp_destroy(gsicp_gicp* g) {
@@ -1941,17 +1954,35 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     int nwg = (s.n_track + AL_T - 1) / AL_T;
     if (nwg < 1) nwg = 1;
     if (nwg > AL_MAX_WG) nwg = AL_MAX_WG;
-    { gsicp::ProfileScope ps(gsicp::ST_GICP_ALIGN, g->stream);
-      hipLaunchKernelGGL(gicp_align_kernel, dim3(nwg), dim3(AL_T), 0, g->stream, a); }
-    ++launches;
-    GC(hipGetLastError());
-    GC(hipEventRecord(e1, g->stream));
-    if (int rc_ = wait_mailbox(g, &g->mailbox->align_seq, a.seq)) return rc_;
-    g->host_result = g->mailbox->result;
+    if (nwg > g->max_resident_wg) nwg = g->max_resident_wg;   // e.g. a partitioned (CPX) device: fewer, fatter workgroups
+    const float ms = 0.f;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (g->inject_abort && attempt == 0) {   // test hook: the first barrier of this launch sees the abort flag
+            const unsigned one = 1u;
+            GC(hipMemcpyAsync((char*)g->sync.p + offsetof(AlignSync, abort), &one, sizeof(one), hipMemcpyHostToDevice, g->stream));
+            g->inject_abort = false;
+        }
+        { gsicp::ProfileScope ps(gsicp::ST_GICP_ALIGN, g->stream);
+          hipLaunchKernelGGL(gicp_align_kernel, dim3(nwg), dim3(AL_T), 0, g->stream, a); }
+        ++launches;
+        GC(hipGetLastError());
+        GC(hipEventRecord(e1, g->stream));
+        if (int rc_ = wait_mailbox(g, &g->mailbox->align_seq, a.seq)) return rc_;
+        g->host_result = g->mailbox->result;
+        if (g->host_result.failed != 2) break;
+        // The grid barrier gave up: some workgroup never became resident (the GPU was saturated by a co-tenant for longer than the spin
+        // budget) or the abort flag was set.  Barrier state may be stale: drain, reset, and re-run the registration as ONE workgroup —
+        // grid_sum then needs no cross-workgroup barrier at all, so it cannot fail this way (slower, still entirely on the device).
+        (void)hipStreamSynchronize(g->stream);
+        (void)hipMemset(g->sync.p, 0, 128);
+        if (nwg == 1) break;
+        nwg = 1;
+        a.seq = ++g->seq;
+        ++g->barrier_retries;
+    }
     for (int w = 0; w < 2; ++w) { g->src.staged_pending[w] = false; g->tgt.staged_pending[w] = false; }   // everything before the kernel has completed
     g->stats_pending = true;   // the events are read lazily (gsicp_gicp_last_align_stats): e1 completes a few us after the mailbox write
-    const float ms = 0.f;
-    if (g->host_result.failed) { (void)hipStreamSynchronize(g->stream); (void)hipMemset(g->sync.p, 0, 128); }   // an aborted launch may leave barrier state behind
+    if (g->host_result.failed == 2) { g_last_error = "align: the grid barrier timed out even with a single workgroup"; return -1; }
     std::memcpy(out, g->host_result.final_pose, sizeof(double) * 16);
     g->aligned = true; g->dist_exact = false;
     g->stats[0] = launches; g->stats[1] = g->host_result.lm_trials; g->stats[2] = g->host_result.cost;
@@ -2021,6 +2052,8 @@ int gsicp_gicp_last_align_stats(gsicp_gicp* g, double out[6]) {
     std::memcpy(out, g->stats, sizeof(double) * 6);
     return 0;
 }
+int gsicp_gicp_debug_abort_next_align(gsicp_gicp* g) { g->inject_abort = true; return 0; }
+int gsicp_gicp_barrier_retries(gsicp_gicp* g) { return g->barrier_retries; }
 int gsicp_gicp_get_final_hessian(gsicp_gicp* g, double out[36]) { std::memcpy(out, g->host_result.H_final, sizeof(double) * 36); return 0; }
 
 }  // extern "C"

@@ -287,4 +287,8 @@ class FastGICP:
         out = np.empty(6, np.float64)
         self._lib.gsicp_gicp_last_align_stats(self._h, _vp(out))
         return dict(launches=int(out[0]), lm_trials=int(out[1]), cost=float(out[2]), converged=bool(out[3]), device_us=float(out[4]),
-                    failed=bool(out[5]), iterations=getattr(self, "iterations", 0))
+                    failed=bool(out[5]), iterations=getattr(self, "iterations", 0), barrier_retries=int(self._lib.gsicp_gicp_barrier_retries(self._h)))
+
+    def _debug_abort_next_align(self):
+        """Test hook: the next align()'s first grid barrier aborts, exercising the single-workgroup recovery path."""
+        self._lib.gsicp_gicp_debug_abort_next_align(self._h)

@@ -216,6 +216,12 @@ int gsicp_gicp_num_source(gsicp_gicp*);
 int gsicp_gicp_num_target(gsicp_gicp*);
 /* out[0..5]: kernel launches of the last align, LM trials, final cost, converged flag, device microseconds, reserved */
 int gsicp_gicp_last_align_stats(gsicp_gicp*, double out[6]);
+/* Robustness of the persistent align kernel's grid barrier.  The launch never exceeds the number of workgroups the device can hold at
+ * once; if a barrier nevertheless times out (a co-tenant kept some workgroup from becoming resident for ~0.2 s) the registration is re-run
+ * as ONE workgroup, which needs no grid barrier.  gsicp_gicp_barrier_retries() counts such re-runs; gsicp_gicp_debug_abort_next_align()
+ * is a test hook that makes the next align's first barrier abort, so that the recovery path can be exercised deterministically. */
+int gsicp_gicp_debug_abort_next_align(gsicp_gicp* g);
+int gsicp_gicp_barrier_retries(gsicp_gicp* g);
 int gsicp_gicp_get_final_hessian(gsicp_gicp*, double out[36]);
 
 /* --------------------------------------------------------------------------------------------------------

@@ -180,6 +180,30 @@ def test_variance_scale_semantics_round_trips_and_matches_oracle():
     np.testing.assert_allclose(out["variance"][1]["T"], out["stddev"][1]["T"], rtol=0, atol=2e-5)   # float32 export of s vs s^2 rounds differently
 
 
+def test_lost_grid_barrier_recovers_on_the_device():
+    """The persistent align kernel synchronises its workgroups with a hand-rolled grid barrier.  When a barrier gives up (a workgroup that
+    never became resident under a saturating co-tenant, or the abort flag — injected here through the test hook), the registration is re-run
+    as ONE workgroup (no grid barrier to lose) instead of returning a half-optimised pose; the next frame runs multi-workgroup again."""
+    import pygicp
+    cfg = synth.REPLICA
+    sp = synth.s_pair(cfg)
+    reg = pygicp.FastGICP()
+    good = drive(reg, sp, cfg)
+    assert reg.last_align_stats()["barrier_retries"] == 0
+    reg._debug_abort_next_align()
+    reg.set_input_source(sp["points_b"])
+    reg.set_source_filter(len(sp["trackable_b"]), filt(len(sp["points_b"]), sp["trackable_b"]))
+    T = reg.align(sp["pose_a"])
+    st = reg.last_align_stats()
+    assert st["barrier_retries"] == 1 and not st["failed"] and st["converged"]
+    np.testing.assert_allclose(T, good["T"], rtol=0, atol=1e-6)
+    idx, d2 = reg.get_source_correspondence()
+    assert np.array_equal(idx, good["idx"]) and np.array_equal(d2, good["d2"])
+    T2 = reg.align(sp["pose_a"])                       # barrier state was reset: the next launch is a normal one
+    assert reg.last_align_stats()["barrier_retries"] == 1
+    np.testing.assert_allclose(T2, good["T"], rtol=0, atol=1e-6)
+
+
 def test_known_answer_rigid_motion():
     """Source = target moved by a known SE(3): GICP must recover it (no sampling difference, wide gate)."""
     import pygicp

@@ -72,15 +72,30 @@ def _run(rasterizer, g, target):
     return color.detach(), depth.detach(), {k: v.grad.clone() for k, v in t.items()}, used
 
 
+def _scene():
+    g = synth.random_gaussians(120, seed=4)
+    g["means3D"][:30, 2] = -2.0        # a quarter of the map is behind the camera: culled rows must not travel in the gradient all-reduce
+    return g
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gs_icp_slam_amd.sharded import ShardedGaussianRasterizer
     cam = synth.make_camera(80, 48, 64.0, 64.0)
-    g = synth.random_gaussians(120, seed=4)
+    g = _scene()
     target = torch.from_numpy(np.random.default_rng(0).random((4, 48, 80)).astype(np.float32))
-    color, depth, grads, used = _run(ShardedGaussianRasterizer(_settings(cam), rasterizer_cls=_OracleRasterizer), g, target)
-    q.put((rank, color.numpy(), depth.numpy(), {k: v.numpy() for k, v in grads.items()}, used.numpy()))
+    sh = ShardedGaussianRasterizer(_settings(cam), rasterizer_cls=_OracleRasterizer)            # defaults: compacted gradient all-reduce
+    color, depth, grads, used = _run(sh, g, target)
+    vol_compact = sh.holder.last_volume_bytes
+    dense = ShardedGaussianRasterizer(_settings(cam), rasterizer_cls=_OracleRasterizer, compact_grads=False, sync_is_used=True)
+    color_d, depth_d, grads_d, used_d = _run(dense, g, target)
+    assert torch.equal(color, color_d) and torch.equal(depth, depth_d)
+    for k in grads:   # the compacted all-reduce (visible rows only) must equal the dense one bit for bit
+        assert torch.equal(grads[k], grads_d[k]), k
+    assert vol_compact < dense.holder.last_volume_bytes
+    q.put((rank, color.numpy(), depth.numpy(), {k: v.numpy() for k, v in grads.items()}, used.numpy(), used_d.numpy(),
+           vol_compact, dense.holder.last_volume_bytes))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,13 +115,15 @@ def test_two_rank_sharding_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     cam = synth.make_camera(80, 48, 64.0, 64.0)
-    g = synth.random_gaussians(120, seed=4)
+    g = _scene()
     target = torch.from_numpy(np.random.default_rng(0).random((4, 48, 80)).astype(np.float32))
     color, depth, grads, used = _run(_OracleRasterizer(_settings(cam)), g, target)
-    for rank, c, d, gr, u in outs:
+    for rank, c, d, gr, u_local, u_synced, vol_c, vol_d in outs:
         assert np.array_equal(c, color.numpy()) and np.array_equal(d, depth.numpy()), f"rank {rank}: image differs"
-        assert np.array_equal(u, used.numpy())
+        assert np.array_equal(u_synced, used.numpy())
+        assert vol_c < vol_d
         for k in grads:
             np.testing.assert_allclose(gr[k], grads[k].numpy(), rtol=1e-5, atol=1e-7 * (np.abs(grads[k].numpy()).max() + 1e-30))
     for k in grads:   # both ranks hold identical (all-reduced) gradients
         assert np.array_equal(outs[0][3][k], outs[1][3][k])
+    assert np.array_equal(np.maximum(outs[0][4], outs[1][4]), used.numpy())   # per-rank is_used flags OR to the full ones
