@@ -16,7 +16,6 @@ ARCH = "gfx950"
 SOURCES = [
     ("raster_preprocess.hip", ["-ffp-contract=off"]),
     ("raster.hip", []),
-    ("knn.hip", []),
     ("mapper_ops.hip", []),
     ("frontend.hip", ["-ffp-contract=off"]),
     ("gicp.hip", ["-ffp-contract=off"]),

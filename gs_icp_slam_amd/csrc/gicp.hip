@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -572,6 +573,31 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(int n, int k, const float
         nbr_d2[(size_t)q * 64 + lane] = t.my_d;
     }
     if (lane == 0 && ring_hist) atomicAdd(&ring_hist[how], 1u);
+}
+
+// simple_knn._C.distCUDA2 [REF scene/gaussian_model.py:20]: mean squared distance to the 3 nearest OTHER points — the k = 4 instance of the
+// same exact grid search (the query itself is one of the four; the entry carrying its own index is dropped, so coincident points count as
+// neighbours at distance 0, as in the brute-force definition).  Replaces an O(P^2) LDS-tiled scan (ms at P = 300 k).
+__global__ __launch_bounds__(256) void knn3_pack_kernel(int n, const float* __restrict__ xyz, float4* __restrict__ pts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) pts[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
+}
+__global__ __launch_bounds__(256) void knn3_grid_kernel(int n, const float4* __restrict__ pts, const KnnGrid* __restrict__ gp,
+                                                        const unsigned* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= n) return;                       // wave-uniform
+    const int kk = n < 4 ? n : 4;
+    const KnnGrid g = *gp;
+    TopK t;
+    (void)knn_search(pts[q], kk, (1ull << kk) - 1ull, g, cell_start, sorted, n, lane, t);
+    // lanes 0..kk-1 hold the kk nearest in (d, index) order; add the (up to) three that are not the query, nearest first
+    const unsigned long long others = __ballot(lane < kk && t.my_i != q);
+    float s = 0.f;
+    int taken = 0;
+    for (unsigned long long m = others; m && taken < 3; m &= m - 1, ++taken) s += readlane_f(t.my_d, __ffsll((long long)m) - 1);
+    if (lane == 0) out[q] = taken ? s / 3.0f : 0.0f;
 }
 
 // Exact nearest-target distance for the source points the gated search left without a neighbour (the reference exports the raw
@@ -2055,5 +2081,32 @@ int gsicp_gicp_last_align_stats(gsicp_gicp* g, double out[6]) {
 int gsicp_gicp_debug_abort_next_align(gsicp_gicp* g) { g->inject_abort = true; return 0; }
 int gsicp_gicp_barrier_retries(gsicp_gicp* g) { return g->barrier_retries; }
 int gsicp_gicp_get_final_hessian(gsicp_gicp* g, double out[36]) { std::memcpy(out, g->host_result.H_final, sizeof(double) * 36); return 0; }
+
+
+// simple_knn._C.distCUDA2: out[i] = mean squared distance from point i to its 3 nearest other points (f32).  Asynchronous on `stream`
+// after the first call (scratch grows with hipMalloc); one scratch set per process, guarded by a mutex (the function is off the SLAM loop:
+// the reference calls it at most when a map is created from a point cloud [REF scene/gaussian_model.py:20]).
+int gsicp_knn_dist2(int P, const float* points, float* out, void* stream_v) {
+    if (P < 0) { g_last_error = "gsicp_knn_dist2: negative size"; return -2; }
+    if (P == 0) return 0;
+    if (!points || !out) { g_last_error = "gsicp_knn_dist2: null pointer"; return -2; }
+    static std::mutex mu;
+    static DevBuf<float4> pts, sorted;
+    static DevBuf<int> cell_of;
+    static DevBuf<unsigned> count, start, fill;
+    static DevBuf<KnnGrid> params;
+    std::lock_guard<std::mutex> lk(mu);
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (pts.ensure((size_t)P) || sorted.ensure((size_t)P) || cell_of.ensure((size_t)P) || count.ensure(KNN_MAX_CELLS + 1) ||
+        start.ensure(KNN_MAX_CELLS + 1) || fill.ensure(KNN_MAX_CELLS + 1) || params.ensure(1)) { g_last_error = "hipMalloc failed"; return -1; }
+    hipLaunchKernelGGL(knn3_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, pts.p);
+    hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, stream, P, pts.p, KNN_H_AREA, KNN_H_VOL, params.p, count.p);
+    hipLaunchKernelGGL(knn_count_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, pts.p, params.p, cell_of.p, count.p);
+    hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, stream, params.p, count.p, start.p, fill.p);
+    hipLaunchKernelGGL(knn_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, pts.p, cell_of.p, fill.p, sorted.p);
+    hipLaunchKernelGGL(knn3_grid_kernel, dim3((P + 3) / 4), dim3(256), 0, stream, P, pts.p, params.p, start.p, sorted.p, out);
+    GC(hipGetLastError());
+    return 0;
+}
 
 }  // extern "C"

@@ -257,8 +257,8 @@ __global__ __launch_bounds__(1024) void split_scatter_kernel(const uint32_t* __r
 }
 
 // One workgroup per tile: sort the tile's list by (depth bits, Gaussian id) — a total order, so the result is unique.
-// Lists up to SORT_CAP entries are bitonic-sorted in LDS; longer ones fall back to an O(n^2) rank sort in global memory
-// (correct, slow, and not reached by the scenes in BASELINE.json: their longest lists are a few hundred entries).
+// Lists up to SORT_CAP entries are bitonic-sorted in LDS; longer ones are sorted in SORT_CAP-entry chunks and merged by rank
+// (binary searches across the sorted chunks) — not reached by the scenes in BASELINE.json, whose longest lists are a few hundred entries.
 constexpr int SORT_CAP = 4096;     // large-list kernel: 256 threads, 48 KB LDS
 constexpr int SORT_SMALL = 512;    // small-list kernel: 128 threads, 6 KB LDS -> many workgroups per CU (a one-wave variant measured slower)
 template <int CAP, int THREADS, int MIN_N>
@@ -274,18 +274,68 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __re
     if (n <= MIN_N || (MIN_N == 0 && n > CAP)) return;   // the other size class's kernel handles this tile
     const int tid = threadIdx.x;
     if (n > CAP) {
+        // Long list (> CAP entries: far beyond the BASELINE scenes, whose longest lists are a few hundred entries).  Chunks of CAP entries
+        // are bitonic-sorted in LDS and written back in place; because (depth bits, Gaussian id) is a TOTAL order with unique keys, an
+        // entry's final rank is its rank inside its own chunk plus, for every other chunk, the number of that chunk's keys below it —
+        // one binary search per other chunk.  O(n (n / CAP) log CAP) instead of the O(n^2) rank sort this replaces, and still exact.
+        uint32_t* gk = const_cast<uint32_t*>(sc_keys) + range.x;   // forward-only scratch: reordered in place
+        uint32_t* gv = const_cast<uint32_t*>(sc_vals) + range.x;
+        const int n_chunks = (n + CAP - 1) / CAP;
+        for (int c = 0; c < n_chunks; ++c) {
+            const int base = c * CAP, m = (n - base) < CAP ? (n - base) : CAP;
+            for (int i = tid; i < CAP; i += THREADS) {
+                if (i < m) {
+                    const uint32_t v = gv[base + i];
+                    s_val[i] = v;
+                    s_key[i] = ((unsigned long long)gk[base + i] << 32) | entry_gauss[v & ID_MASK];
+                } else {
+                    s_key[i] = ~0ull;
+                    s_val[i] = 0;
+                }
+            }
+            __syncthreads();
+            for (int k = 2; k <= CAP; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = tid; i < CAP; i += THREADS) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const unsigned long long a = s_key[i], b = s_key[l];
+                            const bool up = (i & k) == 0;
+                            if ((a > b) == up) {
+                                s_key[i] = b; s_key[l] = a;
+                                const uint32_t va = s_val[i]; s_val[i] = s_val[l]; s_val[l] = va;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = tid; i < m; i += THREADS) { gk[base + i] = (uint32_t)(s_key[i] >> 32); gv[base + i] = s_val[i]; }
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
         for (int i = tid; i < n; i += THREADS) {
-            const uint32_t v = sc_vals[range.x + i];
-            const unsigned long long k = ((unsigned long long)sc_keys[range.x + i] << 32) | entry_gauss[v & ID_MASK];
-            int rank = 0;
-            for (int j = 0; j < n; ++j) {
-                const uint32_t vj = sc_vals[range.x + j];
-                const unsigned long long kj = ((unsigned long long)sc_keys[range.x + j] << 32) | entry_gauss[vj & ID_MASK];
-                rank += kj < k;
+            const uint32_t v = gv[i];
+            const uint32_t gid = entry_gauss[v & ID_MASK];
+            const unsigned long long key = ((unsigned long long)gk[i] << 32) | gid;
+            const int own = i / CAP;
+            int rank = i - own * CAP;
+            for (int c = 0; c < n_chunks; ++c) {
+                if (c == own) continue;
+                const int base = c * CAP, m = (n - base) < CAP ? (n - base) : CAP;
+                int lo = 0, hi = m;                       // number of keys of chunk c below `key`
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint32_t vm = gv[base + mid];
+                    const unsigned long long km = ((unsigned long long)gk[base + mid] << 32) | entry_gauss[vm & ID_MASK];
+                    if (km < key) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
             }
             point_list[range.x + rank] = v;
             tile_keys[range.x + rank] = tile;
-            list_gauss[range.x + rank] = (uint32_t)k;
+            list_gauss[range.x + rank] = gid;
         }
         return;
     }

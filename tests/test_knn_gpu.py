@@ -23,3 +23,34 @@ def test_dist2_rejects_cpu_tensor():
     from simple_knn._C import distCUDA2
     with pytest.raises(RuntimeError):
         distCUDA2(torch.zeros(4, 3))
+
+
+def test_dist2_duplicates_surfaces_and_full_size():
+    """Coincident points count as neighbours at distance 0; a surface-shaped cloud at the map's size (P = 300 k, the S-map means) runs the
+    grid search (not an O(P^2) scan) and still equals the exhaustive definition on a sample of queries."""
+    import time
+    import torch
+    import oracle
+    from simple_knn._C import distCUDA2
+    from gs_icp_slam_amd import synth
+    rng = np.random.default_rng(5)
+    base = rng.normal(size=(400, 3)).astype(np.float32)
+    pts = np.concatenate([base, base[:150], base[:40]])               # duplicates and triplicates
+    got = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.knn_dist2(pts), rtol=2e-6, atol=1e-12)
+    assert (got[:40] == 0).sum() == 0 and np.all(got[:40] < got[200:400].mean())   # two coincident copies + one real neighbour
+    big = synth.s_map(300_000, seed=2)["means3D"]
+    t = torch.from_numpy(big).cuda()
+    distCUDA2(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got_big = distCUDA2(t)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"distCUDA2 at P = 300 000: {1e3 * dt:.3f} ms")
+    assert dt < 0.01                                                   # the O(P^2) scan this replaces took several ms of GPU time
+    sample = rng.choice(300_000, 300, replace=False)
+    d = ((big[sample, None, :].astype(np.float32) - big[None, :, :]) ** 2).sum(-1, dtype=np.float32)
+    d[np.arange(300), sample] = np.inf
+    want = np.sort(d, axis=1)[:, :3].sum(1) / 3.0
+    np.testing.assert_allclose(got_big.cpu().numpy()[sample], want, rtol=1e-5)

@@ -346,6 +346,18 @@ def test_long_tile_lists_use_the_fallback_sort(hip_lib):
     assert (o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]).max() > 4096
 
 
+def test_very_long_tile_lists_merge_several_sorted_chunks(hip_lib):
+    """20 000 entries in every tile: five 4096-entry chunks sorted in LDS and merged by rank.  The lists (bit-exact against the oracle's
+    stable 64-bit sort) are the point here; images only on robust pixels."""
+    cam = synth.make_camera(32, 32, 30.0, 30.0)
+    g = synth.random_gaussians(20000, seed=14, spread=0.15, zmin=2.0, zmax=6.0)
+    g["scales"] = (g["scales"] * 8.0).astype(np.float32)
+    g["opacities"] = (g["opacities"] * 0.004).astype(np.float32)
+    g["means3D"][:4000, 2] = g["means3D"][4000:8000, 2]          # exact depth ties across chunks: the Gaussian id must break them
+    o, p, _ = check_forward(g, cam, [0, 0, 0], 0, hip_lib, "very long lists", tol=2e-4, max_fragile=0.2)
+    assert (o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]).min() > 4 * 4096
+
+
 def test_many_tiles_uhd(hip_lib):
     """3840x2160 = 32 400 tiles: the tile multi-split needs 127 KB of dynamic LDS per workgroup."""
     cam = synth.make_camera(3840, 2160, 2800.0, 2800.0)
