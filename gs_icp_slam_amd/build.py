@@ -77,7 +77,28 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_experiments(force=force, verbose=verbose)
     return OUT
+
+
+def build_experiments(force=False, verbose=True):
+    """Side library with recorded experiments (not loaded by the product): csrc/experiments/*.hip -> libgsicp_experiments.so."""
+    hipcc = _hipcc()
+    exp_dir = os.path.join(CSRC, "experiments")
+    out = os.path.join(HERE, "libgsicp_experiments.so")
+    srcs = sorted(os.path.join(exp_dir, f) for f in os.listdir(exp_dir) if f.endswith(".hip")) if os.path.isdir(exp_dir) else []
+    if not srcs:
+        return None
+    if force or _newer(out, srcs):
+        link = []
+        tl = _torch_lib_dir()
+        if tl and os.path.exists(os.path.join(tl, "libamdhip64.so")):
+            link = [f"-L{tl}", f"-Wl,-rpath,{tl}", "-Wl,--disable-new-dtags"]
+        cmd = [hipcc] + COMMON + ["-shared", "-o", out] + srcs + link
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":
