@@ -356,7 +356,7 @@ def main():
                                          f"{valu * 4.0 / 1024.0 / 2.4e3:.0f} us issue floor ({os.path.basename(sq)})")
                                 break
                     break
-        roofline = {"bound": "hbm", "kernel": "blend_backward_strip_kernel (R7)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "blend_backward_tile_kernel (R7)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "kernel_us": round(us_r7, 2),
                     "algorithmic_bytes": int(b_r7), "byte_model": "SURVEY 8(d): 44 D + 40 W H + 44 P_vis",
                     "design_bytes": int(design_bytes), "design_frac": round(gbs(design_bytes, us_r7) / HBM_PEAK_GBS, 5),

@@ -77,11 +77,17 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", src_tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for name in ("bench", "bench_tum", "bench_eager", "bench_under_rocprof"):
+    for name in ("bench", "bench_tum", "bench_basin", "bench_eager", "bench_under_rocprof", "reference_run_replica", "reference_run_tum_shaped",
+                 "mfma_cov_experiment"):
         j = last_json_line(os.path.join(src, name + ".json"))
         if j is not None:
             json.dump(j, open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
-            print(name, j["value"], j["unit"], j["ms_per_step"], "ms/step")
+            if "value" in j:
+                print(name, j["value"], j["unit"], j["ms_per_step"], "ms/step")
+    for name in ("slam_demo.txt", "reference_call_trace.json"):
+        if os.path.exists(os.path.join(src, name)):
+            import shutil
+            shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
     ks = find(os.path.join(src, "kt"), "*kernel_stats.csv")
     if ks:
         rows = list(csv.DictReader(open(ks)))
@@ -121,17 +127,16 @@ def refresh_bench_lines(tag):
     tpath, sqpath = os.path.join(dst, f"{tag}_pmc_traffic.json"), os.path.join(dst, f"{tag}_rocprofv3_pmc_sq.csv")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     sq = {r["kernel"]: r for r in csv.DictReader(open(sqpath))} if os.path.exists(sqpath) else {}
-    kernel_of = {"blend_backward": "blend_backward_strip_kernel", "blend_forward": "blend_forward_strip_kernel"}
-    for name in ("bench", "bench_eager", "bench_under_rocprof"):
+    for name in ("bench", "bench_basin", "bench_eager", "bench_under_rocprof"):
         path = os.path.join(dst, f"{tag}_{name}.json")
         if not os.path.exists(path):
             continue
         j = json.load(open(path))
         rf = j.get("roofline") or {}
-        k = rf.get("kernel")
-        if k in traffic:
-            rf["traffic"] = int(traffic[k]["fetch_bytes"] + traffic[k]["write_bytes"])
-        row = sq.get(kernel_of.get(k, ""))
+        if "blend_backward" in traffic:
+            rf["traffic"] = int(traffic["blend_backward"]["fetch_bytes"] + traffic["blend_backward"]["write_bytes"])
+            rf["traffic_source"] = f"profiles/{tag}_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command in the same capture)"
+        row = sq.get("blend_backward_tile_kernel")
         if row and float(row.get("SQ_INSTS_VALU", 0) or 0) > 0:
             valu = float(row["SQ_INSTS_VALU"])
             rf["note"] = ("working set (~60 MB) sits in the 256 MiB Infinity Cache; the kernel is VALU-issue bound, the HBM fraction is a formality"
