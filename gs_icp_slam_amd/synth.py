@@ -203,12 +203,20 @@ def render_frame(cfg, pose_c2w, noise_seed=None, holes=0.0):
 
 
 def trajectory(n_frames, step=None, start=None):
-    """Camera-to-world poses of a smooth synthetic sequence: start o step^k (default step: 0.1 / 0.25 deg, 6 / 2 mm per frame —
-    the order of Replica's inter-frame motion)."""
-    step = se3((0.1, 0.25, 0.0), (0.006, 0.0, 0.002)) if step is None else step
-    poses = [DEFAULT_POSE_A.copy() if start is None else start.copy()]
-    for _ in range(n_frames - 1):
-        poses.append(poses[-1] @ step)
+    """Camera-to-world poses of a smooth synthetic sequence of ANY length that stays inside the analytic room: the camera rides a tilted
+    ellipse in the cuboid-free half of the room (|x - c_x| <= 0.75 m, |z - c_z| <= 0.55 m) while its yaw and pitch sway slowly, so that floor,
+    walls and the interior cuboids stay in view.  Per frame at most ~7 mm and ~0.25 deg — the order of Replica's inter-frame motion.
+    (With `step` given: the older `start o step^k` path, which leaves the room after ~230 frames at the default step.)"""
+    if step is not None:
+        poses = [DEFAULT_POSE_A.copy() if start is None else start.copy()]
+        for _ in range(n_frames - 1):
+            poses.append(poses[-1] @ step)
+        return poses
+    poses = []
+    for k in range(n_frames):
+        th = 0.009 * k
+        pos = (-0.1 + 0.75 * math.cos(th), -0.1 + 0.12 * math.sin(2.0 * th), -0.9 + 0.55 * math.sin(th))
+        poses.append(se3((10.0 + 6.0 * math.sin(1.1 * th), 30.0 + 35.0 * math.sin(0.7 * th), 0.0), pos))
     return poses
 
 
