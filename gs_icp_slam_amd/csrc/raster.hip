@@ -166,7 +166,27 @@ __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int tile_mod
 }
 
 // One thread per Gaussian (id order): fill its contiguous run of emission slots — tile id, depth bits, list word
-// (slot | strip bits), slot -> Gaussian map.  Coalesced-ish plain stores, no atomics.
+// (slot | strip bits), slot -> Gaussian map.  Coalesced-ish plain stores, no atomics.  A splat that covers more than EMIT_WIDE tiles (a
+// near-field or badly conditioned Gaussian can cover the whole screen: thousands of tiles) is not walked by its own thread — that would
+// stall its wave for the length of the longest splat — but handed to the whole wave afterwards, one tile per lane and trip.
+constexpr int EMIT_WIDE = 48;
+__device__ inline void emit_one(int x, int y, int gx, int tile_mod, int tile_rem, float fx0, float fx1, float fy0, float fy1, uint32_t dbits,
+                                uint32_t id, uint32_t u, uint32_t* __restrict__ emit_tile, uint32_t* __restrict__ emit_depth,
+                                uint32_t* __restrict__ entry_gauss, uint32_t* __restrict__ entry_bits) {
+    const int t = y * gx + x;
+    uint32_t bits = 0;
+    if (fx1 >= (float)(x * TILE) && fx0 <= (float)(x * TILE + TILE - 1)) {
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const float ylo = (float)(y * TILE + 4 * sidx);
+            if (fy1 >= ylo && fy0 <= ylo + 3.f) bits |= 1u << sidx;
+        }
+    }
+    emit_tile[u] = (uint32_t)t;
+    emit_depth[u] = dbits;
+    entry_gauss[u] = id;
+    entry_bits[u] = bits;
+}
 __global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __restrict__ total, uint32_t cap,
                                                    const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ slot_base,
                                                    const SplatRec* __restrict__ rec, const int* __restrict__ radii, int gx, int gy,
@@ -174,33 +194,54 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __rest
                                                    uint32_t* __restrict__ emit_depth, uint32_t* __restrict__ entry_gauss,
                                                    uint32_t* __restrict__ entry_bits, uint32_t* __restrict__ num_rendered_dev) {
     const int id = blockIdx.x * 256 + threadIdx.x;
-    if (id >= P) return;
+    const int lane = threadIdx.x & 63;
     if (id == 0 && num_rendered_dev) *num_rendered_dev = *total;   // the caller's copy of R (async path)
-    if (tiles_touched[id] == 0 || *total > cap) return;
-    uint32_t u = slot_base[id];
-    const SplatRec r = rec[id];
-    const uint32_t dbits = __float_as_uint(r.depth);
-    int x0, y0, x1, y1;
-    tile_rect(r.px, r.py, radii[id], gx, gy, x0, y0, x1, y1);
-    const float fx0 = r.px - r.hx, fx1 = r.px + r.hx, fy0 = r.py - r.hy, fy1 = r.py + r.hy;   // alpha footprint box
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) {
-            const int t = y * gx + x;
-            if (tile_mod > 1 && (t % tile_mod) != tile_rem) continue;
-            uint32_t bits = 0;
-            if (fx1 >= (float)(x * TILE) && fx0 <= (float)(x * TILE + TILE - 1)) {
-#pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx) {
-                    const float ylo = (float)(y * TILE + 4 * sidx);
-                    if (fy1 >= ylo && fy0 <= ylo + 3.f) bits |= 1u << sidx;
-                }
+    const bool active = id < P && tiles_touched[id] != 0 && *total <= cap;
+    uint32_t u = 0, dbits = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    float fx0 = 0.f, fx1 = 0.f, fy0 = 0.f, fy1 = 0.f;
+    if (active) {
+        u = slot_base[id];
+        const SplatRec r = rec[id];
+        dbits = __float_as_uint(r.depth);
+        tile_rect(r.px, r.py, radii[id], gx, gy, x0, y0, x1, y1);
+        fx0 = r.px - r.hx; fx1 = r.px + r.hx; fy0 = r.py - r.hy; fy1 = r.py + r.hy;   // alpha footprint box
+    }
+    const int area = (x1 - x0) * (y1 - y0);
+    const bool wide = active && area > EMIT_WIDE;
+    if (active && !wide) {
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                if (tile_mod > 1 && ((y * gx + x) % tile_mod) != tile_rem) continue;
+                emit_one(x, y, gx, tile_mod, tile_rem, fx0, fx1, fy0, fy1, dbits, (uint32_t)id, u, emit_tile, emit_depth, entry_gauss, entry_bits);
+                ++u;
             }
-            emit_tile[u] = (uint32_t)t;
-            emit_depth[u] = dbits;
-            entry_gauss[u] = (uint32_t)id;
-            entry_bits[u] = bits;
-            ++u;
+    }
+    // wide splats: the wave takes them one at a time, a tile per lane (slots stay in row-major tile order, as the per-thread walk emits them)
+    for (unsigned long long m = __ballot(wide); m; m &= m - 1) {
+        const int src = __ffsll((long long)m) - 1;
+        const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bx1 = __shfl(x1, src, 64), by1 = __shfl(y1, src, 64);
+        const float gfx0 = __shfl(fx0, src, 64), gfx1 = __shfl(fx1, src, 64), gfy0 = __shfl(fy0, src, 64), gfy1 = __shfl(fy1, src, 64);
+        const uint32_t gdb = (uint32_t)__shfl((int)dbits, src, 64), gu = (uint32_t)__shfl((int)u, src, 64);
+        const uint32_t gid = (uint32_t)(blockIdx.x * 256 + (threadIdx.x & ~63) + src);
+        const int w = bx1 - bx0, n = w * (by1 - by0);
+        if (tile_mod == 1) {
+            for (int k = lane; k < n; k += 64)
+                emit_one(bx0 + k % w, by0 + k / w, gx, tile_mod, tile_rem, gfx0, gfx1, gfy0, gfy1, gdb, gid, gu + (uint32_t)k, emit_tile, emit_depth,
+                         entry_gauss, entry_bits);
+        } else {   // sharded: only this rank's tiles own slots; rank them with a running count of the tiles kept so far
+            uint32_t kept = 0;
+            for (int k0 = 0; k0 < n; k0 += 64) {
+                const int k = k0 + lane;
+                const bool mine = k < n && (((by0 + k / w) * gx + bx0 + k % w) % tile_mod) == tile_rem;
+                const unsigned long long mm = __ballot(mine);
+                if (mine)
+                    emit_one(bx0 + k % w, by0 + k / w, gx, tile_mod, tile_rem, gfx0, gfx1, gfy0, gfy1, gdb, gid,
+                             gu + kept + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)), emit_tile, emit_depth, entry_gauss, entry_bits);
+                kept += (uint32_t)__popcll(mm);
+            }
         }
+    }
 }
 
 // Tile multi-split, pass 1: each workgroup histograms its contiguous chunk of emission slots over all T tiles in LDS
