@@ -410,6 +410,111 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(int n, const float4* __re
     sorted[atomicAdd(&cell_fill[cell_of[i]], 1u)] = p;
 }
 
+// Tracker-sized clouds (<= KNN_FUSED_MAX_N points: 8-12 k per frame): the four launches above as ONE single-workgroup kernel — bounding box,
+// grid parameters, counting sort with the cell counters in LDS (global memory when the grid has more than KNN_LDS_CELLS cells), exclusive
+// scan, fill.  Same parameters, same cell assignment, same cell_start table as the multi-launch path (the order of the points inside a
+// cell is arbitrary in both; the search result does not depend on it).  Three kernel boundaries (~4 us each plus their launch gaps) less
+// per tracked frame.
+constexpr int KNN_FUSED_MAX_N = 32768;
+constexpr int KNN_LDS_CELLS = 8192;
+__global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const float4* __restrict__ pts, float h_area, float h_vol,
+                                                               KnnGrid* __restrict__ gp, int* __restrict__ cell_of,
+                                                               unsigned* __restrict__ cell_count /* global fallback counters */,
+                                                               unsigned* __restrict__ cell_start, unsigned* __restrict__ cell_fill,
+                                                               float4* __restrict__ sorted) {
+    __shared__ float s_lo[3][16], s_hi[3][16];
+    __shared__ unsigned s_cnt[KNN_LDS_CELLS];
+    __shared__ unsigned s_part[1024];
+    __shared__ KnnGrid s_g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = pts[i];
+        lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+        if (lane == 0) { s_lo[d][wave] = lo[d]; s_hi[d][wave] = hi[d]; }
+    }
+    __syncthreads();
+    if (tid == 0) {   // identical arithmetic to knn_grid_params_kernel
+        float L[3], E[3];
+        for (int d = 0; d < 3; ++d) {
+            float l = s_lo[d][0], u = s_hi[d][0];
+            for (int w = 1; w < 16; ++w) { l = fminf(l, s_lo[d][w]); u = fmaxf(u, s_hi[d][w]); }
+            L[d] = l; E[d] = fmaxf(u - l, 0.f);
+        }
+        const float emax = fmaxf(fmaxf(E[0], E[1]), fmaxf(E[2], 1e-6f));
+        const float area = E[0] * E[1] + E[1] * E[2] + E[0] * E[2];
+        const float vol = fmaxf(E[0], 1e-3f * emax) * fmaxf(E[1], 1e-3f * emax) * fmaxf(E[2], 1e-3f * emax);
+        float h = fmaxf(h_area * sqrtf(area / (float)n), h_vol * cbrtf(vol / (float)n));
+        h = fmaxf(h, emax * (1.f / 1024.f));
+        int nx, ny, nz;
+        for (;;) {
+            nx = (int)(E[0] / h) + 1; ny = (int)(E[1] / h) + 1; nz = (int)(E[2] / h) + 1;
+            if ((long long)nx * ny * nz <= KNN_MAX_CELLS) break;
+            h *= 1.25f;
+        }
+        KnnGrid g;
+        g.ox = L[0]; g.oy = L[1]; g.oz = L[2]; g.h = h; g.inv_h = 1.f / h;
+        g.nx = nx; g.ny = ny; g.nz = nz; g.ncells = nx * ny * nz;
+        for (int i = 0; i < 5; ++i) g.ring_hist[i] = 0u;
+        s_g = g;
+        *gp = g;
+    }
+    __syncthreads();
+    const KnnGrid g = s_g;
+    const int ncells = g.ncells;
+    const bool in_lds = ncells <= KNN_LDS_CELLS;
+    unsigned* cnt = in_lds ? s_cnt : cell_count;
+    for (int c = tid; c < ncells; c += 1024) cnt[c] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const float4 p = pts[i];
+        int cx, cy, cz;
+        knn_cell_of(g, p.x, p.y, p.z, cx, cy, cz);
+        const int c = (cz * g.ny + cy) * g.nx + cx;
+        cell_of[i] = c;
+        atomicAdd(&cnt[c], 1u);
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int per = (ncells + 1023) / 1024;
+    const int clo = tid * per, chi = (clo + per) < ncells ? (clo + per) : ncells;
+    unsigned sum = 0;
+    for (int c = clo; c < chi; ++c) sum += cnt[c];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
+        const unsigned v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = s_part[tid] - sum;
+    unsigned* cur = in_lds ? s_cnt : cell_fill;     // the counters become the fill cursors
+    for (int c = clo; c < chi; ++c) {
+        const unsigned k = cnt[c];
+        cell_start[c] = run;
+        cur[c] = run;
+        run += k;
+    }
+    if (tid == 1023) cell_start[ncells] = s_part[1023];
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        float4 p = pts[i];
+        p.w = __int_as_float(i);
+        sorted[atomicAdd(&cur[cell_of[i]], 1u)] = p;
+    }
+}
+
 struct TopK { float my_d; int my_i; float tau_d; int tau_i; };
 // Offer one candidate per lane (d = FLT_MAX / id = INT_MAX for idle lanes) to the cross-lane sorted list.
 __device__ inline void topk_offer(TopK& t, float d, int id, int kk, unsigned long long kmask, int lane) {
@@ -1629,13 +1734,18 @@ int calc_cov(gsicp_gicp* g, Cloud& c) {
             g->knn_fill.ensure(KNN_MAX_CELLS + 1) || g->knn_sorted.ensure((size_t)n)) { g_last_error = "hipMalloc failed"; return -1; }
         static const bool knn_stats_on = std::getenv("GSICP_KNN_STATS") != nullptr;
         static const float h_area = [] { const char* e = std::getenv("GSICP_KNN_H"); const float v = e ? (float)std::atof(e) : 0.f; return v > 0.f ? v : KNN_H_AREA; }();
-        hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, g->stream, n, c.pts.p, h_area, h_area * (KNN_H_VOL / KNN_H_AREA),
-                           g->knn_params.p, g->knn_count.p);
-        hipLaunchKernelGGL(knn_count_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, c.pts.p, g->knn_params.p, g->knn_cell_of.p,
-                           g->knn_count.p);
-        hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, g->stream, g->knn_params.p, g->knn_count.p, g->knn_start.p, g->knn_fill.p);
-        hipLaunchKernelGGL(knn_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, c.pts.p, g->knn_cell_of.p, g->knn_fill.p,
-                           g->knn_sorted.p);
+        if (n <= KNN_FUSED_MAX_N) {
+            hipLaunchKernelGGL(knn_build_fused_kernel, dim3(1), dim3(1024), 0, g->stream, n, c.pts.p, h_area, h_area * (KNN_H_VOL / KNN_H_AREA),
+                               g->knn_params.p, g->knn_cell_of.p, g->knn_count.p, g->knn_start.p, g->knn_fill.p, g->knn_sorted.p);
+        } else {
+            hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, g->stream, n, c.pts.p, h_area, h_area * (KNN_H_VOL / KNN_H_AREA),
+                               g->knn_params.p, g->knn_count.p);
+            hipLaunchKernelGGL(knn_count_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, c.pts.p, g->knn_params.p, g->knn_cell_of.p,
+                               g->knn_count.p);
+            hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, g->stream, g->knn_params.p, g->knn_count.p, g->knn_start.p, g->knn_fill.p);
+            hipLaunchKernelGGL(knn_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, c.pts.p, g->knn_cell_of.p, g->knn_fill.p,
+                               g->knn_sorted.p);
+        }
         hipLaunchKernelGGL(knn_grid_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, n, g->k, c.pts.p, g->knn_params.p, g->knn_start.p,
                            g->knn_sorted.p, g->nbr_idx.p, g->nbr_d2.p,
                            knn_stats_on ? g->knn_params.p->ring_hist : (unsigned*)nullptr);   // same-address atomics: diagnostics only
