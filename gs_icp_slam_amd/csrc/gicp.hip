@@ -741,20 +741,42 @@ __global__ __launch_bounds__(64) void cov_eig_kernel(int n, int k, const float4*
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= n) return;
     const int kk = k < n ? k : n;
-    double mu[3] = {0, 0, 0};
+    // how many of the (distance-sorted) neighbours lie inside the k-NN radius: the row is scanned with independent loads first, so that the
+    // point gathers below are not serialised behind a data-dependent exit
     int cnt = 0;
-    for (int j = 0; j < kk; ++j) {
-        if (nbr_d2[(size_t)q * 64 + j] > max_d2) break;
-        const float4 p = pts[nbr_idx[(size_t)q * 64 + j]];
-        mu[0] += (double)p.x; mu[1] += (double)p.y; mu[2] += (double)p.z;
-        ++cnt;
+    {
+        const float* drow = nbr_d2 + (size_t)q * 64;
+        for (int j = 0; j < kk; j += 4) {
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = (j + u < kk) ? drow[j + u] : FLT_MAX;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (j + u == cnt && d[u] <= max_d2) ++cnt;   // stops counting at the first neighbour beyond the radius
+        }
+    }
+    const int* irow = nbr_idx + (size_t)q * 64;
+    // four gathers in flight per trip; the additions keep the rank order (bit-identical to the one-at-a-time loop and to the oracle)
+    double mu[3] = {0, 0, 0};
+    for (int j = 0; j < cnt; j += 4) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = pts[irow[j + u < cnt ? j + u : j]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (j + u < cnt) { mu[0] += (double)p[u].x; mu[1] += (double)p[u].y; mu[2] += (double)p[u].z; }
     }
     mu[0] /= cnt; mu[1] /= cnt; mu[2] /= cnt;
     double raw[6] = {0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < cnt; ++j) {
-        const float4 p = pts[nbr_idx[(size_t)q * 64 + j]];
-        const double dx = (double)p.x - mu[0], dy = (double)p.y - mu[1], dz = (double)p.z - mu[2];
-        raw[0] += dx * dx; raw[1] += dx * dy; raw[2] += dx * dz; raw[3] += dy * dy; raw[4] += dy * dz; raw[5] += dz * dz;
+    for (int j = 0; j < cnt; j += 4) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = pts[irow[j + u < cnt ? j + u : j]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j + u < cnt) {
+                const double dx = (double)p[u].x - mu[0], dy = (double)p[u].y - mu[1], dz = (double)p[u].z - mu[2];
+                raw[0] += dx * dx; raw[1] += dx * dy; raw[2] += dx * dz; raw[3] += dy * dy; raw[4] += dy * dz; raw[5] += dz * dz;
+            }
+        }
     }
 #pragma unroll
     for (int d = 0; d < 6; ++d) raw[d] /= cnt;
