@@ -286,7 +286,7 @@ def main():
     align_stats = trk.reg.last_align_stats() if args.only != "mapper" else {}
 
     # ---------------- per-kernel hipEvent times ----------------
-    # kernels inside a replayed graph carry no HIP events: the SAME kernels on the same inputs are timed in eager iterations right after the
+    # kernels inside a replayed graph carry no HIP events: the SAME kernels on the same inputs are timed (one hipEvent bracket per kernel) in eager iterations right after the
     # timed region, the tracker stages in tracker-only frames (rocprofv3's kernel trace of this command sees all of them and must agree —
     # profiles/README.md)
     _lib.profile_enable(True)
@@ -327,8 +327,8 @@ def main():
         b_r7 = 44.0 * D_local + 40.0 * WHr + 44.0 * P_vis                       # blend backward (R7)
         b_bwd = b_r7 + 184.0 * P                                                # + R8/R9
         b_fwd = 128.0 * P + D_local * (64.0 + 24.0 * n_pass) + 24.0 * WHr + 8.0 * Tr
-        fwd_stages = ["preprocess", "tile_scan_lpt", "emit_split", "tile_sort", "blend_forward"]
-        bwd_stages = ["blend_backward", "entry_grad_sum", "preprocess_backward"]
+        fwd_stages = ["preprocess", "emit", "split_hist", "split_colscan", "tile_scan_lpt", "split_scatter", "tile_sort_long", "tile_sort", "blend_forward"]
+        bwd_stages = ["blend_backward", "preprocess_backward"]
         us_r7 = per_launch_us.get("blend_backward", float("nan"))
         us_bwd = sum(per_launch_us.get(k, 0.0) for k in bwd_stages)
         us_fwd = sum(per_launch_us.get(k, 0.0) for k in fwd_stages)
@@ -563,8 +563,7 @@ def main():
                        "variants": {"depth_mode": "sum z alpha T (un-normalised)", "fromqs_scale_mode": "s^2", "regularization": "PLANE"},
                        "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-reduce image + grads), tracker replicated",
                        "world_size": world, "backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen},
-            "render_bwd_ms_per_iter": round(sum(per_launch_us.get(k, 0.0) for k in ["preprocess", "tile_scan_lpt", "emit_split", "tile_sort", "blend_forward",
-                                                                                   "blend_backward", "entry_grad_sum", "preprocess_backward"]) / 1e3, 4),
+            "render_bwd_ms_per_iter": round(sum(v for k, v in per_launch_us.items() if not k.startswith("gicp")) / 1e3, 4),
             "tracker_align_kernel_us": stage_us.get("gicp_align"),
             "stage_us_per_step": stage_us,
             "legs": legs, "roofline": roofline, "cpu_baseline": cpu,

@@ -47,13 +47,13 @@ std::vector<ProfRec> g_prof_log;
 std::vector<hipEvent_t> g_prof_pool;
 hipEvent_t g_prof_open[ST_COUNT];
 std::atomic<int> g_prof_enabled{0};
-// stage -> kernels: preprocess = preprocess_kernel; tile_scan_lpt = tile_scan_lpt_kernel; emit_split = emit_kernel + split_hist_kernel +
-// split_colscan_kernel + split_scatter_kernel; tile_sort = both tile_sort_kernel size classes; blend_* = the strip kernels;
-// blend_backward = blend_backward_tile_kernel; entry_grad_sum = (retired: the tile kernel writes entry records itself);
-// preprocess_backward = preprocess_backward_kernel
-const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "emit_split", "tile_sort", "blend_forward",
-                                             "blend_backward", "entry_grad_sum", "preprocess_backward", "gicp_knn_cov", "gicp_grid_build",
-                                             "gicp_align", "gicp_exact_nn"};
+// stage -> kernel: preprocess = preprocess_kernel; tile_scan_lpt = tile_scan_lpt_kernel; emit = emit_kernel; split_hist / split_colscan /
+// split_scatter = the three multi-split kernels; tile_sort_long / tile_sort = tile_sort_kernel's two size classes (> 512 entries / the rest);
+// blend_forward = blend_forward_strip_kernel; blend_backward = blend_backward_tile_kernel; preprocess_backward = preprocess_backward_kernel;
+// gicp_* = the tracker's call-level stages (several launches each)
+const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "emit", "split_hist", "split_colscan", "split_scatter", "tile_sort_long",
+                                             "tile_sort", "blend_forward", "blend_backward", "preprocess_backward", "gicp_knn_cov",
+                                             "gicp_grid_build", "gicp_align", "gicp_exact_nn"};
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -111,13 +111,16 @@ __global__ void publish_count_kernel(const uint32_t* __restrict__ total, uint32_
 // counting sort over 64 length buckets (exact ordering is not needed for load balance).  Any T; one launch.
 constexpr int LPT_BUCKETS = 64;
 __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int tile_mod, int tile_rem, const uint32_t* __restrict__ tile_count,
-                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
+                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                             uint32_t* __restrict__ n_front /* tiles at the head of `order` that may exceed long_min */,
+                                                             uint32_t long_min) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     __shared__ uint32_t s_hist[LPT_BUCKETS];
     __shared__ uint32_t s_maxlen;
+    __shared__ uint32_t s_front;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_carry = 0; s_maxlen = 0; }
+    if (tid == 0) { s_carry = 0; s_maxlen = 0; s_front = 0; }
     if (tid < LPT_BUCKETS) s_hist[tid] = 0;
     __syncthreads();
     for (int base = 0; base < T; base += 1024) {
@@ -147,11 +150,14 @@ __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int tile_mod
     const uint32_t maxlen = s_maxlen;
     const uint32_t div = maxlen / LPT_BUCKETS + 1;
     const int n_local = (T - tile_rem + tile_mod - 1) / tile_mod;
+    const uint32_t front_bucket = (long_min + 1) / div;   // every tile longer than long_min sits in this length bucket or a longer one
     for (int i = tid; i < n_local; i += 1024) {
         const uint32_t c = tile_count[i * tile_mod + tile_rem];
         atomicAdd(&s_hist[LPT_BUCKETS - 1 - (c / div)], 1u);     // bucket 0 = longest lists
+        if (c / div >= front_bucket && c > 0) atomicAdd(&s_front, 1u);
     }
     __syncthreads();
+    if (tid == 0 && n_front) *n_front = s_front;             // those tiles are contiguous at the head of the LPT order
     if (tid == 0) {
         uint32_t run = 0;
         for (int b = 0; b < LPT_BUCKETS; ++b) { const uint32_t h = s_hist[b]; s_hist[b] = run; run += h; }
@@ -300,16 +306,13 @@ __global__ __launch_bounds__(1024) void split_scatter_kernel(const uint32_t* __r
 // One workgroup per tile: sort the tile's list by (depth bits, Gaussian id) — a total order, so the result is unique.
 // Lists up to SORT_CAP entries are bitonic-sorted in LDS; longer ones are sorted in SORT_CAP-entry chunks and merged by rank
 // (binary searches across the sorted chunks) — not reached by the scenes in BASELINE.json, whose longest lists are a few hundred entries.
-constexpr int SORT_CAP = 4096;     // large-list kernel: 256 threads, 48 KB LDS
+constexpr int SORT_CAP = 4096;     // long-list kernel: 1024 threads, 48 KB LDS, a small persistent grid over the head of the LPT order
 constexpr int SORT_SMALL = 512;    // small-list kernel: 128 threads, 6 KB LDS -> many workgroups per CU (a one-wave variant measured slower)
 template <int CAP, int THREADS, int MIN_N>
-__global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __restrict__ order, const uint2* __restrict__ ranges,
-                                                        const uint32_t* __restrict__ sc_keys, const uint32_t* __restrict__ sc_vals,
-                                                        const uint32_t* __restrict__ entry_gauss, uint32_t* __restrict__ point_list,
-                                                        uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ list_gauss) {
-    __shared__ unsigned long long s_key[CAP];
-    __shared__ uint32_t s_val[CAP];
-    const uint32_t tile = order[blockIdx.x];
+__device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uint32_t* __restrict__ s_val, const uint32_t tile,
+                                     const uint2* __restrict__ ranges, const uint32_t* __restrict__ sc_keys, const uint32_t* __restrict__ sc_vals,
+                                     const uint32_t* __restrict__ entry_gauss, uint32_t* __restrict__ point_list,
+                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ list_gauss) {
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n <= MIN_N || (MIN_N == 0 && n > CAP)) return;   // the other size class's kernel handles this tile
@@ -414,6 +417,25 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint32_t* __re
         point_list[range.x + i] = s_val[i];
         tile_keys[range.x + i] = tile;
         list_gauss[range.x + i] = (uint32_t)s_key[i];   // low word of the sort key = Gaussian id
+    }
+}
+// The long class (MIN_N > 0) runs a small persistent grid over the head of the LPT order only (`limit_dev` = the number of tiles that may be
+// longer than MIN_N, counted by tile_scan_lpt_kernel) with 1024 threads per list: a bitonic stage then costs one compare-exchange and one
+// barrier per thread instead of four, which is what a handful of 600-1000-entry lists on the critical path are made of (37 -> 9 us when the
+// trained map pushes a few tiles past 512 entries).  The short class keeps one 128-thread workgroup per tile.
+template <int CAP, int THREADS, int MIN_N>
+__global__ __launch_bounds__(THREADS) void tile_sort_kernel(int n_tiles, const uint32_t* __restrict__ limit_dev, const uint32_t* __restrict__ order,
+                                                            const uint2* __restrict__ ranges, const uint32_t* __restrict__ sc_keys,
+                                                            const uint32_t* __restrict__ sc_vals, const uint32_t* __restrict__ entry_gauss,
+                                                            uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
+                                                            uint32_t* __restrict__ list_gauss) {
+    __shared__ unsigned long long s_key[CAP];
+    __shared__ uint32_t s_val[CAP];
+    int limit = n_tiles;
+    if (limit_dev) { const int l = (int)*limit_dev; limit = l < limit ? l : limit; }
+    for (int bi = blockIdx.x; bi < limit; bi += gridDim.x) {
+        tile_sort_one<CAP, THREADS, MIN_N>(s_key, s_val, order[bi], ranges, sc_keys, sc_vals, entry_gauss, point_list, tile_keys, list_gauss);
+        __syncthreads();   // the LDS arrays are reused by the next list
     }
 }
 
@@ -867,33 +889,38 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     uint32_t* entry_bits = (uint32_t*)(bin + BL.entry_bits);
     uint32_t* block_hist = (uint32_t*)(bin + BL.block_hist);
     if (num_rendered > 0) {
-        ProfileScope ps(ST_DUPLICATE, stream);
-        hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, total_counter, cap, tiles_touched, slot_base, rec, radii, gx, gy,
-                           tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits, num_rendered_dev);
-        hipLaunchKernelGGL(split_hist_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, block_hist);
-        hipLaunchKernelGGL(split_colscan_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, nb, block_hist, tile_count);
+        { ProfileScope ps(ST_EMIT, stream);
+          hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, total_counter, cap, tiles_touched, slot_base, rec, radii, gx, gy,
+                             tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits, num_rendered_dev); }
+        { ProfileScope ps(ST_SPLIT_HIST, stream);
+          hipLaunchKernelGGL(split_hist_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, block_hist); }
+        { ProfileScope ps(ST_SPLIT_COLSCAN, stream);
+          hipLaunchKernelGGL(split_colscan_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, nb, block_hist, tile_count); }
     }
     {
         ProfileScope ps(ST_RANGES, stream);
-        hipLaunchKernelGGL(tile_scan_lpt_kernel, dim3(1), dim3(1024), 0, stream, T, tile_mod, tile_rem, tile_count, ranges, order);
+        hipLaunchKernelGGL(tile_scan_lpt_kernel, dim3(1), dim3(1024), 0, stream, T, tile_mod, tile_rem, tile_count, ranges, order, total_counter + 1,
+                           (uint32_t)SORT_SMALL);
     }
     if (num_rendered > 0) {
         {
-            ProfileScope ps(ST_DUPLICATE, stream);
+            ProfileScope ps(ST_SPLIT_SCATTER, stream);
             hipLaunchKernelGGL(split_scatter_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, emit_depth,
                                entry_bits, block_hist, ranges, (uint32_t*)(bin + BL.scatter_keys), (uint32_t*)(bin + BL.scatter_vals));
         }
         const int n_local = (T - tile_rem + tile_mod - 1) / tile_mod;
-        {
-            ProfileScope ps(ST_TILE_SORT, stream);
-            // two size classes over the same (LPT-ordered) tile list; each kernel skips the other class's tiles
-            hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP, 256, SORT_SMALL>), dim3(n_local), dim3(256), 0, stream, order, ranges,
-                               (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
-                               (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss));
-            hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 128, 0>), dim3(n_local), dim3(128), 0, stream, order, ranges,
-                               (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
-                               (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss));
-        }
+        // two size classes over the same (LPT-ordered) tile list; each kernel skips the other class's tiles.  (They touch disjoint lists, but
+        // running the long class on a side stream between fork / join events — two parallel branches of the captured hipGraph — made the
+        // replayed iteration 0.71 ms instead of 0.40 ms on this stack: cross-stream edges in a graph are far dearer than the 23 us they hide.)
+        { ProfileScope ps(ST_TILE_SORT_LONG, stream);
+          hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP, 1024, SORT_SMALL>), dim3(n_local < 64 ? n_local : 64), dim3(1024), 0, stream, n_local,
+                             (const uint32_t*)(total_counter + 1), order, ranges,
+                             (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
+                             (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss)); }
+        { ProfileScope ps(ST_TILE_SORT, stream);
+          hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 128, 0>), dim3(n_local), dim3(128), 0, stream, n_local, (const uint32_t*)nullptr, order, ranges,
+                             (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
+                             (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss)); }
     }
 
     BlendArgs ba;
