@@ -303,6 +303,32 @@ __global__ __launch_bounds__(1024) void split_scatter_kernel(const uint32_t* __r
     }
 }
 
+// Bitonic network over `npad` (power of two) keys in LDS, one compare-exchange PAIR per thread and step: pair p exchanges elements
+// i = 2 j (p / j) + (p % j) and i + j.  64 consecutive pairs — one wave's share of a step — cover 128 consecutive elements, so every step
+// with j < 64 only touches elements of the wave's own 128-element blocks and needs no workgroup barrier (a wave's LDS operations execute in
+// program order): of the log2(n) (log2(n) + 1) / 2 steps only those with j >= 64 synchronise the workgroup (none up to 128 elements, 10 of 55
+// at 1024).
+template <int THREADS>
+__device__ inline void bitonic_pairs(unsigned long long* __restrict__ s_key, uint32_t* __restrict__ s_val, int npad, int tid) {
+    const int half = npad >> 1;
+    for (int k = 2; k <= npad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < half; p += THREADS) {
+                const int i = 2 * j * (p / j) + (p % j), l = i + j;
+                const unsigned long long a = s_key[i], b = s_key[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    s_key[i] = b; s_key[l] = a;
+                    const uint32_t va = s_val[i]; s_val[i] = s_val[l]; s_val[l] = va;
+                }
+            }
+            if (j >= 64 && THREADS > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        }
+        // the next merge level starts with j = k: its first step reads across wave blocks whenever k >= 64
+        if (k >= 64 && k < npad && THREADS > 64) __syncthreads();
+    }
+}
+
 // One workgroup per tile: sort the tile's list by (depth bits, Gaussian id) — a total order, so the result is unique.
 // Lists up to SORT_CAP entries are bitonic-sorted in LDS; longer ones are sorted in SORT_CAP-entry chunks and merged by rank
 // (binary searches across the sorted chunks) — not reached by the scenes in BASELINE.json, whose longest lists are a few hundred entries.
@@ -338,22 +364,8 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
                 }
             }
             __syncthreads();
-            for (int k = 2; k <= CAP; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = tid; i < CAP; i += THREADS) {
-                        const int l = i ^ j;
-                        if (l > i) {
-                            const unsigned long long a = s_key[i], b = s_key[l];
-                            const bool up = (i & k) == 0;
-                            if ((a > b) == up) {
-                                s_key[i] = b; s_key[l] = a;
-                                const uint32_t va = s_val[i]; s_val[i] = s_val[l]; s_val[l] = va;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
+            bitonic_pairs<THREADS>(s_key, s_val, CAP, tid);
+            __syncthreads();
             for (int i = tid; i < m; i += THREADS) { gk[base + i] = (uint32_t)(s_key[i] >> 32); gv[base + i] = s_val[i]; }
             __syncthreads();
         }
@@ -397,22 +409,8 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
     }
     // a single wave needs no s_barrier: its LDS operations execute in program order
     if (THREADS == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-    for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npad; i += THREADS) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = s_key[i], b = s_key[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) {
-                        s_key[i] = b; s_key[l] = a;
-                        const uint32_t va = s_val[i]; s_val[i] = s_val[l]; s_val[l] = va;
-                    }
-                }
-            }
-            if (THREADS == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-        }
-    }
+    bitonic_pairs<THREADS>(s_key, s_val, npad, tid);
+    __syncthreads();
     for (int i = tid; i < n; i += THREADS) {
         point_list[range.x + i] = s_val[i];
         tile_keys[range.x + i] = tile;
@@ -913,7 +911,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
         // running the long class on a side stream between fork / join events — two parallel branches of the captured hipGraph — made the
         // replayed iteration 0.71 ms instead of 0.40 ms on this stack: cross-stream edges in a graph are far dearer than the 23 us they hide.)
         { ProfileScope ps(ST_TILE_SORT_LONG, stream);
-          hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP, 1024, SORT_SMALL>), dim3(n_local < 64 ? n_local : 64), dim3(1024), 0, stream, n_local,
+          hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP, 512, SORT_SMALL>), dim3(n_local < 64 ? n_local : 64), dim3(512), 0, stream, n_local,
                              (const uint32_t*)(total_counter + 1), order, ranges,
                              (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
                              (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss)); }
