@@ -77,7 +77,8 @@ class MapperIterationGraph:
         inner = self.rasterizer.inner if hasattr(self.rasterizer, "inner") else self.rasterizer
         if getattr(inner, "num_rendered", None) is None:
             inner.num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
-        optimizer.set_overflow_guard(inner.num_rendered, self.capacity)
+        self._guard_count = inner.num_rendered     # bound to the optimiser in capture(): several graphs (e.g. one per training_stage
+        optimizer.set_overflow_guard(inner.num_rendered, self.capacity)   # resolution) may share one optimiser, each with its own guard
         # screen-space gradient holder [REF gaussian_renderer/__init__.py:227]: the reference makes a fresh zero tensor per call;
         # its VALUE is never read by the rasteriser, so one static tensor serves every replay
         self._means2D = torch.zeros_like(params["means3D"], requires_grad=True)
@@ -132,6 +133,9 @@ class MapperIterationGraph:
         update per loop iteration [REF mp_Mapper.py:219-248]."""
         dev = self.params["means3D"].device
         self.optimizer.zero_grad(set_to_none=True)
+        self.optimizer.set_overflow_guard(self._guard_count, self.capacity)   # the launches captured below read THIS graph's count / capacity
+        if self.live_count is not None:
+            self.optimizer.set_live_rows(self.live_count)
         snap_p = {k: v.detach().clone() for k, v in self.params.items()}
         snap_s = {}
         for p in self.params.values():

@@ -203,6 +203,53 @@ def test_overflowing_replay_skips_the_optimiser_step_on_the_device():
         assert torch.equal(opt.state[v]["exp_avg"], snap_m[k]) and torch.equal(opt.state[v]["exp_avg_sq"], snap_v[k])
 
 
+def test_one_graph_per_training_stage_resolution_shares_parameters_and_optimiser():
+    """render_3's coarse-to-fine `training_stage` renders at W/2 x H/2 or W/4 x H/4 with the same tan(fov/2) [REF gaussian_renderer/__init__.py:238-242;
+    mp_Mapper.py:207-216].  A captured iteration is tied to one resolution, so the mapper keeps one MapperIterationGraph per stage over the SAME
+    parameters and the SAME capturable optimiser; alternating them must equal the eager iterations at the respective resolutions (each graph's
+    captured Adam launches carry that graph's own overflow guard)."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gs_icp_slam_amd.graph import MapperIterationGraph, default_activations
+    from gs_icp_slam_amd.loss import mapper_loss_parts
+    P, W, H = 15000, 320, 192
+    g, cam, params_e, opt_e = _mapper_setup(P, W, H, capturable=False)
+    _, _, params_g, opt_g = _mapper_setup(P, W, H, capturable=True)
+    stages = {0: (W, H), 1: (W // 2, H // 2)}
+    views, graphs = {}, {}
+    for st, (w, h) in stages.items():
+        cam_s = synth.make_camera(w, h, cam["fx"] * w / W, cam["fy"] * h / H, synth.DEFAULT_POSE_A)
+        rs_s = make_settings(cam_s, [0.0, 0.0, 0.0])
+        t2 = torch_inputs(synth.s_map(P, seed=5, perturb_seed=7))
+        with torch.no_grad():
+            d, c, _, _ = GaussianRasterizer(rs_s)(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"],
+                                                  opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
+        views[st] = (rs_s, c.clone(), d.clone())
+        assert abs(cam_s["tanfovx"] - cam["tanfovx"]) < 1e-12
+    for st, (w, h) in stages.items():        # both graphs are BUILT before either is captured: the guard must not leak from one to the other
+        graphs[st] = MapperIterationGraph(params_g, opt_g, h, w, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=(2_000_000 if st == 0 else 700_000), warmup=1)
+    for st in stages:
+        rs_s, c, d = views[st]
+        graphs[st].set_view(rs_s.viewmatrix, rs_s.projmatrix, rs_s.campos, c, d)
+        graphs[st].capture()
+    schedule = [0, 1, 1, 0, 1, 0]
+    for st in schedule:
+        rs_s, gt_c, gt_d = views[st]
+        a = default_activations(params_e)
+        m2 = torch.zeros_like(a["means3D"], requires_grad=True)
+        depth, color, _, _ = GaussianRasterizer(rs_s)(means3D=a["means3D"], means2D=m2, shs=a["shs"], opacities=a["opacities"], scales=a["scales"],
+                                                      rotations=a["rotations"])
+        loss, _ = mapper_loss_parts(color, depth, gt_c, gt_d)
+        loss.backward()
+        opt_e.step()
+        opt_e.zero_grad(set_to_none=True)
+        lg = float(graphs[st].step())
+        assert not graphs[st].overflowed()
+        np.testing.assert_allclose(lg, float(loss.detach()), rtol=2e-5)
+    assert int(opt_g.state[params_g["means3D"]]["step"].item()) == len(schedule) and graphs[0].skipped_steps() == 0
+    for k in params_e:
+        torch.testing.assert_close(params_g[k], params_e[k], rtol=1e-4, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
+
+
 def test_graph_rejects_host_step_optimizer():
     from gs_icp_slam_amd.graph import MapperIterationGraph
     g, cam, params, opt = _mapper_setup(1000, 64, 48, capturable=False)
