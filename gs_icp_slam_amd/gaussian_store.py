@@ -199,17 +199,15 @@ class GaussianStore:
             _lib.check(lib.gsicp_store_compact(self.n, ctypes.c_void_p(keep.data_ptr()), len(live), S, D, RB,
                                                ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_void_p(self._n_dev.data_ptr()), stream),
                        "gsicp_store_compact")
-        n_old = self.n
         self.n = int(self._n_dev.item())
         if self.stable:
             # addresses must not move: the survivors go back into set 0 (the compaction cannot run in place: a parallel scatter would
-            # overwrite rows other threads have not read yet).  Rows [n, n_old) keep stale values; nothing reads them, and append()
+            # overwrite rows other threads have not read yet).  Rows behind the new count keep stale values; nothing reads them, and append()
             # rewrites parameters and zeroes moments of the rows it claims.
             with torch.no_grad():
                 for k in keys:
                     if src[k][0].numel() > 0 and self.n > 0:
                         src[k][: self.n].copy_(dst[k][: self.n])
-            del n_old
             return self.params
         self._cur ^= 1
         self._rebind()
