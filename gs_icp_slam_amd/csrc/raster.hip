@@ -593,10 +593,12 @@ __device__ inline float swap16_add(float a, float b) {
 // the three registers
 // are folded across the 16 lanes of a row with bank-masked DPP adds (two registers into one per level: banks 2,3 take one source's
 // shr:8 fold, banks 0,1 the other's shl:8 fold), so that the quad reduction runs on a single register: 7 DPP adds instead of 12.
-// Result: lanes with (lane & 3) == 0 of bank b in row k hold  b=2: value {0,2,1,3}[k];  b=0: value {4,6,5,7}[k];  b=3: {8,-,9,-}[k].
+// Result: lanes with (lane & 3) == 0 of bank b in row k hold  b=2: value {0,2,1,3}[k];  b=0: value {4,6,5,7}[k];  b=3: half of value {8,8,9,9}[k].
 __device__ inline float wave_sum10_banked(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, float v8, float v9) {
     const float p0 = swap32_add(v0, v1), p1 = swap32_add(v2, v3), p2 = swap32_add(v4, v5), p3 = swap32_add(v6, v7), p4 = swap32_add(v8, v9);
-    float q0 = swap16_add(p0, p1), q1 = swap16_add(p2, p3), q2 = swap16_add(p4, 0.f);
+    // the fifth pair is NOT folded across row pairs (that would cost a zero register, a swap and an add per entry): rows 0, 1 of p4 hold
+    // value 8 and rows 2, 3 value 9; their two row totals land in record words 8 / 10 and 9 / 11, and the per-batch merge adds them
+    float q0 = swap16_add(p0, p1), q1 = swap16_add(p2, p3), q2 = p4;
     float r, r2, t;
     asm volatile(
         "s_nop 1\n\t"
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
     // where this lane's value of wave_sum10_banked belongs in a 12-float record (lanes with (lane & 3) == 0 of banks 0, 2, 3 store)
     const int srow = lane >> 4, sbank = (lane >> 2) & 3;
     const int perm = srow == 0 ? 0 : (srow == 1 ? 2 : (srow == 2 ? 1 : 3));
-    const int st_idx = sbank == 2 ? perm : (sbank == 0 ? 4 + perm : 8 + perm);      // 8 + {0,2,1,3}: 10, 11 are the record's padding words
+    const int st_idx = sbank == 2 ? perm : (sbank == 0 ? 4 + perm : 8 + perm);      // 8 + {0,2,1,3}: rows 0, 1 -> words 8, 10 (value 8), rows 2, 3 -> 9, 11 (value 9)
     const bool st_lane = (lane & 3) == 0 && sbank != 1;
 
     // entries at positions >= the strip's largest n_contrib reach no pixel of this strip
@@ -735,7 +737,8 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
                 for (int w = 0; w < 4; ++w) {
                     if ((s_wrote[w] >> p) & 1ull) {
                         const float4 v = *(const float4*)&s_part[w][p][4 * q];
-                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                        if (q == 2) { acc.x += v.x + v.z; acc.y += v.y + v.w; }      // words 10, 11 = the second row halves of values 8, 9
+                        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
                     }
                 }
                 *(float4*)(a.entry_sum + (size_t)(s_e[p] & ID_MASK) * SLOT_F + 4 * q) = acc;
