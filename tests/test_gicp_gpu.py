@@ -204,6 +204,29 @@ def test_lost_grid_barrier_recovers_on_the_device():
     np.testing.assert_allclose(T2, good["T"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("k,max_iter", [(10, 64), (33, 64), (20, 3)])
+def test_other_neighbourhood_sizes_and_iteration_caps_match_oracle(k, max_iter):
+    """Upstream options the reference leaves at their defaults (set_correspondence_randomness = k of the k-NN covariances,
+    set_max_iterations): other values must track the oracle just the same, including a run that is cut off before convergence."""
+    import oracle
+    import pygicp
+    cfg = synth.TUM
+    sp = synth.s_pair(cfg, noise=True)
+    out = []
+    for reg in (oracle.OracleGICP(), pygicp.FastGICP()):
+        reg.set_correspondence_randomness(k)
+        reg.set_max_iterations(max_iter)
+        out.append((drive(reg, sp, cfg), reg))
+    (po, oreg), (pp, reg) = out
+    st = reg.last_align_stats()
+    assert st["iterations"] == oreg.iterations
+    if max_iter == 3:
+        assert st["iterations"] == 3 and not st["converged"]
+    np.testing.assert_allclose(pp["scales"], po["scales"], rtol=2e-5, atol=1e-7)
+    assert np.array_equal(pp["idx"], po["idx"]) and np.array_equal(pp["d2"], po["d2"])
+    np.testing.assert_allclose(pp["T"], po["T"], rtol=0, atol=1e-6)
+
+
 def test_known_answer_rigid_motion():
     """Source = target moved by a known SE(3): GICP must recover it (no sampling difference, wide gate)."""
     import pygicp

@@ -130,7 +130,7 @@ def test_argument_validation():
         GaussianRasterizer(rs)(means3D=t["means3D"], means2D=None, shs=t["shs"], opacities=t["opacities"], scales=t["scales"])
 
 
-@pytest.mark.parametrize("deg", [0, 3])
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
 def test_backward_small_random(hip_lib, deg):
     cam = synth.make_camera(160, 96, 120.0, 120.0)
     g = synth.random_gaussians(400, seed=20 + deg, sh_degree=deg)
@@ -171,6 +171,45 @@ def test_colors_precomp_and_cov_precomp_paths(hip_lib):
     o0 = util.oracle_forward(g, cam, [0, 0, 0], 0)
     g2 = dict(means3D=g["means3D"], opacities=g["opacities"], colors_precomp=o0["geom"][:, 7:10].copy(), scales=g["scales"], rotations=g["rotations"])
     check_forward(g2, cam, [0, 0, 0], 0, hip_lib, "colors_precomp")
+
+
+def _cov3d_from(scales, quats_xyzw):
+    """6 unique entries (xx, xy, xz, yy, yz, zz) of R diag(s^2) R^T — what GaussianModel.get_covariance hands over as cov3D_precomp
+    [REF scene/gaussian_model.py:28-33; utils/general_utils.py:73-123]."""
+    x, y, z, r = [quats_xyzw[:, i].astype(np.float64) for i in range(4)]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                  2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+    M = R * scales[:, None, :].astype(np.float64)
+    S = M @ np.swapaxes(M, 1, 2)
+    return np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1).astype(np.float32)
+
+
+def test_precomputed_covariance_and_colour_paths_forward_and_backward(hip_lib):
+    """The two optional input forms of the API [REF gaussian_renderer/__init__.py:268-292: pipe.compute_cov3D_python / convert_SHs_python]:
+    cov3D_precomp instead of (scales, rotations) and colors_precomp instead of SHs — forward lists / images and the gradients that reach
+    the precomputed tensors themselves (dL/dcov3D, dL/dcolors), against the oracle."""
+    cam = synth.make_camera(160, 96, 120.0, 120.0)
+    g = synth.random_gaussians(400, seed=23)
+    rng = np.random.default_rng(4)
+    gp = dict(means3D=g["means3D"], opacities=g["opacities"], colors_precomp=rng.uniform(0, 1, (400, 3)).astype(np.float32),
+              cov3D_precomp=_cov3d_from(g["scales"], g["rotations"]))
+    bg = [0.2, 0.0, 0.1]
+    check_forward(gp, cam, bg, 0, hip_lib, "cov3D_precomp + colors_precomp")
+    gc = rng.normal(size=(3, 96, 160)).astype(np.float32)
+    gd = rng.normal(size=(96, 160)).astype(np.float32)
+    o = util.oracle_backward(gp, cam, bg, gc, gd, 0)
+    o64 = util.oracle_backward({k: v.astype(np.float64) for k, v in gp.items()}, cam, bg, gc, gd, 0, dtype=np.float64)
+    p = run_product(gp, cam, bg, 0, grads=(gc, gd))
+    assert p["grads"].get("scales") is None and p["grads"].get("rotations") is None
+    for name, key in [("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("cov3D_precomp", "dL_dcov3D"), ("colors_precomp", "dL_dcolors"),
+                      ("means2D", "dL_dmeans2D")]:
+        a, b, b64 = p["grads"][name].reshape(-1).astype(np.float64), o[key].reshape(-1).astype(np.float64), o64[key].reshape(-1)
+        mx = np.abs(b).max()
+        assert (np.abs(a - b) <= 2e-4 * mx + 1e-4 * np.abs(b) + 2 * np.abs(b - b64)).all(), f"{name}: {np.abs(a - b).max() / mx:.3e} of max"
+    # the same scene through (scales, rotations) renders the same image (the covariance is the same matrix, up to its float32 rounding)
+    gs = dict(means3D=g["means3D"], opacities=g["opacities"], colors_precomp=gp["colors_precomp"], scales=g["scales"], rotations=g["rotations"])
+    q = run_product(gs, cam, bg, 0)
+    assert np.abs(q["color"] - p["color"]).max() < 2e-3
 
 
 def test_tile_sharding_composes_to_full_image(hip_lib):
