@@ -29,12 +29,12 @@ SIGNATURES = {
     "gsicp_raster_forward_async": (c_int, [RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, RESIZE_FN, c_void_p, c_int, c_int, c_int, c_void_p,
                                            c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                           c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "gsicp_raster_backward_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gsicp_raster_backward": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "gsicp_raster_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_raster_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "gsicp_knn_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),

@@ -797,7 +797,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                          const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                          float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
                          int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode, int capacity, unsigned int* num_rendered_dev,
-                         const int* live_rows, void* stream_v) {
+                         const int* live_rows, int raw_params, void* stream_v) {
     (void)prefiltered; (void)debug;
     if (depth_mode < 0 || depth_mode > 1) { g_last_error = "depth_mode: 0 = sum z alpha T, 1 = alpha-normalised"; return -2; }
     const bool async = capacity > 0 && P > 0;   // capacity given: no host round trip, R stays on the device
@@ -842,7 +842,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     int num_rendered = 0;
     if (P > 0) {
         PreprocessArgs pa;
-        pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.live_rows = live_rows;
+        pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.live_rows = live_rows; pa.raw_params = raw_params;
         pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp; pa.opacities = opacities; pa.scales = scales;
         pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.scale_modifier = scale_modifier;
         pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos; pa.tanfovx = tan_fovx; pa.tanfovy = tan_fovy;
@@ -950,7 +950,7 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
     return raster_forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width, height,
                                means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
                                projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, radii, is_used, tile_mod,
-                               tile_rem, debug, depth_mode, 0, nullptr, nullptr, stream);
+                               tile_rem, debug, depth_mode, 0, nullptr, nullptr, 0, stream);
 }
 
 int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
@@ -960,12 +960,12 @@ int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
                                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
                                int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode, int capacity,
-                               unsigned int* num_rendered_dev, const int* live_rows_dev, void* stream) {
+                               unsigned int* num_rendered_dev, const int* live_rows_dev, int raw_params, void* stream) {
     if (capacity <= 0) { g_last_error = "gsicp_raster_forward_async: capacity must be positive"; return -2; }
     return raster_forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width, height,
                                means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
                                projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, radii, is_used, tile_mod,
-                               tile_rem, debug, depth_mode, capacity, num_rendered_dev, live_rows_dev, stream);
+                               tile_rem, debug, depth_mode, capacity, num_rendered_dev, live_rows_dev, raw_params, stream);
 }
 
 size_t gsicp_raster_backward_scratch_bytes(int num_rendered, int width, int height) {
@@ -982,7 +982,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
                           const float* dL_dpix, const float* dL_ddepth, float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity,
                           float* dL_dcolors, float* dL_ddepths, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                           float* dL_dscales, float* dL_drots, int tile_mod, int tile_rem, int debug, int depth_mode, const float* out_depth,
-                          const int* live_rows_dev, void* stream_v) {
+                          const int* live_rows_dev, int raw_params, void* stream_v) {
     (void)debug;
     if (depth_mode < 0 || depth_mode > 1 || (depth_mode == 1 && dL_ddepth && !out_depth)) {
         g_last_error = "gsicp_raster_backward: depth_mode 1 needs the forward's depth image"; return -2;
@@ -1019,7 +1019,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     }
 
     PreprocessBwdArgs pb;
-    pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.live_rows = live_rows_dev;
+    pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.live_rows = live_rows_dev; pb.raw_params = raw_params;
     pb.means3D = means3D; pb.shs = shs; pb.colors_precomp = colors_precomp; pb.scales = scales; pb.rotations = rotations;
     pb.cov3D_precomp = cov3D_precomp; pb.scale_modifier = scale_modifier; pb.view = viewmatrix; pb.proj = projmatrix;
     pb.campos = cam_pos; pb.tanfovx = tan_fovx; pb.tanfovy = tan_fovy; pb.radii = radii;

@@ -78,6 +78,7 @@ inline ImgLayout img_layout(int W, int H) {
 struct PreprocessArgs {
     int P, D, M, W, H;
     const int* live_rows;      // DEVICE, optional: only rows [0, min(P, *live_rows)) are Gaussians (capacity-backed map, captured graphs)
+    int raw_params;            // 1: opacities / scales / rotations are GaussianModel's RAW parameters; sigmoid / exp / normalize happen here
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     float scale_modifier;
     const float *view, *proj, *campos;
@@ -95,6 +96,7 @@ static_assert(sizeof(SplatRec) == 48, "SplatRec must stay 48 bytes");
 struct PreprocessBwdArgs {
     int P, D, M, W, H;
     const int* live_rows;      // DEVICE, optional (see PreprocessArgs)
+    int raw_params;            // 1: scales / rotations are raw and dL_dopacity / dL_dscales / dL_drots are gradients w.r.t. the RAW parameters
     const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;
     float scale_modifier;
     const float *view, *proj, *campos;

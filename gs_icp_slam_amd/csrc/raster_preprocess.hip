@@ -136,6 +136,15 @@ __device__ inline void sh_to_rgb(int deg, const float* mean, const float* campos
     *clampmask = m;
 }
 
+// GaussianModel's activation getters [REF scene/gaussian_model.py:44-56, 105-125], applied in place of a separate launch when the caller hands
+// over the raw parameters (raw_params): the same formulas as activations_forward_kernel / torch (sigmoid, exp, x / max(||x||, 1e-12)).
+__device__ inline float act_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ inline float act_normalize4(const float* r, float* y) {
+    const float n = fmaxf(sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]), 1e-12f);
+    y[0] = r[0] / n; y[1] = r[1] / n; y[2] = r[2] / n; y[3] = r[3] / n;
+    return n;
+}
+
 __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool in_range = idx < a.P;
@@ -169,8 +178,13 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) c6[k] = a.cov3D_precomp[6 * idx + k];
         } else {
-            const float s[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-            const float q[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]};
+            float s[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+            float q[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]};
+            if (a.raw_params) {
+                s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]);
+                const float raw[4] = {q[0], q[1], q[2], q[3]};
+                (void)act_normalize4(raw, q);
+            }
             cov3_from_scale_rot(s, a.scale_modifier, q, c6);
         }
         float Mm[6], abc[3];
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
                 }
                 rec.r = rgb[0]; rec.g = rgb[1]; rec.b = rgb[2];
                 rec.depth = pv[2];
-                rec.opacity = a.opacities[idx];
+                rec.opacity = a.raw_params ? act_sigmoid(a.opacities[idx]) : a.opacities[idx];
                 // Footprint of alpha = min(0.99, o * exp(power)) >= 1/255:  q(d) = -2 power <= 2 ln(255 o).  Its bounding
                 // box has half-extents sqrt(2 tau * Sigma2_xx), sqrt(2 tau * Sigma2_yy).  tau is padded by 0.01 (1 % in
                 // alpha) and the box by half a pixel, far more than any fp32 / __expf rounding, so culling with it never
@@ -330,6 +344,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     const bool visible = a.radii[i] > 0 && (a.live_rows == nullptr || i < *a.live_rows);
     const bool use_sh = (a.colors_precomp == nullptr) && (a.dL_dsh != nullptr);
+    float sc_act[3] = {1.f, 1.f, 1.f}, q_act[4] = {0.f, 0.f, 0.f, 1.f}, q_norm_v = 1.f;   // activated scales / quaternion and the raw norm (raw_params)
     // screen-space gradient sums of this Gaussian: its emission slots are one contiguous run of entry_sum
     float gs[NGRAD];
 #pragma unroll
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     }
     a.dL_dmean2D[3 * i] = gs[0]; a.dL_dmean2D[3 * i + 1] = gs[1]; a.dL_dmean2D[3 * i + 2] = 0.f;
     a.dL_dconic[4 * i] = gs[2]; a.dL_dconic[4 * i + 1] = gs[3]; a.dL_dconic[4 * i + 2] = gs[4]; a.dL_dconic[4 * i + 3] = 0.f;
-    a.dL_dopacity[i] = gs[5];
+    a.dL_dopacity[i] = (a.raw_params && visible) ? gs[5] * a.rec[i].opacity * (1.f - a.rec[i].opacity) : gs[5];   // sigmoid' = o (1 - o)
     a.dL_dcolors[3 * i] = gs[6]; a.dL_dcolors[3 * i + 1] = gs[7]; a.dL_dcolors[3 * i + 2] = gs[8];
     a.dL_ddepths[i] = gs[9];
     if (visible) {
@@ -379,6 +394,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
         const float p[3] = {a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]};
         float c6[6];
         float q[4] = {0.f, 0.f, 0.f, 1.f}, sc[3] = {1.f, 1.f, 1.f};
+        float q_raw[4] = {0.f, 0.f, 0.f, 1.f}, q_norm = 1.f;
         if (a.cov3D_precomp) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) c6[k] = a.cov3D_precomp[6 * i + k];
@@ -387,6 +403,19 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
             for (int k = 0; k < 3; ++k) sc[k] = a.scales[3 * i + k];
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k] = a.rotations[4 * i + k];
+            if (a.raw_params) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) sc[k] = expf(sc[k]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q_raw[k] = q[k];
+                q_norm = act_normalize4(q_raw, q);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sc_act[k] = sc[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q_act[k] = q[k];
+            q_norm_v = sqrtf(q_raw[0] * q_raw[0] + q_raw[1] * q_raw[1] + q_raw[2] * q_raw[2] + q_raw[3] * q_raw[3]);
+            (void)q_norm;
             cov3_from_scale_rot(sc, a.scale_modifier, q, c6);
         }
         float pv[3], Mm[6], tcl[3], abc[3];
@@ -481,6 +510,20 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     for (int k = 0; k < 3; ++k) a.dL_dmeans3D[3 * i + k] = dm[k];
 #pragma unroll
     for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = dcov[k];
+    if (a.raw_params && visible && !a.cov3D_precomp) {
+        // chain rule of the activations (as activations_backward_kernel): exp' = s;  normalize: (g - y (y . g)) / n above the 1e-12 clamp
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dsc[k] *= sc_act[k];
+        const float dot = q_act[0] * drot[0] + q_act[1] * drot[1] + q_act[2] * drot[2] + q_act[3] * drot[3];
+        if (q_norm_v > 1e-12f) {
+            const float inv = 1.f / q_norm_v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) drot[k] = (drot[k] - q_act[k] * dot) * inv;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) drot[k] *= 1e12f;
+        }
+    }
     if (a.dL_dscales) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) a.dL_dscales[3 * i + k] = dsc[k];

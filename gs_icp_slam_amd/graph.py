@@ -41,8 +41,12 @@ class MapperIterationGraph:
     (e.g. 1.5x the count of an eager forward; `overflowed()` tells when it was too small)."""
 
     def __init__(self, params, optimizer, image_height, image_width, tanfovx, tanfovy, sh_degree, capacity, bg=None, lambda_dssim=0.2,
-                 depth_weight=0.1, d_max=10.0, activations=default_activations, rasterizer_factory=None, warmup=2, live_count=None,
+                 depth_weight=0.1, d_max=10.0, activations=None, rasterizer_factory=None, warmup=2, live_count=None,
                  depth_mode=0):
+        # activations=None (default): the rasteriser takes the RAW parameters and applies sigmoid / exp / normalize and their chain rule inside
+        # its preprocess kernels (GaussianRasterizationSettings.raw_params) — two launches and 64 B per Gaussian of traffic less per iteration;
+        # pass default_activations / torch_activations to run them as separate operators instead.
+        fused = activations is None
         if not isinstance(optimizer, FusedAdam) or not optimizer.capturable:
             raise RuntimeError("MapperIterationGraph needs FusedAdam(capturable=True): a host-side step count cannot be replayed")
         if capacity <= 0:
@@ -63,7 +67,8 @@ class MapperIterationGraph:
         rs = GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=float(tanfovx), tanfovy=float(tanfovy), bg=self.bg, scale_modifier=1.0,
             viewmatrix=self.viewmatrix, projmatrix=self.projmatrix, sh_degree=int(sh_degree), campos=self.campos, prefiltered=False,
-            debug=False, capacity=self.capacity, live_count=live_count, depth_mode=int(depth_mode))
+            debug=False, capacity=self.capacity, live_count=live_count, depth_mode=int(depth_mode), raw_params=fused)
+        self._fused_activations = fused
         # live_count (int32[1] device tensor): `params` are the FULL-CAPACITY buffers of a GaussianStore(stable=True) and only the first
         # live_count[0] rows are Gaussians.  Growth and pruning then change that number and rows in place — no pointer, shape or launch grid
         # of the captured iteration changes, so ONE capture serves the whole run [REF mp_Mapper.py:161-195, 244-245 append / prune].
@@ -113,7 +118,11 @@ class MapperIterationGraph:
         self.gt_depth.copy_(gt_depth.reshape(self.gt_depth.shape), non_blocking=True)
 
     def _iteration(self):
-        a = self.activations(self.params, self.live_count) if self.live_count is not None else self.activations(self.params)
+        if self._fused_activations:
+            a = dict(means3D=self.params["means3D"], shs=self.params["shs"], opacities=self.params["opacities"], scales=self.params["scales"],
+                     rotations=self.params["rotations"])
+        else:
+            a = self.activations(self.params, self.live_count) if self.live_count is not None else self.activations(self.params)
         depth, color, radii, used = self.rasterizer(means3D=a["means3D"], means2D=self._means2D, shs=a["shs"], opacities=a["opacities"],
                                                     scales=a["scales"], rotations=a["rotations"])
         # the loss kernels produce dL/dimage and dL/ddepth directly: no autograd node, no ones_like / multiply launches

@@ -45,6 +45,9 @@ class GaussianRasterizationSettings(NamedTuple):
     # Extension: int32[1] DEVICE tensor holding the number of live Gaussians when the input tensors are the full-capacity buffers of a
     # preallocated map (gs_icp_slam_amd/gaussian_store.py): rows behind it are ignored.  Needs capacity > 0 (the sync-free forward).
     live_count: object = None
+    # Extension: opacities / scales / rotations are GaussianModel's RAW parameters (_opacity, _scaling, _rotation); sigmoid / exp / normalize
+    # [REF scene/gaussian_model.py:44-56] and their chain rule run inside the preprocess kernels.  Needs capacity > 0.
+    raw_params: bool = False
 
 
 def _ptr(t):
@@ -120,8 +123,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise RuntimeError("GaussianRasterizationSettings.live_count needs capacity > 0 (the sync-free forward)")
             if live is not None and (not live.is_cuda or live.dtype != torch.int32 or live.numel() != 1):
                 raise RuntimeError("GaussianRasterizationSettings.live_count must be an int32[1] device tensor")
+            raw = bool(getattr(rs, "raw_params", False))
+            if raw and not (capacity > 0 and P > 0 and cov_c is None):
+                raise RuntimeError("GaussianRasterizationSettings.raw_params needs capacity > 0 and (scales, rotations) inputs")
             if capacity > 0 and P > 0:
-                n = lib.gsicp_raster_forward_async(*args, capacity, _ptr(count_out), _ptr(live), stream)
+                n = lib.gsicp_raster_forward_async(*args, capacity, _ptr(count_out), _ptr(live), int(raw), stream)
             else:
                 n = lib.gsicp_raster_forward(*args, stream)
                 if count_out is not None:
@@ -171,7 +177,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), _ptr(dL_dmeans3D),
                 _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drots), int(rs.tile_mod), int(rs.tile_rem),
                 int(bool(rs.debug)), ctx.depth_mode, _ptr(depth_out.detach() if depth_out is not None else None),
-                _ptr(getattr(rs, "live_count", None)), stream)
+                _ptr(getattr(rs, "live_count", None)), int(bool(getattr(rs, "raw_params", False))), stream)
             _lib.check(rc, "gsicp_raster_backward")
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors if col_c is not None else None, dL_dopacity, dL_dscales, dL_drots,
                 dL_dcov3D if cov_c is not None else None, None, None)

@@ -83,6 +83,10 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
  *   arrays is ignored (treated as culled; zero gradients): P is then the CAPACITY of a preallocated map whose live count changes on the
  *   device — every pointer and launch grid stays what it was, so a captured graph survives map growth and pruning (pass the same
  *   pointer to gsicp_raster_backward, the activation operators and gsicp_adam_step_guarded).
+ *   raw_params: 1 = `opacities`, `scales`, `rotations` are GaussianModel's RAW parameters (logit opacity, log scales, un-normalised
+ *   quaternion) and the activation getters [REF scene/gaussian_model.py:44-56, 105-125] — sigmoid, exp, x / max(||x||, 1e-12) — are applied
+ *   inside the preprocess kernel; gsicp_raster_backward with the same flag then returns dL_dopacity / dL_dscales / dL_drots with respect
+ *   to the raw parameters (two element-wise launches and 64 B per Gaussian of traffic less per iteration).
  * Returns `capacity`; pass that value as `num_rendered` to gsicp_raster_backward_scratch_bytes / gsicp_raster_backward. */
 int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
                                gsicp_resize_fn img_alloc, void* img_user, int P, int D, int M, const float* background,
@@ -91,7 +95,7 @@ int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                                float* out_depth, int* radii, int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode,
-                               int capacity, unsigned int* num_rendered_dev, const int* live_rows_dev, void* stream);
+                               int capacity, unsigned int* num_rendered_dev, const int* live_rows_dev, int raw_params, void* stream);
 
 /* Bytes of DEVICE scratch gsicp_raster_backward needs (one 48-byte gradient record per (Gaussian, tile) duplicate; contents need no
  * initialisation and are dead after the call). */
@@ -114,7 +118,8 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
                           const char* img_buffer, char* scratch, const float* dL_dpix, const float* dL_ddepth,
                           float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_ddepths,
                           float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, int tile_mod,
-                          int tile_rem, int debug, int depth_mode, const float* out_depth, const int* live_rows_dev, void* stream);
+                          int tile_rem, int debug, int depth_mode, const float* out_depth, const int* live_rows_dev, int raw_params,
+                          void* stream);
 
 /* present[i] = 1 iff Gaussian i passes the frustum test (view-space z > 0.2).  Asynchronous. */
 int gsicp_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

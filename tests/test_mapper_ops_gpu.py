@@ -118,3 +118,41 @@ def test_fused_activations_match_torch_ops():
     assert torch.all(c[1].grad == 0) and torch.all(c[2].grad == 0)
     with pytest.raises(RuntimeError):
         activate(*[r.cpu() for r in raw])
+
+
+def test_raw_parameter_rasteriser_equals_activations_plus_rasteriser():
+    """GaussianRasterizationSettings(raw_params=True): sigmoid / exp / normalize and their chain rule inside the preprocess kernels must give
+    what the separate activation operator followed by the rasteriser gives — same lists, images to rounding, gradients w.r.t. the RAW
+    parameters to 1e-5 of their maximum."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gs_icp_slam_amd import synth
+    from gs_icp_slam_amd.activations import activate
+    from tests.util import make_settings
+    P, W, H = 20000, 320, 200
+    cfg = synth.REPLICA
+    cam = synth.make_camera(W, H, cfg["fx"] * W / cfg["W"], cfg["fy"] * H / cfg["H"], synth.DEFAULT_POSE_A)
+    g = synth.s_map(P, seed=9)
+    raw = {"means3D": torch.from_numpy(g["means3D"]), "scales": torch.log(torch.from_numpy(g["scales"])),
+           "rotations": torch.from_numpy(g["rotations"]) * 1.7,          # un-normalised on purpose
+           "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-4, 1 - 1e-4)), "shs": torch.from_numpy(g["shs"])}
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    wc, wd = torch.rand((3, H, W), device="cuda", generator=gen), torch.rand((1, H, W), device="cuda", generator=gen)
+    outs = []
+    for fused in (False, True):
+        t = {k: v.clone().cuda().requires_grad_(True) for k, v in raw.items()}
+        rs = make_settings(cam, [0.0, 0.0, 0.0])._replace(capacity=2_000_000, raw_params=fused)
+        m2 = torch.zeros_like(t["means3D"], requires_grad=True)
+        if fused:
+            o, s_, q = t["opacities"], t["scales"], t["rotations"]
+        else:
+            o, s_, q = activate(t["opacities"], t["scales"], t["rotations"])
+        depth, color, radii, used = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=m2, shs=t["shs"], opacities=o, scales=s_, rotations=q)
+        ((color * wc).sum() + (depth * wd).sum()).backward()
+        outs.append((depth.detach(), color.detach(), radii, {k: v.grad.clone() for k, v in t.items()}, m2.grad.clone()))
+    (d0, c0, r0, g0, m0), (d1, c1, r1, g1, m1) = outs
+    assert (r0 != r1).sum() <= 2                      # a 1-ulp difference in a scale may move a 3-sigma radius across an integer
+    assert float((c0 - c1).abs().max()) < 2e-5 and float((d0 - d1).abs().max()) < 1e-4
+    for k in g0:
+        mx = float(g0[k].abs().max())
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * mx + 1e-12, (k, float((g0[k] - g1[k]).abs().max()), mx)
+    assert float((m0 - m1).abs().max()) <= 2e-5 * float(m0.abs().max())
