@@ -333,7 +333,9 @@ __device__ inline void bitonic_pairs(unsigned long long* __restrict__ s_key, uin
 // Lists up to SORT_CAP entries are bitonic-sorted in LDS; longer ones are sorted in SORT_CAP-entry chunks and merged by rank
 // (binary searches across the sorted chunks) — not reached by the scenes in BASELINE.json, whose longest lists are a few hundred entries.
 constexpr int SORT_CAP = 4096;     // long-list kernel: 1024 threads, 48 KB LDS, a small persistent grid over the head of the LPT order
-constexpr int SORT_SMALL = 512;    // small-list kernel: 128 threads, 6 KB LDS -> many workgroups per CU (a one-wave variant measured slower)
+constexpr int SORT_SMALL = 1024;   // short-list kernel: 256 threads (one wave does all the work of a <= 128-entry list; the others only meet it at
+                                   // three barriers), 12 KB LDS -> many workgroups per CU.  With the pair-per-thread network a 1024-entry list costs this
+                                   // class ~6 us, so the long class only sees lists the BASELINE scenes never produce
 template <int CAP, int THREADS, int MIN_N>
 __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uint32_t* __restrict__ s_val, const uint32_t tile,
                                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ sc_keys, const uint32_t* __restrict__ sc_vals,
@@ -919,7 +921,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                              (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
                              (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss)); }
         { ProfileScope ps(ST_TILE_SORT, stream);
-          hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 128, 0>), dim3(n_local), dim3(128), 0, stream, n_local, (const uint32_t*)nullptr, order, ranges,
+          hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 256, 0>), dim3(n_local), dim3(256), 0, stream, n_local, (const uint32_t*)nullptr, order, ranges,
                              (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
                              (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss)); }
     }
