@@ -94,11 +94,44 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N > 1: the captured iteration carries two RCCL calls.  Whether this stack can capture and replay them across N GPUs is probed in a
+    # child process with its own rendezvous and a timeout BEFORE this process joins its group (a capture that hangs must not take the
+    # benchmark with it); GSICP_BENCH_RCCL_GRAPH=0 / 1 skips the probe and forces eager / graph.
+    rccl_graph_probe = None
+    if world > 1 and not args.no_graph and os.environ.get("GSICP_BENCH_BACKEND", "nccl") == "nccl":
+        forced = os.environ.get("GSICP_BENCH_RCCL_GRAPH")
+        if forced is not None:
+            rccl_graph_probe = {"ok": forced == "1", "how": f"GSICP_BENCH_RCCL_GRAPH={forced}"}
+        else:
+            import subprocess
+            env = dict(os.environ, MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                       MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23))
+            for k in list(env):     # the child rendezvous is a plain env:// one, not torchrun's agent store
+                if k.startswith("TORCHELASTIC") or k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING",):
+                    env.pop(k)
+            t0p = time.perf_counter()
+            try:
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_graph_probe.py")], env=env, capture_output=True, text=True,
+                                    timeout=float(os.environ.get("GSICP_BENCH_PROBE_TIMEOUT", "240")))
+                rccl_graph_probe = {"ok": pr.returncode == 0, "how": f"tools/rccl_graph_probe.py rc={pr.returncode}",
+                                    "seconds": round(time.perf_counter() - t0p, 1)}
+                for line in pr.stdout.splitlines():
+                    if line.startswith("{"):
+                        rccl_graph_probe.update(json.loads(line))
+            except subprocess.TimeoutExpired:
+                rccl_graph_probe = {"ok": False, "how": "tools/rccl_graph_probe.py timed out", "seconds": round(time.perf_counter() - t0p, 1)}
     # GSICP_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (functional check only).
     backend = os.environ.get("GSICP_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # GSICP_BENCH_FORCE_COLLECTIVES=1 (diagnostic, one GPU): join a 1-rank RCCL group and run the N > 1 iteration — movers and both
+    # collectives captured in the graph — so that the cost of the exchange machinery without wire time can be measured on a 1-GPU box.
+    force_coll = world == 1 and os.environ.get("GSICP_BENCH_FORCE_COLLECTIVES") == "1"
+    if force_coll:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -117,7 +150,11 @@ def main():
            "rotations": torch.from_numpy(g["rotations"]),
            "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-4, 1 - 1e-4)), "shs": torch.from_numpy(g["shs"])}
     params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in raw.items()}
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph
+    if world > 1:
+        ok = torch.tensor([1.0 if (rccl_graph_probe or {}).get("ok") else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank must have seen the probe succeed
+        use_graph = use_graph and bool(ok.item() == 1.0)
     optimizer = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in LRS.items()], lr=0.0, eps=1e-15, capturable=use_graph)
     rs = GaussianRasterizationSettings(
         image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev), scale_modifier=1.0,
@@ -212,13 +249,14 @@ def main():
             probe = GaussianRasterizer(rs._replace(capacity=cap, tile_mod=world, tile_rem=rank))
             with torch.no_grad():
                 a0 = activated()
-                probe(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"],
-                      scales=a0["scales"], rotations=a0["rotations"])
+                probe_radii[0] = probe(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"],
+                                       scales=a0["scales"], rotations=a0["rotations"])[2]
             r = int(probe.num_rendered.item())
             if r <= cap:
-                return int(1.5 * r) + 4096
+                return int(1.5 * r) + 4096, int(1.5 * int((probe_radii[0] > 0).sum())) + 1024
             cap *= 2
-    capacity = probe_capacity()
+    probe_radii = [None]
+    capacity, vis_capacity = probe_capacity()      # vis_capacity: rows of the static gradient all-reduce block (same on every rank: radii are replicated)
     rast = ShardedGaussianRasterizer(rs._replace(capacity=capacity))   # eager iterations also run without the forward's host sync
 
     mg = None
@@ -227,8 +265,11 @@ def main():
         # Single GPU: the whole iteration is one hipGraph launch (gs_icp_slam_amd/graph.py); the keyframe (camera + targets) is
         # re-selected before every replay, as the reference's mapper does [REF mp_Mapper.py:205-217].
         from gs_icp_slam_amd.graph import MapperIterationGraph
+        # N > 1: the tile-sharded rasteriser with its static-size exchange (tile chunks all-gathered, visible gradient rows all-reduced) is
+        # captured in the same graph, RCCL calls included (gs_icp_slam_amd/sharded.py)
+        factory = (lambda rs_: ShardedGaussianRasterizer(rs_, vis_capacity=vis_capacity, force_collectives=force_coll)) if (world > 1 or force_coll) else None
         mg = MapperIterationGraph(params, optimizer, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=capacity,
-                                  lambda_dssim=0.2, warmup=2)
+                                  lambda_dssim=0.2, warmup=2, rasterizer_factory=factory)
         mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_color, gt_depth)
         mg.capture()
 
@@ -279,8 +320,9 @@ def main():
         step()
     blocks = timed_blocks(step, args.steps, max(1, args.repeats))
     dt = statistics.median(blocks)
-    if mg is not None and mg.overflowed():
-        raise RuntimeError(f"duplicate-list capacity overflowed during the timed region: R = {int(mg.num_rendered.item())} > {mg.capacity}")
+    if mg is not None and (mg.overflowed() or mg.skipped_steps() > 0):
+        raise RuntimeError(f"capacity overflowed during the timed region: R = {int(mg.num_rendered.item())} (capacity {mg.capacity}), "
+                           f"{mg.skipped_steps()} optimiser steps skipped")
     if mg is None and int(rast.inner.num_rendered.item()) > capacity:
         raise RuntimeError("duplicate-list capacity overflowed during the timed region")
     align_stats = trk.reg.last_align_stats() if args.only != "mapper" else {}
@@ -559,9 +601,14 @@ def main():
                        "tracker_pair": args.pair, "tracker_motion": motions[args.pair], "lm_iterations": it,
                        "gaussians": P, "width": W, "height": H, "duplicates_per_rank": D_local, "visible_gaussians": P_vis,
                        "tracker_mapper_overlap": worker is not None,
-                       "mapper_iteration": "one hipGraph replay per iteration" if mg is not None else "eager launches from Python",
+                       "mapper_iteration": (("one hipGraph replay per iteration" + (" (tile all-gather + gradient all-reduce captured inside)" if (world > 1 or force_coll) else ""))
+                                            if mg is not None else "eager launches from Python"),
+                       "rccl_graph_probe": rccl_graph_probe,
+                       "exchange_bytes_per_rank": ({"image_all_gather_chunk": mg.rasterizer.holder.last_image_bytes,
+                                                    "gradient_all_reduce_block": mg.rasterizer.holder.last_volume_bytes}
+                                                   if (mg is not None and (world > 1 or force_coll)) else None),
                        "variants": {"depth_mode": "sum z alpha T (un-normalised)", "fromqs_scale_mode": "s^2", "regularization": "PLANE"},
-                       "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-reduce image + grads), tracker replicated",
+                       "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-gather of own tiles + all-reduce of visible gradient rows), tracker replicated",
                        "world_size": world, "backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen},
             "render_bwd_ms_per_iter": round(sum(v for k, v in per_launch_us.items() if not k.startswith("gicp")) / 1e3, 4),
             "tracker_align_kernel_us": stage_us.get("gicp_align"),
@@ -571,7 +618,7 @@ def main():
         print(json.dumps(out))
     if worker is not None:
         jobs.put(None)
-    if world > 1:
+    if world > 1 or force_coll:
         dist.destroy_process_group()
 
 

@@ -43,6 +43,12 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p]),
     "gsicp_store_compact_scratch_bytes": (c_size_t, [c_int]),
     "gsicp_store_compact": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsicp_tiles_chunk_floats": (c_size_t, [c_int, c_int, c_int]),
+    "gsicp_tiles_pack": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsicp_tiles_unpack": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsicp_rows_pack_scratch_bytes": (c_size_t, [c_int]),
+    "gsicp_rows_pack": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p]),
+    "gsicp_rows_unpack": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_set_view": (c_int, [c_int, c_int] + [c_void_p] * 11),
     "gsicp_mapper_activations_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_activations_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -117,7 +123,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.gsicp_abi_version() != 2:
+        if lib.gsicp_abi_version() != 3:
             raise ImportError("libgsicp_hip.so ABI version mismatch")
         if os.environ.get("GSICP_ANNOUNCE"):   # tools/run_reference_slam.py: show which processes of the reference run loaded the library
             print(f"GSICP_LOADED {LIB_PATH} pid={os.getpid()}", flush=True)

@@ -516,6 +516,78 @@ __global__ __launch_bounds__(256) void activations_backward_kernel(int P, const 
     }
 }
 
+
+// ---- multi-GPU mapper: the gradient rows of the visible Gaussians, packed for ONE all-reduce -----------------------------------
+// Every rank preprocesses all Gaussians, so radii (and with them the packed order: ascending Gaussian index) are identical everywhere; the
+// packed block has a static size (row_capacity rows + one flag word), so the all-reduce can sit inside a captured hipGraph.
+constexpr int PACK_MAX_ARRAYS = 8;
+struct PackTable {
+    float* arr[PACK_MAX_ARRAYS];     // (P, width) row-major gradient tensors
+    int width[PACK_MAX_ARRAYS];
+    int offset[PACK_MAX_ARRAYS];     // column of the array's first float inside a packed row
+    int n_arrays, row_floats;
+};
+__global__ __launch_bounds__(256) void rows_count_kernel(int P, const int* __restrict__ radii, unsigned* __restrict__ block_count) {
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long b = __ballot(i < P && radii[i] > 0);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// PACK = true: rows -> packed (and the local overflow flag); false: packed -> rows of the visible Gaussians (and the global flag).
+template <bool PACK>
+__global__ __launch_bounds__(256) void rows_move_kernel(int P, const int* __restrict__ radii, const unsigned* __restrict__ block_base,
+                                                        const int* __restrict__ n_vis, PackTable t, float* __restrict__ packed, int row_capacity,
+                                                        const unsigned* __restrict__ guard_count, unsigned guard_limit,
+                                                        unsigned* __restrict__ overflow_out) {
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* flag = packed + (size_t)row_capacity * t.row_floats;
+    if (i == 0) {
+        if (PACK) *flag = (*n_vis > row_capacity || (guard_count && *guard_count > guard_limit)) ? 1.f : 0.f;
+        else if (overflow_out) *overflow_out = *flag > 0.f ? 1u : 0u;      // after the all-reduce: some rank overflowed
+    }
+    const bool k = i < P && radii[i] > 0;
+    const unsigned long long b = __ballot(k);
+    if (lane == 0) s_w[wave] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (!k) return;
+    unsigned pos = block_base[blockIdx.x] + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += s_w[w];
+    if (pos >= (unsigned)row_capacity) return;                              // overflow: flagged above, the optimiser step is skipped
+    float* __restrict__ row = packed + (size_t)pos * t.row_floats;
+    for (int a = 0; a < t.n_arrays; ++a) {
+        const int w = t.width[a];
+        float* __restrict__ g = t.arr[a] + (size_t)i * w;
+        float* __restrict__ r = row + t.offset[a];
+        for (int c = 0; c < w; ++c) { if (PACK) r[c] = g[c]; else g[c] = r[c]; }
+    }
+}
+
+
+// ---- multi-GPU mapper: a rank's own 16x16 tiles (tile t belongs to rank t % tile_mod) as one contiguous all-gather chunk --------------------
+// chunk layout: [k = t / tile_mod][channel: r, g, b, depth][256 pixels of the tile, row-major]; pixels outside the image are zero.
+template <bool PACK>
+__global__ __launch_bounds__(256) void tiles_move_kernel(int W, int H, int gx, int T, int tile_mod, int tile_rem, int chunk_tiles,
+                                                         float* __restrict__ color, float* __restrict__ depth, float* __restrict__ buf) {
+    // PACK: blockIdx.x = k, own tile t = k * tile_mod + tile_rem.  UNPACK: blockIdx.x = t, source chunk of rank t % tile_mod.
+    const int t = PACK ? (int)blockIdx.x * tile_mod + tile_rem : (int)blockIdx.x;
+    const int k = PACK ? (int)blockIdx.x : t / tile_mod;
+    float* __restrict__ slab = buf + ((size_t)(PACK ? 0 : (t % tile_mod)) * chunk_tiles + k) * 1024 + threadIdx.x;
+    const int x = (t % gx) * 16 + (threadIdx.x & 15), y = (t / gx) * 16 + (threadIdx.x >> 4);
+    const bool inside = t < T && x < W && y < H;
+    const size_t HW = (size_t)W * H, pix = (size_t)y * W + x;
+    if (PACK) {
+        slab[0] = inside ? color[pix] : 0.f;
+        slab[256] = inside ? color[HW + pix] : 0.f;
+        slab[512] = inside ? color[2 * HW + pix] : 0.f;
+        slab[768] = inside ? depth[pix] : 0.f;
+    } else if (inside) {
+        color[pix] = slab[0]; color[HW + pix] = slab[256]; color[2 * HW + pix] = slab[512]; depth[pix] = slab[768];
+    }
+}
+
 }  // namespace
 }  // namespace gsicp
 
@@ -592,6 +664,77 @@ int gsicp_store_compact(int n, const unsigned char* keep, int n_arrays, const vo
         hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(256), 0, stream, n, keep, (const unsigned*)block_count, t);
     }
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_store_compact: kernel launch failed"; return -1; }
+    return 0;
+}
+
+size_t gsicp_rows_pack_scratch_bytes(int P) { return ((size_t)(P > 0 ? (P + 255) / 256 : 1) + 2) * sizeof(unsigned); }
+
+static int rows_table(const char* who, int P, const int* radii, int n_arrays, float* const* arrays, const int* row_width, float* packed,
+                      int row_capacity, void* scratch, PackTable& t) {
+    if (P <= 0 || !radii || n_arrays <= 0 || n_arrays > PACK_MAX_ARRAYS || !arrays || !row_width || !packed || row_capacity <= 0 || !scratch) {
+        g_last_error = std::string(who) + ": bad arguments (1..8 arrays, P > 0, row_capacity > 0)"; return -2;
+    }
+    t.n_arrays = n_arrays; t.row_floats = 0;
+    for (int a = 0; a < PACK_MAX_ARRAYS; ++a) { t.arr[a] = nullptr; t.width[a] = 0; t.offset[a] = 0; }
+    for (int a = 0; a < n_arrays; ++a) {
+        if (!arrays[a] || row_width[a] <= 0) { g_last_error = std::string(who) + ": null array or non-positive row width"; return -2; }
+        t.arr[a] = arrays[a]; t.width[a] = row_width[a]; t.offset[a] = t.row_floats; t.row_floats += row_width[a];
+    }
+    return 0;
+}
+
+int gsicp_rows_pack(int P, const int* radii, int n_arrays, const float* const* src, const int* row_width, float* packed, int row_capacity,
+                    const unsigned int* guard_count, unsigned int guard_limit, void* scratch, void* stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    PackTable t;
+    if (int rc = rows_table("gsicp_rows_pack", P, radii, n_arrays, (float* const*)src, row_width, packed, row_capacity, scratch, t)) return rc;
+    const int nblocks = (P + 255) / 256;
+    unsigned* block_count = (unsigned*)scratch;
+    int* n_vis = (int*)(block_count + nblocks);
+    hipLaunchKernelGGL(rows_count_kernel, dim3(nblocks), dim3(256), 0, stream, P, radii, block_count);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, stream, nblocks, block_count, n_vis);
+    hipLaunchKernelGGL(rows_move_kernel<true>, dim3(nblocks), dim3(256), 0, stream, P, radii, (const unsigned*)block_count, (const int*)n_vis, t,
+                       packed, row_capacity, guard_count, guard_limit, (unsigned*)nullptr);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_rows_pack: kernel launch failed"; return -1; }
+    return 0;
+}
+
+int gsicp_rows_unpack(int P, const int* radii, int n_arrays, float* const* dst, const int* row_width, const float* packed, int row_capacity,
+                      const void* scratch, unsigned int* overflow_out, void* stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    PackTable t;
+    if (int rc = rows_table("gsicp_rows_unpack", P, radii, n_arrays, dst, row_width, (float*)packed, row_capacity, (void*)scratch, t)) return rc;
+    const int nblocks = (P + 255) / 256;
+    const unsigned* block_base = (const unsigned*)scratch;
+    hipLaunchKernelGGL(rows_move_kernel<false>, dim3(nblocks), dim3(256), 0, stream, P, radii, block_base, (const int*)(block_base + nblocks), t,
+                       (float*)packed, row_capacity, (const unsigned*)nullptr, 0u, overflow_out);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_rows_unpack: kernel launch failed"; return -1; }
+    return 0;
+}
+
+size_t gsicp_tiles_chunk_floats(int width, int height, int tile_mod) {
+    if (width <= 0 || height <= 0 || tile_mod <= 0) return 0;
+    const size_t T = (size_t)((width + 15) / 16) * ((height + 15) / 16);
+    return ((T + tile_mod - 1) / tile_mod) * 1024;
+}
+
+int gsicp_tiles_pack(int width, int height, int tile_mod, int tile_rem, const float* color, const float* depth, float* chunk, void* stream) {
+    if (width <= 0 || height <= 0 || tile_mod <= 0 || tile_rem < 0 || tile_rem >= tile_mod || !color || !depth || !chunk) {
+        g_last_error = "gsicp_tiles_pack: bad arguments"; return -2;
+    }
+    const int gx = (width + 15) / 16, T = gx * ((height + 15) / 16), chunk_tiles = (T + tile_mod - 1) / tile_mod;
+    hipLaunchKernelGGL(tiles_move_kernel<true>, dim3(chunk_tiles), dim3(256), 0, (hipStream_t)stream, width, height, gx, T, tile_mod, tile_rem,
+                       chunk_tiles, (float*)color, (float*)depth, chunk);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_tiles_pack: kernel launch failed"; return -1; }
+    return 0;
+}
+
+int gsicp_tiles_unpack(int width, int height, int tile_mod, const float* gathered, float* color, float* depth, void* stream) {
+    if (width <= 0 || height <= 0 || tile_mod <= 0 || !gathered || !color || !depth) { g_last_error = "gsicp_tiles_unpack: bad arguments"; return -2; }
+    const int gx = (width + 15) / 16, T = gx * ((height + 15) / 16), chunk_tiles = (T + tile_mod - 1) / tile_mod;
+    hipLaunchKernelGGL(tiles_move_kernel<false>, dim3(T), dim3(256), 0, (hipStream_t)stream, width, height, gx, T, tile_mod, 0, chunk_tiles, color,
+                       depth, (float*)gathered);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_tiles_unpack: kernel launch failed"; return -1; }
     return 0;
 }
 

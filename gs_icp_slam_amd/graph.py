@@ -11,6 +11,9 @@ lives in static device buffers that `set_view()` overwrites before `step()`.  Ev
 Adam state, learning rates, step count) is updated in place by the replay.  The graph is valid while the parameter tensors
 are the ones captured: after the map grows or is pruned (new parameter tensors, [REF scene/gaussian_model.py:409-492]) build
 a new MapperIterationGraph — capture costs about three eager iterations of time but applies NO optimiser update (warm-up is rolled back).
+
+Several GPUs: pass `rasterizer_factory=lambda rs: ShardedGaussianRasterizer(rs, vis_capacity=R)` (sharded.py).  Its two RCCL collectives
+have static sizes and are captured with everything else; the overflow guard then is the all-reduced flag, identical on every rank.
 """
 import ctypes
 
@@ -82,8 +85,12 @@ class MapperIterationGraph:
         inner = self.rasterizer.inner if hasattr(self.rasterizer, "inner") else self.rasterizer
         if getattr(inner, "num_rendered", None) is None:
             inner.num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
-        self._guard_count = inner.num_rendered     # bound to the optimiser in capture(): several graphs (e.g. one per training_stage
-        optimizer.set_overflow_guard(inner.num_rendered, self.capacity)   # resolution) may share one optimiser, each with its own guard
+        self._guard_count, self._guard_limit = inner.num_rendered, self.capacity   # bound to the optimiser in capture(): several graphs (e.g.
+        # one per training_stage resolution) may share one optimiser, each with its own guard
+        shared_guard = self.rasterizer.overflow_guard() if hasattr(self.rasterizer, "overflow_guard") else None
+        if shared_guard is not None:     # tile-sharded across GPUs (sharded.py, static exchange): 1 when ANY rank overflowed, so all ranks skip alike
+            self._guard_count, self._guard_limit = shared_guard
+        optimizer.set_overflow_guard(self._guard_count, self._guard_limit)
         # screen-space gradient holder [REF gaussian_renderer/__init__.py:227]: the reference makes a fresh zero tensor per call;
         # its VALUE is never read by the rasteriser, so one static tensor serves every replay
         self._means2D = torch.zeros_like(params["means3D"], requires_grad=True)
@@ -142,7 +149,7 @@ class MapperIterationGraph:
         update per loop iteration [REF mp_Mapper.py:219-248]."""
         dev = self.params["means3D"].device
         self.optimizer.zero_grad(set_to_none=True)
-        self.optimizer.set_overflow_guard(self._guard_count, self.capacity)   # the launches captured below read THIS graph's count / capacity
+        self.optimizer.set_overflow_guard(self._guard_count, self._guard_limit)   # the launches captured below read THIS graph's count / limit
         if self.live_count is not None:
             self.optimizer.set_live_rows(self.live_count)
         snap_p = {k: v.detach().clone() for k, v in self.params.items()}
@@ -197,6 +204,8 @@ class MapperIterationGraph:
     def overflowed(self):
         """True when the last replay produced more duplicates than the capacity (it then rendered nothing and its optimiser step was
         skipped on the device).  Synchronises."""
+        if self._guard_count is not self.num_rendered and int(self._guard_count.item()) > self._guard_limit:   # sharded: some rank overflowed
+            return True
         return self.num_rendered is not None and int(self.num_rendered.item()) > self.capacity
 
     def skipped_steps(self):

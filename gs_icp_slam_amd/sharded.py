@@ -5,28 +5,41 @@ Every rank holds the full Gaussian set (replicated parameters + optimiser state)
 16x16 tiles with ``tile_id % world == r`` (interleaved for load balance), so the expensive per-(tile, Gaussian) work
 is divided by the world size.  Two collectives per iteration, both RCCL over xGMI when the backend is "nccl":
 
-  forward : ALL-GATHER of each rank's own pixels — a rank packs the pixels of its tiles (4 channels, 13/N MB at 1200x680), one
-            all_gather_into_tensor moves them, and one index_copy unpacks the N chunks into the full image.  Every pixel is produced by
-            exactly one rank, so the image is bit-identical to the single-GPU one; nothing is summed (the first version all-reduced the
-            full zero-padded image: twice the volume plus a reduction).  The loss (SSIM needs an 11x11 window,
-            [REF utils/loss_utils.py:37-69]) is then computed redundantly on the full image on every rank, so the backward needs no
-            image collective at all;
+  forward : ALL-GATHER of each rank's own tiles — `gsicp_tiles_pack` writes the rank's tiles (r, g, b, depth) as one contiguous chunk
+            (13/N MB at 1200x680), one all_gather_into_tensor moves the N chunks, `gsicp_tiles_unpack` writes the full image.  Every
+            pixel is produced by exactly one rank, so the image is bit-identical to the single-GPU one; nothing is summed.  The loss
+            (SSIM needs an 11x11 window, [REF utils/loss_utils.py:37-69]) is then computed redundantly on the full image on every
+            rank, so the backward needs no image collective at all;
   backward: ALL-REDUCE(sum) of the per-Gaussian gradients of the VISIBLE Gaussians only — radii are replicated (every rank
             preprocesses all Gaussians), so every rank compacts the same rows (radii > 0: ~26 % of the map on the benchmark view) in
             index order into one packed block (14 floats x P_vis = 4.4 MB instead of 16.8 MB), all-reduces it and scatters it back;
             culled Gaussians have exactly zero gradient everywhere.  After it every rank applies the same optimiser step.
 
-The result equals the single-GPU rasteriser up to fp32 summation order in the gradient all-reduce (`compact_grads=False` all-reduces
-the dense block instead: same sums, tests compare the two).  `is_used` is not read by the reference [REF mp_Mapper.py:219-222]; it
-stays per-rank unless `sync_is_used=True`.
+Three ways to run the gradient exchange:
+  compact_grads=False             dense block of all rows (same sums; tests compare the others against it);
+  compact_grads=True              rows selected with torch.nonzero — exact volume, one host sync per backward (eager use);
+  vis_capacity=R (CUDA)           `gsicp_rows_pack / _unpack` with a STATIC block of R rows + one flag word: no host sync, every size fixed,
+                                  so the whole iteration — both RCCL calls included — can be captured in a hipGraph
+                                  (MapperIterationGraph(rasterizer_factory=...)).  A rank whose visible rows exceed R, or whose duplicate lists
+                                  overflowed, raises the flag; after the all-reduce every rank sees it in `overflow_guard()` and the
+                                  capturable Adam skips that step on all ranks alike.
+
+The result equals the single-GPU rasteriser up to fp32 summation order in the gradient all-reduce.  `is_used` is not read by the
+reference [REF mp_Mapper.py:219-222]; it stays per-rank unless `sync_is_used=True`.
+
+CPU tensors (the gloo tests, whose per-rank rasteriser is an oracle-backed stand-in) take torch index operations with the same layout
+rules instead of the HIP movers; CUDA tensors always go through libgsicp_hip.so.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
 
 def _own_pixel_table(W, H, world, device):
-    """(world, n_max) int64: flat pixel indices of each rank's tiles (tile t belongs to rank t % world), padded with H*W (a dummy slot)."""
+    """(world, n_max) int64: flat pixel indices of each rank's tiles (tile t belongs to rank t % world), padded with H*W (a dummy slot).
+    CPU path only."""
     gx = (W + 15) // 16
     ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
     owner = (((ys // 16) * gx + (xs // 16)) % world).reshape(-1)
@@ -38,31 +51,117 @@ def _own_pixel_table(W, H, world, device):
     return table.to(device)
 
 
+def _all_gather_flat(gathered, mine, group):
+    try:
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+    except (RuntimeError, AttributeError):                                     # backends without the flat variant
+        parts = [torch.empty_like(mine) for _ in range(gathered.shape[0])]
+        dist.all_gather(parts, mine, group=group)
+        gathered.copy_(torch.stack(parts).view_as(gathered))
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
 class _GatherImage(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, depth, color, group, table, rank):
-        world, n_max = table.shape
+    def forward(ctx, depth, color, group, holder, rank, world):
         H, W = color.shape[-2:]
         HW = H * W
+        if color.is_cuda:
+            from . import _lib
+            lib = _lib.load()
+            dev = color.device
+            color, depth = color.contiguous(), depth.contiguous()
+            n = int(lib.gsicp_tiles_chunk_floats(W, H, world))
+            mine = torch.empty(n, dtype=torch.float32, device=dev)
+            gathered = torch.empty((world, n), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.gsicp_tiles_pack(W, H, world, rank, _p(color), _p(depth), _p(mine), _stream(dev)), "gsicp_tiles_pack")
+                _all_gather_flat(gathered, mine, group)
+                full_c, full_d = torch.empty_like(color), torch.empty_like(depth)
+                _lib.check(lib.gsicp_tiles_unpack(W, H, world, _p(gathered), _p(full_c), _p(full_d), _stream(dev)), "gsicp_tiles_unpack")
+            holder.last_image_bytes = n * 4
+            return full_d, full_c
+        if holder.table is None:
+            holder.table = _own_pixel_table(W, H, world, color.device)
+        table = holder.table
+        n_max = table.shape[1]
         flat = torch.cat([torch.cat([color.reshape(3, HW), depth.reshape(1, HW)], dim=0),
                           torch.zeros((4, 1), dtype=color.dtype, device=color.device)], dim=1)          # (4, HW + 1): the last column is the pad slot
         mine = flat.index_select(1, table[rank]).contiguous()                     # (4, n_max): this rank's pixels
-        gathered = torch.empty((world, 4, n_max), dtype=color.dtype, device=color.device)
-        try:
-            dist.all_gather_into_tensor(gathered, mine, group=group)
-        except (RuntimeError, AttributeError):                                     # backends without the flat variant
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine, group=group)
-            gathered = torch.stack(parts)
+        gathered = torch.empty((world, 4 * n_max), dtype=color.dtype, device=color.device)
+        _all_gather_flat(gathered, mine.reshape(-1), group)
         full = torch.empty((4, HW + 1), dtype=color.dtype, device=color.device)
-        full.index_copy_(1, table.reshape(-1), gathered.permute(1, 0, 2).reshape(4, world * n_max))
+        full.index_copy_(1, table.reshape(-1), gathered.view(world, 4, n_max).permute(1, 0, 2).reshape(4, world * n_max))
+        holder.last_image_bytes = mine.numel() * 4
         return full[3:4, :HW].reshape(1, H, W), full[0:3, :HW].reshape(3, H, W)
 
     @staticmethod
     def backward(ctx, g_depth, g_color):
         # every rank computed the same full-image loss, so the incoming gradient is already the full one;
         # the local rasteriser backward only consumes the pixels of its own tiles.
-        return g_depth, g_color, None, None, None
+        return g_depth, g_color, None, None, None, None
+
+
+def _static_exchange_cuda(grads, radii, holder, group):
+    """gsicp_rows_pack -> all_reduce -> gsicp_rows_unpack, all sizes static.  `grads`: contiguous float32 (P, ...) CUDA tensors, updated in place."""
+    from . import _lib
+    lib = _lib.load()
+    dev = grads[0].device
+    P = grads[0].shape[0]
+    widths = [g[0].numel() for g in grads]
+    R, Wt = int(holder.vis_capacity), sum(widths)
+    key = (P, tuple(widths), R, dev)
+    if holder.static_key != key:
+        holder.static_key = key
+        holder.packed = torch.zeros(R * Wt + 1, dtype=torch.float32, device=dev)
+        holder.scratch = torch.zeros(int(lib.gsicp_rows_pack_scratch_bytes(P)), dtype=torch.uint8, device=dev)
+        if holder.overflow is None:          # may already be bound to the optimiser (overflow_guard)
+            holder.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        holder.c_widths = (ctypes.c_int * len(widths))(*widths)
+    ptrs = (ctypes.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+    guard, limit = holder.guard if holder.guard is not None else (None, 0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsicp_rows_pack(P, _p(radii), len(grads), ptrs, holder.c_widths, _p(holder.packed), R,
+                                       _p(guard) if guard is not None else None, int(limit), _p(holder.scratch), _stream(dev)), "gsicp_rows_pack")
+        dist.all_reduce(holder.packed, op=dist.ReduceOp.SUM, group=group)
+        _lib.check(lib.gsicp_rows_unpack(P, _p(radii), len(grads), ptrs, holder.c_widths, _p(holder.packed), R, _p(holder.scratch),
+                                         _p(holder.overflow), _stream(dev)), "gsicp_rows_unpack")
+    holder.last_volume_bytes = holder.packed.numel() * 4
+
+
+def _static_exchange_torch(grads, radii, holder, group):
+    """The same block layout with torch index operations (CPU tensors of the gloo tests).  Returns new gradient tensors."""
+    P = grads[0].shape[0]
+    widths = [g[0].numel() for g in grads]
+    R, Wt = int(holder.vis_capacity), sum(widths)
+    mask = radii > 0
+    pos = torch.cumsum(mask, 0) - 1
+    n_vis = int(mask.sum())
+    keep = mask & (pos < R)
+    rows = torch.cat([g.reshape(P, -1) for g in grads], dim=1)
+    packed = torch.zeros(R * Wt + 1, dtype=rows.dtype, device=rows.device)
+    packed[: R * Wt].view(R, Wt).index_copy_(0, pos[keep], rows[keep])
+    guard, limit = holder.guard if holder.guard is not None else (None, 0)
+    packed[-1] = 1.0 if (n_vis > R or (guard is not None and int(guard.item()) > limit)) else 0.0
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    if holder.overflow is None:
+        holder.overflow = torch.zeros(1, dtype=torch.int32, device=rows.device)
+    holder.overflow.fill_(1 if float(packed[-1]) > 0 else 0)
+    out_rows = rows.clone()
+    out_rows[keep] = packed[: R * Wt].view(R, Wt).index_select(0, pos[keep])
+    holder.last_volume_bytes = packed.numel() * 4
+    out, off = [], 0
+    for g, w in zip(grads, widths):
+        out.append(out_rows[:, off:off + w].reshape(g.shape).contiguous())
+        off += w
+    return out
 
 
 class _SyncGrads(torch.autograd.Function):
@@ -79,10 +178,20 @@ class _SyncGrads(torch.autograd.Function):
         present = [g for g in grads if g is not None]
         if not present:
             return (None, None, None, *grads)
-        radii = getattr(ctx.holder, "radii", None)
+        holder = ctx.holder
+        radii = getattr(holder, "radii", None)
         P = present[0].shape[0]
-        rowwise = ctx.compact and radii is not None and all(g.dim() >= 1 and g.shape[0] == P for g in present) and radii.shape[0] == P
-        if rowwise:
+        rowwise = radii is not None and all(g.dim() >= 1 and g.shape[0] == P for g in present) and radii.shape[0] == P
+        if rowwise and holder.vis_capacity:
+            if present[0].is_cuda:
+                present = [g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float() for g in present]
+                _static_exchange_cuda(present, radii, holder, ctx.group)
+                summed = present
+            else:
+                summed = _static_exchange_torch(present, radii, holder, ctx.group)
+            it = iter(summed)
+            return (None, None, None, *[None if g is None else next(it) for g in grads])
+        if rowwise and ctx.compact:
             idx = torch.nonzero(radii > 0).squeeze(1)            # identical on every rank; one host sync for the count
             widths = [g[0].numel() for g in present]
             packed = torch.cat([g.reshape(P, -1).index_select(0, idx) for g in present], dim=1).contiguous()   # (P_vis, sum widths)
@@ -97,7 +206,7 @@ class _SyncGrads(torch.autograd.Function):
                 full.index_copy_(0, idx, packed[:, off:off + w])
                 out.append(full.view(g.shape))
                 off += w
-            ctx.holder.last_volume_bytes = packed.numel() * packed.element_size()
+            holder.last_volume_bytes = packed.numel() * packed.element_size()
         else:
             packed = torch.cat([g.reshape(-1) for g in present])
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
@@ -109,20 +218,27 @@ class _SyncGrads(torch.autograd.Function):
                     n = g.numel()
                     out.append(packed[off:off + n].view(g.shape))
                     off += n
-            ctx.holder.last_volume_bytes = packed.numel() * packed.element_size()
+            holder.last_volume_bytes = packed.numel() * packed.element_size()
         return (None, None, None, *out)
 
 
 class _Holder:
     radii = None
     last_volume_bytes = 0
+    last_image_bytes = 0
+    table = None
+    vis_capacity = 0
+    guard = None          # (int32[1] device tensor: this rank's duplicate count, its capacity) or None
+    static_key = None
+    packed = scratch = overflow = c_widths = None
 
 
 class ShardedGaussianRasterizer(nn.Module):
     """Drop-in for GaussianRasterizer when torch.distributed is initialised: same call signature and return tuple.
     ``rasterizer_cls`` is injectable so that the CPU (gloo) tests can exercise the collective logic."""
 
-    def __init__(self, raster_settings, group=None, rasterizer_cls=None, force_collectives=False, compact_grads=True, sync_is_used=False):
+    def __init__(self, raster_settings, group=None, rasterizer_cls=None, force_collectives=False, compact_grads=True, sync_is_used=False,
+                 vis_capacity=0):
         super().__init__()
         if rasterizer_cls is None:
             from .rasterizer import GaussianRasterizer as rasterizer_cls
@@ -133,11 +249,26 @@ class ShardedGaussianRasterizer(nn.Module):
         self.compact_grads, self.sync_is_used = bool(compact_grads), bool(sync_is_used)
         self.raster_settings = raster_settings._replace(tile_mod=world, tile_rem=rank)
         self.inner = rasterizer_cls(raster_settings=self.raster_settings)
-        self._table = None
         self.holder = _Holder()
+        self.holder.vis_capacity = int(vis_capacity or 0)
+
+    @property
+    def collective(self):
+        return self.world > 1 or self.force_collectives
+
+    def overflow_guard(self):
+        """(int32[1] device tensor, limit) for FusedAdam.set_overflow_guard when the static gradient exchange is on: the tensor is 1 after
+        a backward in which ANY rank overflowed (duplicate lists or visible rows), so every rank skips the same optimiser step.  None
+        otherwise (the caller then guards on this rank's own duplicate count)."""
+        if not (self.collective and self.holder.vis_capacity):
+            return None
+        if self.holder.overflow is None:
+            dev = self.raster_settings.viewmatrix.device
+            self.holder.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        return self.holder.overflow, 0
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
-        if self.world == 1 and not self.force_collectives:
+        if not self.collective:
             return self.inner(means3D=means3D, means2D=means2D, opacities=opacities, shs=shs, colors_precomp=colors_precomp,
                               scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
         names = ["means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"]
@@ -151,10 +282,10 @@ class ShardedGaussianRasterizer(nn.Module):
             kw[names[i]] = t
         depth, color, radii, is_used = self.inner(**kw)
         holder.radii = radii          # replicated: every rank preprocesses all Gaussians
-        rs = self.raster_settings
-        if self._table is None or self._table.device != color.device:
-            self._table = _own_pixel_table(int(rs.image_width), int(rs.image_height), self.world, color.device)
-        depth, color = _GatherImage.apply(depth, color, self.group, self._table, self.rank)
+        cap = int(getattr(self.raster_settings, "capacity", 0) or 0)
+        count = getattr(self.inner, "num_rendered", None)
+        holder.guard = (count, cap) if (cap > 0 and count is not None) else None
+        depth, color = _GatherImage.apply(depth, color, self.group, holder, self.rank, self.world)
         if self.sync_is_used:
             is_used = is_used.clone()
             dist.all_reduce(is_used, op=dist.ReduceOp.MAX, group=self.group)

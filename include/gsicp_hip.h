@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GSICP_ABI_VERSION 2
+#define GSICP_ABI_VERSION 3
 
 int gsicp_abi_version(void);
 const char* gsicp_last_error(void);
@@ -304,6 +304,32 @@ int gsicp_adam_step_guarded(int n_groups, float* const* params, const float* con
 size_t gsicp_store_compact_scratch_bytes(int n);
 int gsicp_store_compact(int n, const unsigned char* keep, int n_arrays, const void* const* src, void* const* dst, const int* row_bytes,
                         void* scratch, int* n_out_dev, void* stream);
+
+/* --------------------------------------------------------------------------------------------------------
+ * 4b. Multi-GPU mapper (not in the reference, which is single-GPU).  Rank r rasterises the tiles t with
+ *     t % tile_mod == r (section 2's tile_mod / tile_rem); these four calls move what the two collectives carry, with static
+ *     sizes so that the whole iteration — RCCL calls included — can be captured in a hipGraph.  All pointers are DEVICE pointers.
+ *
+ *  image all-gather: gsicp_tiles_pack writes this rank's tiles as one chunk of gsicp_tiles_chunk_floats() floats, laid out
+ *     [k = t / tile_mod][r, g, b, depth][256 pixels of the tile]; after an all-gather of the tile_mod chunks (rank order),
+ *     gsicp_tiles_unpack writes every tile of the (3,H,W) colour and (1,H,W) depth images from the chunk of its owner.
+ *  gradient all-reduce: radii (int[P], identical on every rank because every rank preprocesses all Gaussians) selects the rows
+ *     with radii > 0; gsicp_rows_pack copies those rows of n_arrays (<= 8) row-major (P, row_width[a]) float arrays, in ascending
+ *     Gaussian order, into packed[row_capacity][sum of widths] and sets the flag word packed[row_capacity * sum] to 1.0 when this
+ *     rank overflowed (more visible rows than row_capacity, or *guard_count > guard_limit — the rasteriser's duplicate count and
+ *     capacity), else 0.0.  All-reduce (sum) the row_capacity * sum + 1 floats; gsicp_rows_unpack writes the summed rows back in
+ *     place (rows with radii <= 0 are left alone: their gradient is exactly zero on every rank) and *overflow_out = 1 when ANY rank
+ *     flagged an overflow (pass it to gsicp_adam_step_guarded with guard_limit 0 so every rank skips the same step), else 0.
+ *     `scratch` (gsicp_rows_pack_scratch_bytes(P)) carries the scan of pack to unpack.  src / dst / row_width are HOST arrays.
+ * ------------------------------------------------------------------------------------------------------ */
+size_t gsicp_tiles_chunk_floats(int width, int height, int tile_mod);
+int gsicp_tiles_pack(int width, int height, int tile_mod, int tile_rem, const float* color, const float* depth, float* chunk, void* stream);
+int gsicp_tiles_unpack(int width, int height, int tile_mod, const float* gathered, float* color, float* depth, void* stream);
+size_t gsicp_rows_pack_scratch_bytes(int P);
+int gsicp_rows_pack(int P, const int* radii, int n_arrays, const float* const* src, const int* row_width, float* packed, int row_capacity,
+                    const unsigned int* guard_count, unsigned int guard_limit, void* scratch, void* stream);
+int gsicp_rows_unpack(int P, const int* radii, int n_arrays, float* const* dst, const int* row_width, const float* packed, int row_capacity,
+                      const void* scratch, unsigned int* overflow_out, void* stream);
 
 /* --------------------------------------------------------------------------------------------------------
  * 5. Tracker front-end — Tracker.downsample_and_make_pointcloud2 [REF mp_Tracker.py:415-431] in one

@@ -72,6 +72,16 @@ def _run(rasterizer, g, target):
     return color.detach(), depth.detach(), {k: v.grad.clone() for k, v in t.items()}, used
 
 
+def _run_flagged(rasterizer, g, target, trip):
+    """One forward / backward in which this rank's duplicate-count guard is tripped (trip=True) or not."""
+    t = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in g.items()}
+    m2d = torch.zeros_like(t["means3D"], requires_grad=True)
+    depth, color, radii, used = rasterizer(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
+                                           rotations=t["rotations"])
+    rasterizer.holder.guard = (torch.tensor([11 if trip else 9], dtype=torch.int32), 10)     # count 11 > capacity 10 on the tripping rank
+    ((color - target[:3]).abs().mean() + 0.1 * (depth - target[3:]).abs().mean()).backward()
+
+
 def _scene():
     g = synth.random_gaussians(120, seed=4)
     g["means3D"][:30, 2] = -2.0        # a quarter of the map is behind the camera: culled rows must not travel in the gradient all-reduce
@@ -94,6 +104,20 @@ def _worker(rank, world, port, q):
     for k in grads:   # the compacted all-reduce (visible rows only) must equal the dense one bit for bit
         assert torch.equal(grads[k], grads_d[k]), k
     assert vol_compact < dense.holder.last_volume_bytes
+    # static block (what a captured hipGraph replays): same sums, fixed volume, and an overflow on ONE rank is seen by both
+    n_vis = int((sh.holder.radii > 0).sum())
+    static = ShardedGaussianRasterizer(_settings(cam), rasterizer_cls=_OracleRasterizer, vis_capacity=n_vis + 5)
+    color_s, depth_s, grads_s, _ = _run(static, g, target)
+    assert torch.equal(color, color_s) and torch.equal(depth, depth_s)
+    for k in grads:
+        assert torch.equal(grads_s[k], grads_d[k]), k
+    assert static.holder.last_volume_bytes == ((n_vis + 5) * 17 + 1) * 4 and int(static.holder.overflow.item()) == 0
+    flagged = ShardedGaussianRasterizer(_settings(cam), rasterizer_cls=_OracleRasterizer, vis_capacity=n_vis + 5)
+    _run_flagged(flagged, g, target, trip=(rank == 1))      # only rank 1's duplicate lists "overflow"
+    assert int(flagged.holder.overflow.item()) == 1, "an overflow on rank 1 must reach rank 0 through the flag word"
+    short = ShardedGaussianRasterizer(_settings(cam), rasterizer_cls=_OracleRasterizer, vis_capacity=n_vis - 1)
+    _run(short, g, target)                                   # fewer rows than visible Gaussians: flagged on both
+    assert int(short.holder.overflow.item()) == 1
     q.put((rank, color.numpy(), depth.numpy(), {k: v.numpy() for k, v in grads.items()}, used.numpy(), used_d.numpy(),
            vol_compact, dense.holder.last_volume_bytes))
     dist.barrier()

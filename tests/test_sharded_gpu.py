@@ -1,0 +1,173 @@
+"""GPU tests of the multi-GPU mapper path on ONE GPU (gpurun exposes a single device): the HIP movers that feed the two collectives are
+checked with several ranks emulated side by side (an all-gather is a concatenation, an all-reduce a sum), and the captured iteration with
+RCCL calls inside runs on backend "nccl" with world size 1, where it must equal the plain single-GPU graph bit for bit.
+The 2-process collective logic itself is covered on CPU by tests/test_sharded_cpu.py (gloo)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gs_icp_slam_amd import synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("W,H,mod", [(176, 100, 3), (320, 200, 8), (64, 48, 1)])
+def test_tile_movers_compose_the_image_of_emulated_ranks(hip_lib, W, H, mod):
+    """Each emulated rank renders its tiles (tile % mod == rank) and packs them; the concatenation of the chunks (what all_gather_into_tensor
+    delivers) unpacks to exactly the single-GPU image, partial edge tiles included."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gs_icp_slam_amd import _lib
+    lib = _lib.load()
+    cam = synth.make_camera(W, H, 140.0, 140.0)
+    g = synth.random_gaussians(700, seed=8)
+    t = util.torch_inputs(g)
+
+    def render(rs):
+        with torch.no_grad():
+            d, c, _, _ = GaussianRasterizer(rs)(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), shs=t["shs"], opacities=t["opacities"],
+                                                scales=t["scales"], rotations=t["rotations"])
+        return d.contiguous(), c.contiguous()
+    d_full, c_full = render(util.make_settings(cam, [0.1, 0.2, 0.3]))
+    n = int(lib.gsicp_tiles_chunk_floats(W, H, mod))
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    assert n == ((T + mod - 1) // mod) * 1024
+    gathered = torch.full((mod, n), float("nan"), device="cuda")
+    for r in range(mod):
+        d, c = render(util.make_settings(cam, [0.1, 0.2, 0.3], tile_mod=mod, tile_rem=r))
+        _lib.check(lib.gsicp_tiles_pack(W, H, mod, r, _p(c), _p(d), _p(gathered[r]), _stream()), "pack")
+    c_out = torch.full_like(c_full, float("nan"))
+    d_out = torch.full_like(d_full, float("nan"))
+    _lib.check(lib.gsicp_tiles_unpack(W, H, mod, _p(gathered), _p(c_out), _p(d_out), _stream()), "unpack")
+    torch.cuda.synchronize()
+    assert torch.equal(c_out, c_full) and torch.equal(d_out, d_full)
+    assert lib.gsicp_tiles_pack(W, H, mod, mod, _p(c_full), _p(d_full), _p(gathered), _stream()) != 0      # tile_rem out of range
+
+
+def test_row_movers_sum_the_visible_rows_of_emulated_ranks_and_flag_overflow(hip_lib):
+    from gs_icp_slam_amd import _lib
+    lib = _lib.load()
+    P, widths, ranks = 5003, [3, 3, 1, 3, 4, 3], 3
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    radii = (torch.rand(P, device="cuda", generator=gen) < 0.3).to(torch.int32) * 7
+    radii[0], radii[-1] = 5, 9
+    n_vis, Wt = int((radii > 0).sum()), sum(widths)
+    arrays = [[torch.randn((P, w), device="cuda", generator=gen) for w in widths] for _ in range(ranks)]
+    expect = [sum(arrays[r][a] for r in range(ranks)) for a in range(len(widths))]
+    untouched = [arrays[0][a].clone() for a in range(len(widths))]
+    cw = (ctypes.c_int * len(widths))(*widths)
+    scratch = torch.zeros(int(lib.gsicp_rows_pack_scratch_bytes(P)), dtype=torch.uint8, device="cuda")
+    count = torch.tensor([100], dtype=torch.int32, device="cuda")
+    overflow = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+
+    def exchange(R, guard_limit):
+        packed = []
+        for r in range(ranks):
+            pk = torch.full((R * Wt + 1,), float("nan"), device="cuda")
+            ptrs = (ctypes.c_void_p * len(widths))(*[x.data_ptr() for x in arrays[r]])
+            _lib.check(lib.gsicp_rows_pack(P, _p(radii), len(widths), ptrs, cw, _p(pk), R, _p(count), guard_limit, _p(scratch), _stream()), "pack")
+            packed.append(pk)
+        return torch.nan_to_num(torch.stack(packed), nan=0.0).sum(0)     # rows behind n_vis are never written: the sum ignores them
+
+    R = n_vis + 11
+    total = exchange(R, 100)
+    assert float(total[-1]) == 0.0
+    # packed rows are the visible rows in ascending Gaussian order
+    vis = torch.nonzero(radii > 0).squeeze(1)
+    ref_rows = torch.cat([e.index_select(0, vis) for e in expect], dim=1)
+    torch.testing.assert_close(total[: n_vis * Wt].view(n_vis, Wt), ref_rows, rtol=0, atol=1e-6)
+    ptrs0 = (ctypes.c_void_p * len(widths))(*[x.data_ptr() for x in arrays[0]])
+    _lib.check(lib.gsicp_rows_unpack(P, _p(radii), len(widths), ptrs0, cw, _p(total), R, _p(scratch), _p(overflow), _stream()), "unpack")
+    torch.cuda.synchronize()
+    assert int(overflow.item()) == 0
+    m = (radii > 0)[:, None]
+    for a in range(len(widths)):
+        torch.testing.assert_close(arrays[0][a], torch.where(m, expect[a], untouched[a]), rtol=0, atol=1e-6)
+    # flags: too few rows, or the duplicate-count guard tripped on a rank -> every rank learns it from the summed flag word
+    for R2, limit in ((n_vis - 1, 100), (n_vis + 11, 99)):
+        total = exchange(R2, limit)
+        assert float(total[-1]) == float(ranks)
+        _lib.check(lib.gsicp_rows_unpack(P, _p(radii), len(widths), ptrs0, cw, _p(total), R2, _p(scratch), _p(overflow), _stream()), "unpack")
+        assert int(overflow.item()) == 1
+    assert lib.gsicp_rows_pack(P, _p(radii), 9, ptrs0, cw, _p(total), R, None, 0, _p(scratch), _stream()) != 0      # more than 8 arrays
+
+
+def test_captured_sharded_iteration_with_rccl_inside_equals_the_plain_graph(hip_lib):
+    """MapperIterationGraph over ShardedGaussianRasterizer(vis_capacity=...): tile pack -> all_gather -> unpack and row pack -> all_reduce ->
+    unpack are captured with the rest of the iteration (backend nccl = RCCL, world size 1, collectives forced).  Same parameters after the
+    same schedule as the single-GPU graph; a row capacity that is too small skips every optimiser step instead of applying partial sums."""
+    import torch.distributed as dist
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gs_icp_slam_amd.graph import MapperIterationGraph
+    from gs_icp_slam_amd.sharded import ShardedGaussianRasterizer
+    from tests.test_graph_gpu import _mapper_setup
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29583"
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        P, W, H = 20000, 320, 200
+        g, cam, params_a, opt_a = _mapper_setup(P, W, H, capturable=True)
+        _, _, params_b, opt_b = _mapper_setup(P, W, H, capturable=True)
+        _, _, params_c, opt_c = _mapper_setup(P, W, H, capturable=True)
+        views = []
+        for pose in (synth.DEFAULT_POSE_A, synth.se3((12.5, 27.0, 0.5), (-0.88, -0.22, -1.08))):
+            cam_k = synth.make_camera(W, H, cam["fx"], cam["fy"], pose)
+            rs_k = util.make_settings(cam_k, [0.0, 0.0, 0.0])
+            t2 = util.torch_inputs(synth.s_map(P, seed=5, perturb_seed=7))
+            with torch.no_grad():
+                d, c, r, _ = GaussianRasterizer(rs_k)(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"],
+                                                      opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
+            views.append((rs_k, c.clone(), d.clone(), int((r > 0).sum())))
+        n_vis = max(v[3] for v in views)
+        holders = []
+
+        def factory(R):
+            def make(rs):
+                sh = ShardedGaussianRasterizer(rs, force_collectives=True, vis_capacity=R)
+                holders.append(sh)
+                return sh
+            return make
+        kw = dict(sh_degree=0, capacity=2_000_000, warmup=2)
+        mg_a = MapperIterationGraph(params_a, opt_a, H, W, cam["tanfovx"], cam["tanfovy"], **kw)
+        mg_b = MapperIterationGraph(params_b, opt_b, H, W, cam["tanfovx"], cam["tanfovy"], rasterizer_factory=factory(int(1.5 * n_vis)), **kw)
+        mg_c = MapperIterationGraph(params_c, opt_c, H, W, cam["tanfovx"], cam["tanfovy"], rasterizer_factory=factory(n_vis // 2), **kw)
+        start = {k: v.detach().clone() for k, v in params_c.items()}
+        schedule = [0, 1, 0, 1, 1, 0]
+        losses = {id(mg_a): [], id(mg_b): [], id(mg_c): []}
+        for mg in (mg_a, mg_b, mg_c):
+            rs0, c0, d0, _ = views[0]
+            mg.set_view(rs0.viewmatrix, rs0.projmatrix, rs0.campos, c0, d0)
+            mg.capture()
+            for k in schedule:
+                rs_k, gt_c, gt_d, _ = views[k]
+                mg.set_view(rs_k.viewmatrix, rs_k.projmatrix, rs_k.campos, gt_c, gt_d)
+                losses[id(mg)].append(float(mg.step()))
+        torch.cuda.synchronize()
+        assert losses[id(mg_a)] == losses[id(mg_b)]
+        for k in params_a:
+            assert torch.equal(params_a[k], params_b[k]), k
+        assert torch.equal(mg_a.screenspace_grad, mg_b.screenspace_grad)
+        assert not mg_b.overflowed() and mg_b.skipped_steps() == 0
+        assert int(opt_b.state[params_b["means3D"]]["step"].item()) == len(schedule)
+        sh_b = holders[0]
+        assert sh_b.holder.last_volume_bytes == (int(1.5 * n_vis) * 17 + 1) * 4        # xyz 3 + means2D 3 + opacity 1 + sh 3 + scale 3 + quat 4
+        assert sh_b.holder.last_image_bytes == ((W + 15) // 16) * ((H + 15) // 16) * 1024 * 4
+        # too few rows: the all-reduced flag makes Adam skip every step; nothing moved, nothing counted
+        assert mg_c.overflowed() and mg_c.skipped_steps() == len(schedule)
+        assert int(opt_c.state[params_c["means3D"]]["step"].item()) == 0
+        for k in params_c:
+            assert torch.equal(params_c[k], start[k]), k
+    finally:
+        dist.destroy_process_group()
