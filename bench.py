@@ -98,7 +98,7 @@ def main():
     # child process with its own rendezvous and a timeout BEFORE this process joins its group (a capture that hangs must not take the
     # benchmark with it); GSICP_BENCH_RCCL_GRAPH=0 / 1 skips the probe and forces eager / graph.
     rccl_graph_probe = None
-    if world > 1 and not args.no_graph and os.environ.get("GSICP_BENCH_BACKEND", "nccl") == "nccl":
+    if (world > 1 or os.environ.get("GSICP_BENCH_FORCE_COLLECTIVES") == "1") and not args.no_graph and os.environ.get("GSICP_BENCH_BACKEND", "nccl") == "nccl":
         forced = os.environ.get("GSICP_BENCH_RCCL_GRAPH")
         if forced is not None:
             rccl_graph_probe = {"ok": forced == "1", "how": f"GSICP_BENCH_RCCL_GRAPH={forced}"}
@@ -151,6 +151,8 @@ def main():
            "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-4, 1 - 1e-4)), "shs": torch.from_numpy(g["shs"])}
     params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in raw.items()}
     use_graph = not args.no_graph
+    if force_coll and not (rccl_graph_probe or {}).get("ok"):
+        raise RuntimeError(f"GSICP_BENCH_FORCE_COLLECTIVES: RCCL graph-capture probe failed: {rccl_graph_probe}")
     if world > 1:
         ok = torch.tensor([1.0 if (rccl_graph_probe or {}).get("ok") else 0.0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank must have seen the probe succeed
