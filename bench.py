@@ -612,7 +612,8 @@ def main():
                        "variants": {"depth_mode": "sum z alpha T (un-normalised)", "fromqs_scale_mode": "s^2", "regularization": "PLANE"},
                        "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-gather of own tiles + all-reduce of visible gradient rows), tracker replicated",
                        "world_size": world, "backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen},
-            "render_bwd_ms_per_iter": round(sum(v for k, v in per_launch_us.items() if not k.startswith("gicp")) / 1e3, 4),
+            "render_bwd_ms_per_iter": round(sum(v for k, v in per_launch_us.items() if not k.startswith(("gicp", "loss_", "adam"))) / 1e3, 4),
+            "loss_adam_ms_per_iter": round(sum(v for k, v in per_launch_us.items() if k.startswith(("loss_", "adam"))) / 1e3, 4),
             "tracker_align_kernel_us": stage_us.get("gicp_align"),
             "stage_us_per_step": stage_us,
             "legs": legs, "roofline": roofline, "cpu_baseline": cpu,

@@ -44,14 +44,17 @@ __device__ inline void lds_load16(const float* __restrict__ row, float v[16]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const float4 t = p[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
 }
-// four adjacent outputs of the 11-tap filter from 14 inputs held in registers (same tap order as a scalar loop: k = 0..10)
+// four adjacent outputs of the 11-tap filter from 14 inputs held in registers (same tap order as a scalar loop: k = 0..10).
+// Explicit fused multiply-adds: the library is built with -ffp-contract=off (the rasteriser's index / count parity needs the oracle's exact
+// mul-then-add rounding), which here would spend two instructions per tap; the loss is compared with the reference to 1e-5, and one rounding
+// per tap is closer to the float64 value than two.
 __device__ inline float4 conv4(const float v[16], const Win& win) {
     float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
         const float w = win.w[k];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += w * v[j + k];
+        for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(w, v[j + k], o[j]);
     }
     return make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -153,12 +156,14 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
                 const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
                 const float a = 2.f * mu12 + C1, b = 2.f * (e12 - mu12) + C2;
                 const float c = mu1_sq + mu2_sq + C1, d = (e11 - mu1_sq) + (e22 - mu2_sq) + C2;
-                const float inv_cd = 1.f / (c * d);
+                // v_rcp_f32 (1 ulp) instead of IEEE divisions (~10 instructions each): c, d >= C1, C2 > 0, far from the denormal range
+                const float inv_d = __builtin_amdgcn_rcpf(d);
+                const float inv_cd = __builtin_amdgcn_rcpf(c) * inv_d;
                 const float S = a * b * inv_cd;
                 ssum += S;
                 // dS/d(mu1), dS/d(E[xx]), dS/d(E[xy]) with mu2, E[yy] fixed (the target image carries no gradient)
                 const float dS_dmu1 = 2.f * mu2 * (b - a) * inv_cd - 2.f * mu1 * S * (d - c) * inv_cd;
-                const float dS_de11 = -S / d;
+                const float dS_de11 = -S * inv_d;
                 const float dS_de12 = 2.f * a * inv_cd;
                 const size_t pix = (size_t)py * W + px;
                 abc[(ch * 3 + 0) * HW + pix] = dS_scale * dS_dmu1;
@@ -626,13 +631,16 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
     float* abc = (float*)scratch;
     float* partial = (float*)(scratch + align_up(9 * HW * sizeof(float)));
     const float n_img = 3.f * (float)HW;
-    hipLaunchKernelGGL(loss_pass1_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
-                       -lambda_dssim / n_img, abc, partial);
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, stream, (const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim,
-                       depth_weight, loss_out);
-    if (dL_dimage && dL_ddepth)
+    { ProfileScope ps(ST_LOSS_PASS1, stream);
+      hipLaunchKernelGGL(loss_pass1_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
+                         -lambda_dssim / n_img, abc, partial);
+      hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, stream, (const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim,
+                         depth_weight, loss_out); }
+    if (dL_dimage && dL_ddepth) {
+        ProfileScope ps(ST_LOSS_PASS2, stream);
         hipLaunchKernelGGL(loss_pass2_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                            (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth);
+    }
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss: kernel launch failed"; return -1; }
     return 0;
 }
@@ -836,11 +844,14 @@ int gsicp_adam_step_guarded(int n_groups, float* const* params, const float* con
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, nullptr, 1.0);
     if (live_rows_dev && row_width)
         for (int k = 0; k < t.n; ++k) t.row_width[k] = row_width[t.src[k]];
-    if (total > 0)
-        hipLaunchKernelGGL(adam_tensor_kernel<true>, adam_grid(t), dim3(256), 0, stream, t, lr_dev, (const int*)step_dev, beta1, beta2, eps, 0.f,
-                           guard_count, guard_limit, (live_rows_dev && row_width) ? live_rows_dev : (const int*)nullptr);
-    if (bump_step)
-        hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, stream, step_dev, guard_count, guard_limit, skipped_dev);
+    {
+        ProfileScope ps(ST_ADAM, stream);
+        if (total > 0)
+            hipLaunchKernelGGL(adam_tensor_kernel<true>, adam_grid(t), dim3(256), 0, stream, t, lr_dev, (const int*)step_dev, beta1, beta2, eps, 0.f,
+                               guard_count, guard_limit, (live_rows_dev && row_width) ? live_rows_dev : (const int*)nullptr);
+        if (bump_step)
+            hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, stream, step_dev, guard_count, guard_limit, skipped_dev);
+    }
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step_capturable: kernel launch failed"; return -1; }
     return 0;
 }

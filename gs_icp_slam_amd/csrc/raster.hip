@@ -50,10 +50,11 @@ std::atomic<int> g_prof_enabled{0};
 // stage -> kernel: preprocess = preprocess_kernel; tile_scan_lpt = tile_scan_lpt_kernel; emit = emit_kernel; split_hist / split_colscan /
 // split_scatter = the three multi-split kernels; tile_sort_long / tile_sort = tile_sort_kernel's two size classes (> 512 entries / the rest);
 // blend_forward = blend_forward_strip_kernel; blend_backward = blend_backward_tile_kernel; preprocess_backward = preprocess_backward_kernel;
-// gicp_* = the tracker's call-level stages (several launches each)
+// gicp_* = the tracker's call-level stages (several launches each); loss_pass1 / loss_pass2 = the two loss kernels (pass 1 includes the
+// one-workgroup reduce); adam = adam_tensor_kernel (+ the one-thread step bump)
 const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "emit", "split_hist", "split_colscan", "split_scatter", "tile_sort_long",
                                              "tile_sort", "blend_forward", "blend_backward", "preprocess_backward", "gicp_knn_cov",
-                                             "gicp_grid_build", "gicp_align", "gicp_exact_nn"};
+                                             "gicp_grid_build", "gicp_align", "gicp_exact_nn", "loss_pass1", "loss_pass2", "adam"};
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -530,7 +531,8 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
             const bool contrib = valid && !stop;
             if (__ballot(contrib) == 0ull) return;
             const float w = contrib ? alpha * T : 0.f;
-            C0 += r.r * w; C1 += r.g * w; C2 += r.b * w; Dz += r.depth * w;
+            // explicit FMAs (the build has -ffp-contract=off for the index / count parity of power, alpha and T; the accumulators are compared to 1e-5)
+            C0 = __builtin_fmaf(r.r, w, C0); C1 = __builtin_fmaf(r.g, w, C1); C2 = __builtin_fmaf(r.b, w, C2); Dz = __builtin_fmaf(r.depth, w, Dz);
             T = contrib ? test_T : T;
             last_contributor = contrib ? pos_v : last_contributor;
             used |= 1ull << j;
@@ -699,10 +701,13 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
                 const float inv_one_m = __builtin_amdgcn_rcpf(1.f - av);   // alpha <= 0.99: one v_rcp_f32 (1 ulp); rcp(1) = 1 exactly
                 T = T * inv_one_m;
                 const float w = av * T;
-                float dL_dalpha = ((r.r - A0) * dp0 + (r.g - A1) * dp1 + (r.b - A2) * dp2 + (r.depth - Ad) * dpd) * T + bgT * inv_one_m;
+                // explicit FMAs from here on (gradient algebra only: power, alpha, T and `valid` above keep the forward's exact mul / add rounding)
+                const float dot = __builtin_fmaf(r.depth - Ad, dpd, __builtin_fmaf(r.b - A2, dp2, __builtin_fmaf(r.g - A1, dp1, (r.r - A0) * dp0)));
+                float dL_dalpha = __builtin_fmaf(dot, T, bgT * inv_one_m);
                 dL_dalpha = valid ? dL_dalpha : 0.f;
                 const float one_m = 1.f - av;
-                A0 = av * r.r + one_m * A0; A1 = av * r.g + one_m * A1; A2 = av * r.b + one_m * A2; Ad = av * r.depth + one_m * Ad;
+                A0 = __builtin_fmaf(av, r.r, one_m * A0); A1 = __builtin_fmaf(av, r.g, one_m * A1); A2 = __builtin_fmaf(av, r.b, one_m * A2);
+                Ad = __builtin_fmaf(av, r.depth, one_m * Ad);
                 // Everything that is constant per entry (conic, opacity, the pixel->NDC factors) is applied ONCE per Gaussian by
                 // preprocess_backward; the lanes only form h = G dL/dalpha and its first and second moments in (dx, dy):
                 //   dL/dopacity = S[h];  dL/dconic = -op (S[h dx dx] / 2, S[h dx dy], S[h dy dy] / 2);

@@ -115,7 +115,7 @@ struct PreprocessBwdArgs {
 // ---- per-stage hipEvent profiler (implemented in raster.hip, shared with gicp.hip)
 // one stage per KERNEL on the rasteriser side (a bracket over several launches would also time the host gaps between them)
 enum Stage { ST_PREPROCESS = 0, ST_RANGES, ST_EMIT, ST_SPLIT_HIST, ST_SPLIT_COLSCAN, ST_SPLIT_SCATTER, ST_TILE_SORT_LONG, ST_TILE_SORT, ST_BLEND_FWD,
-             ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_GICP_COV, ST_GICP_GRID, ST_GICP_ALIGN, ST_GICP_MISS, ST_COUNT };
+             ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_GICP_COV, ST_GICP_GRID, ST_GICP_ALIGN, ST_GICP_MISS, ST_LOSS_PASS1, ST_LOSS_PASS2, ST_ADAM, ST_COUNT };
 bool profile_on();
 void profile_begin(int stage, hipStream_t s);
 void profile_end(int stage, hipStream_t s);

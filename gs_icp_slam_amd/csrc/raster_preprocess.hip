@@ -269,6 +269,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// The two backward functions below contract a * b + c into FMAs (the library is built with -ffp-contract=off because radii, tile counts and depth
+// keys of the FORWARD must round like the oracle; gradients are compared to 1e-5 / 1e-4 and lose nothing).  The forward helpers they inline
+// (quat_to_R, cov3_from_scale_rot, ewa_M, cov2_from_M) keep their own setting.
+#pragma clang fp contract(fast)
+
 __device__ inline void sh_backward(int deg, int M, const float* mean, const float* campos, const float* sh, unsigned cm,
                                    const float* dcol, float* dL_dsh, float* dm) {
     float dRGB[3];
@@ -533,6 +538,8 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
         for (int k = 0; k < 4; ++k) a.dL_drots[4 * i + k] = drot[k];
     }
 }
+
+#pragma clang fp contract(off)
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* means3D, const float* view, unsigned char* present) {
     const int i = blockIdx.x * 256 + threadIdx.x;
