@@ -45,9 +45,7 @@ __device__ inline void lds_load16(const float* __restrict__ row, float v[16]) {
     for (int i = 0; i < 4; ++i) { const float4 t = p[i]; v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
 }
 // four adjacent outputs of the 11-tap filter from 14 inputs held in registers (same tap order as a scalar loop: k = 0..10).
-// Explicit fused multiply-adds: the library is built with -ffp-contract=off (the rasteriser's index / count parity needs the oracle's exact
-// mul-then-add rounding), which here would spend two instructions per tap; the loss is compared with the reference to 1e-5, and one rounding
-// per tap is closer to the float64 value than two.
+// Fused multiply-adds written out (one rounding per tap; the compiler's default contraction forms them here as well).
 __device__ inline float4 conv4(const float v[16], const Win& win) {
     float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

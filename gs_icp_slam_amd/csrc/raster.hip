@@ -531,7 +531,7 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
             const bool contrib = valid && !stop;
             if (__ballot(contrib) == 0ull) return;
             const float w = contrib ? alpha * T : 0.f;
-            // explicit FMAs (the build has -ffp-contract=off for the index / count parity of power, alpha and T; the accumulators are compared to 1e-5)
+            // (FMAs: this file is built with the compiler's default contraction; written out so that the accumulation order is explicit)
             C0 = __builtin_fmaf(r.r, w, C0); C1 = __builtin_fmaf(r.g, w, C1); C2 = __builtin_fmaf(r.b, w, C2); Dz = __builtin_fmaf(r.depth, w, Dz);
             T = contrib ? test_T : T;
             last_contributor = contrib ? pos_v : last_contributor;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
                 const float inv_one_m = __builtin_amdgcn_rcpf(1.f - av);   // alpha <= 0.99: one v_rcp_f32 (1 ulp); rcp(1) = 1 exactly
                 T = T * inv_one_m;
                 const float w = av * T;
-                // explicit FMAs from here on (gradient algebra only: power, alpha, T and `valid` above keep the forward's exact mul / add rounding)
+                // gradient algebra with the FMAs written out (this file is built with the compiler's default contraction anyway)
                 const float dot = __builtin_fmaf(r.depth - Ad, dpd, __builtin_fmaf(r.b - A2, dp2, __builtin_fmaf(r.g - A1, dp1, (r.r - A0) * dp0)));
                 float dL_dalpha = __builtin_fmaf(dot, T, bgT * inv_one_m);
                 dL_dalpha = valid ? dL_dalpha : 0.f;
