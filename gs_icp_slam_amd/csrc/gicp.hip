@@ -516,9 +516,58 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
 }
 
 struct TopK { float my_d; int my_i; float tau_d; int tau_i; };
-// Offer one candidate per lane (d = FLT_MAX / id = INT_MAX for idle lanes) to the cross-lane sorted list.
+// (d, id) pairs are totally ordered (ids are unique; idle lanes carry (FLT_MAX, INT_MAX), the largest pair)
+__device__ inline void lex_cswap(float& d, int& i, const float od, const int oi, const bool keep_min) {
+    const bool other_less = lex_less(od, oi, d, i);
+    if (other_less == keep_min) { d = od; i = oi; }
+}
+// ascending bitonic sort of one pair per lane across the wave: 21 compare-exchange steps, no scalar round trips
+__device__ inline void wave_sort_pairs(float& d, int& i, const int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float od = __shfl_xor(d, j, 64);
+            const int oi = __shfl_xor(i, j, 64);
+            const bool up = (lane & k) == 0 || k == 64;            // direction of this lane's block
+            lex_cswap(d, i, od, oi, ((lane & j) == 0) == up);
+        }
+    }
+}
+// the list (ascending over the lanes) and 64 candidates -> the 64 smallest of both, ascending: sort the candidates, take the lane-wise
+// minimum against the reversed list (a bitonic sequence holding exactly the 64 smallest), finish with the six merge steps
+__device__ inline void topk_merge64(TopK& t, float d, int id, const int kk, const int lane) {
+    wave_sort_pairs(d, id, lane);
+    const float rd = __shfl(d, 63 - lane, 64);
+    const int ri = __shfl(id, 63 - lane, 64);
+    if (lex_less(rd, ri, t.my_d, t.my_i)) { t.my_d = rd; t.my_i = ri; }
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const float od = __shfl_xor(t.my_d, j, 64);
+        const int oi = __shfl_xor(t.my_i, j, 64);
+        lex_cswap(t.my_d, t.my_i, od, oi, (lane & j) == 0);
+    }
+    t.tau_d = readlane_f(t.my_d, kk - 1);
+    t.tau_i = __builtin_amdgcn_readlane(t.my_i, kk - 1);
+}
+// Offer one candidate per lane (d = FLT_MAX / id = INT_MAX for idle lanes) to the cross-lane sorted list (ascending over the lanes; lanes
+// >= kk hold the next larger pairs or the idle pair and are never read).  Few candidates below the current k-th pair are inserted one by one
+// (a scalar round trip each, ~25 instructions); many — the first batches of a query, while the list is still filling — go through the
+// sorting network instead (~270 instructions whatever their number).
+constexpr int TOPK_SORT_FROM = 10;
 __device__ inline void topk_offer(TopK& t, float d, int id, int kk, unsigned long long kmask, int lane) {
+    if (kk == 1) {      // nearest neighbour only (the exact-distance export): a lexicographic wave minimum, no list to maintain
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(d, off, 64);
+            const int oi = __shfl_xor(id, off, 64);
+            if (lex_less(od, oi, d, id)) { d = od; id = oi; }
+        }
+        if (lex_less(d, id, t.tau_d, t.tau_i)) { t.tau_d = d; t.tau_i = id; t.my_d = d; t.my_i = id; }   // every lane holds the same pair
+        return;
+    }
     unsigned long long m = __ballot(lex_less(d, id, t.tau_d, t.tau_i));
+    if (__popcll(m) >= TOPK_SORT_FROM) { topk_merge64(t, d, id, kk, lane); return; }
     while (m) {
         const int b = __ffsll((long long)m) - 1;
         m &= m - 1;
@@ -536,20 +585,55 @@ __device__ inline void topk_offer(TopK& t, float d, int id, int kk, unsigned lon
     }
 }
 
-__device__ inline float wave_min_f(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-// scan one contiguous range of the cell-sorted array
+// scan one contiguous range of the cell-sorted array, four batches per trip (four independent loads in flight: the whole-cloud fallback
+// of a query in an empty neighbourhood is a chain of n / 64 batches, and with one load at a time each of them waited a memory latency)
 __device__ inline void knn_scan_range(TopK& t, const float4& Q, const float4* __restrict__ sorted, unsigned s0, unsigned e0, int kk,
                                       unsigned long long kmask, int lane) {
-    for (unsigned jb = s0; jb < e0; jb += 64) {
-        const unsigned j = jb + lane;
+    for (unsigned jb = s0; jb < e0; jb += 256) {
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned j = jb + 64u * u + lane;
+            p[u] = sorted[j < e0 ? j : e0 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned j = jb + 64u * u + lane;
+            if (jb + 64u * u >= e0) break;        // wave-uniform
+            const bool in = j < e0;
+            const float d = in ? dist2(Q.x, Q.y, Q.z, p[u].x, p[u].y, p[u].z) : FLT_MAX;
+            const int id = in ? __float_as_int(p[u].w) : 0x7fffffff;
+            topk_offer(t, d, id, kk, kmask, lane);
+        }
+    }
+}
+// Up to 64 runs of the cell-sorted array, one per lane (run = [cs, cs + cnt); cnt = 0 for lanes without one): their points are gathered 64
+// per batch — lane l takes the l-th point of the concatenated runs, found by a binary search over the wave-resident prefix sums — so many
+// short runs (a handful of points per cell) cost a few FULL batches instead of one sparse batch each.
+__device__ inline void knn_gather_runs(TopK& t, const float4& Q, const float4* __restrict__ sorted, unsigned cs, unsigned cnt, int kk,
+                                       unsigned long long kmask, int lane) {
+    if (__ballot(cnt != 0u) == 0ull) return;
+    unsigned incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    for (unsigned b0 = 0; b0 < total; b0 += 64) {
+        const unsigned gi = b0 + (unsigned)lane;
+        int lo = 0;                                   // number of runs that end at or before gi = the run holding gi
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const unsigned v = (unsigned)__shfl((int)incl, (lo + step - 1) & 63, 64);
+            if (v <= gi) lo += step;
+        }
+        const int r = lo & 63;
+        const unsigned e1 = (unsigned)__shfl((int)incl, r, 64), n1 = (unsigned)__shfl((int)cnt, r, 64), c1 = (unsigned)__shfl((int)cs, r, 64);
         float d = FLT_MAX;
         int id = 0x7fffffff;
-        if (j < e0) {
-            const float4 p = sorted[j];
+        if (gi < total) {
+            const float4 p = sorted[c1 + (gi - (e1 - n1))];
             d = dist2(Q.x, Q.y, Q.z, p.x, p.y, p.z);
             id = __float_as_int(p.w);
         }
@@ -564,12 +648,13 @@ __device__ inline float knn_gap(float q, float o, float h, int c0, int c1, float
     return fmaxf(g - slack, 0.f);
 }
 
-// One WAVE per query.  Ring 1: the 27 cells around the query, one per lane, visited nearest-first and pruned against the
-// running k-th distance (dense regions settle after one or two cells).  Ring 2: the 5x5x5 shell as 34 row segments, pruned the
-// same way, keeping the list.  After each ring the k-th distance is tested against the distance to the faces of the scanned
-// cube; a query that is still open after ring 2 scans the whole cloud.  Exact for any cell size.
-// The search itself (shared by the k-NN covariance pass and the exact 1-NN export): fills `t` with the kk nearest points of the
-// cell-sorted cloud to Q; returns how the query settled (0 whole grid, 1 / 2 ring, 4 full scan).
+// One WAVE per query.  Ring 1: the 27 cells around the query as nine runs (three x-adjacent cells each).  Ring r >= 2: the shell of the
+// (2r+1)^3 cube as rows of the (2r+1)^2 (y, z) window — rows outside the previous window contribute their whole x segment, rows inside it
+// their two end cells — each run pruned against the running k-th distance before it is gathered.  After each ring the k-th distance is
+// tested against the distance to the faces of the scanned cube; a query still open after ring KNN_RMAX scans the whole cloud.
+// Exact for any cell size.  The search is shared by the k-NN covariance pass, distCUDA2 and the exact 1-NN export: fills `t` with the kk
+// nearest points of the cell-sorted cloud to Q; returns how the query settled (0 whole grid, 1 ring 1, 2 ring 2, 3 a later ring, 4 full scan).
+constexpr int KNN_RMAX = 6;
 __device__ inline int knn_search(const float4 Q, int kk, unsigned long long kmask, const KnnGrid& g, const unsigned* __restrict__ cell_start,
                                  const float4* __restrict__ sorted, int n, int lane, TopK& t) {
     const float slack = 2e-3f * g.h;
@@ -578,67 +663,37 @@ __device__ inline int knn_search(const float4 Q, int kk, unsigned long long kmas
     t.my_d = FLT_MAX; t.my_i = 0x7fffffff; t.tau_d = FLT_MAX; t.tau_i = 0x7fffffff;
     int how = 4;
     bool done = false;
-
-    // ---------------- ring 1: 27 cells, nearest first
-    {
-        float key = FLT_MAX;                  // lower bound of the squared distance to this lane's cell; FLT_MAX = nothing (left) to visit
-        unsigned cs = 0, ce = 0;
-        if (lane < 27) {
-            const int x = cx + lane % 3 - 1, y = cy + (lane / 3) % 3 - 1, z = cz + lane / 9 - 1;
-            if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-                const int c = (z * g.ny + y) * g.nx + x;
-                cs = cell_start[c]; ce = cell_start[c + 1];
-                if (ce > cs) {
-                    const float gx_ = knn_gap(Q.x, g.ox, g.h, x, x, slack), gy_ = knn_gap(Q.y, g.oy, g.h, y, y, slack),
-                                gz_ = knn_gap(Q.z, g.oz, g.h, z, z, slack);
-                    key = gx_ * gx_ + gy_ * gy_ + gz_ * gz_;
-                }
-            }
-        }
-        for (;;) {
-            const float m = wave_min_f(key);
-            if (m == FLT_MAX || m > t.tau_d) break;      // every remaining cell is farther than the current k-th neighbour
-            const int sel = __ffsll((long long)__ballot(key == m)) - 1;
-            const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)cs, sel), e0 = (unsigned)__builtin_amdgcn_readlane((int)ce, sel);
-            knn_scan_range(t, Q, sorted, s0, e0, kk, kmask, lane);
-            if (lane == sel) key = FLT_MAX;
-        }
-    }
-    for (int r = 1; r <= 2 && !done; ++r) {
+    for (int r = 1; r <= KNN_RMAX && !done; ++r) {
         const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r >= g.nx ? g.nx - 1 : cx + r;
         const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r >= g.ny ? g.ny - 1 : cy + r;
         const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r >= g.nz ? g.nz - 1 : cz + r;
-        if (r == 2) {
-            // ---------------- ring 2: rows of the 5x5 (y,z) window.  Rows inside the 3x3 window contribute only their two end cells
-            // (lanes 0..24: left / whole segment, lanes 25..49: right end cell of an inner row); the list from ring 1 is kept.
-            float key = FLT_MAX;
-            unsigned cs = 0, ce = 0;
-            if (lane < 50) {
-                const int rr = lane % 25, y = cy + rr % 5 - 2, z = cz + rr / 5 - 2;
-                const bool inner = (rr % 5 >= 1 && rr % 5 <= 3 && rr / 5 >= 1 && rr / 5 <= 3);
-                if (y >= 0 && y < g.ny && z >= 0 && z < g.nz && (lane < 25 || inner)) {
-                    int xa, xb;
-                    if (!inner) { xa = x0; xb = x1; }
-                    else if (lane < 25) { xa = cx - 2; xb = cx - 2; }
-                    else { xa = cx + 2; xb = cx + 2; }
-                    if (xa >= 0 && xb < g.nx) {
-                        const int base = (z * g.ny + y) * g.nx;
-                        cs = cell_start[base + xa]; ce = cell_start[base + xb + 1];
-                        if (ce > cs) {
-                            const float gx_ = knn_gap(Q.x, g.ox, g.h, xa, xb, slack), gy_ = knn_gap(Q.y, g.oy, g.h, y, y, slack),
-                                        gz_ = knn_gap(Q.z, g.oz, g.h, z, z, slack);
-                            key = gx_ * gx_ + gy_ * gy_ + gz_ * gz_;
+        const int side = 2 * r + 1, rows = side * side;
+        // pass 0: every row of the window (outer rows: the whole segment; inner rows of r >= 2: the left end cell, x = cx - r);
+        // pass 1 (r >= 2): the right end cell (x = cx + r) of the inner rows
+        for (int pass = 0; pass < (r >= 2 ? 2 : 1); ++pass) {
+            for (int w0 = 0; w0 < rows; w0 += 64) {
+                const int w = w0 + lane;
+                unsigned cs = 0, cnt = 0;
+                if (w < rows) {
+                    const int dy = w % side - r, dz = w / side - r;
+                    const int y = cy + dy, z = cz + dz;
+                    const bool inner = r >= 2 && dy > -r && dy < r && dz > -r && dz < r;
+                    if (y >= 0 && y < g.ny && z >= 0 && z < g.nz && (pass == 0 || inner)) {
+                        int xa = x0, xb = x1;
+                        if (inner) { xa = xb = (pass == 0 ? cx - r : cx + r); }
+                        if (xa >= 0 && xb < g.nx) {
+                            const int base = (z * g.ny + y) * g.nx;
+                            cs = cell_start[base + xa];
+                            cnt = cell_start[base + xb + 1] - cs;
+                            if (cnt != 0u && r >= 2) {     // prune against the list of the previous rings (strictly farther runs only)
+                                const float gx_ = knn_gap(Q.x, g.ox, g.h, xa, xb, slack), gy_ = knn_gap(Q.y, g.oy, g.h, y, y, slack),
+                                            gz_ = knn_gap(Q.z, g.oz, g.h, z, z, slack);
+                                if (gx_ * gx_ + gy_ * gy_ + gz_ * gz_ > t.tau_d) cnt = 0u;
+                            }
                         }
                     }
                 }
-            }
-            for (;;) {
-                const float m = wave_min_f(key);
-                if (m == FLT_MAX || m > t.tau_d) break;
-                const int sel = __ffsll((long long)__ballot(key == m)) - 1;
-                const unsigned s0 = (unsigned)__builtin_amdgcn_readlane((int)cs, sel), e0 = (unsigned)__builtin_amdgcn_readlane((int)ce, sel);
-                knn_scan_range(t, Q, sorted, s0, e0, kk, kmask, lane);
-                if (lane == sel) key = FLT_MAX;
+                knn_gather_runs(t, Q, sorted, cs, cnt, kk, kmask, lane);
             }
         }
         // every point outside the scanned cube is at least `gr` away (faces clipped by the grid boundary do not count: nothing lies beyond)
@@ -652,7 +707,7 @@ __device__ inline int knn_search(const float4 Q, int kk, unsigned long long kmas
         if (gr == FLT_MAX) { done = true; how = 0; }                      // the cube already covers the whole grid
         else {
             gr -= slack;                                                  // cell assignment is a rounded float multiply: stay conservative
-            if (gr > 0.f && t.tau_d < gr * gr * 0.9999f) { done = true; how = r; }   // strict: an equal-distance outsider could win the index tie-break
+            if (gr > 0.f && t.tau_d < gr * gr * 0.9999f) { done = true; how = r < 3 ? r : 3; }   // strict: an equal-distance outsider could win the index tie-break
         }
     }
     if (!done) {   // sparse neighbourhood: scan everything
