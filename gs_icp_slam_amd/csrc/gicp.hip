@@ -1078,6 +1078,60 @@ __device__ inline bool is_converged(const double* R, const double* t, double rot
     return fmax(mr, mt) < 1.0;
 }
 
+__device__ inline double readlane_d(double v, int l) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// The scalar steps between two grid-wide phases used to run on ONE lane while the rest of the chip waited (5.8 us of every ~19 us phase).
+// The variants below are called by all 64 lanes of a workgroup's first wave with identical inputs: what is independent runs on
+// different lanes — the four trigonometric calls of the exponential map become two (lane 1 evaluates the full angle while the
+// others evaluate the half angle), the twelve fp64 divisions of the convergence test become one — and every value is the one the
+// single-lane code computed (same operations on the same operands; max and the lane a value is computed on do not change it).
+__device__ inline void se3_exp_wave(const double* a, double* R, double* t, const int lane) {
+    const double wx = a[0], wy = a[1], wz = a[2];
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    double imag, real, theta = 0, s_th = 0, c_th = 1;
+    bool have_full = false;
+    if (theta_sq < 1e-10) {
+        const double t4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * t4;
+        real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * t4;
+    } else {
+        theta = sqrt(theta_sq);
+        const double half = 0.5 * theta;
+        const double arg = lane == 1 ? theta : half;
+        const double sv = sin(arg), cv = cos(arg);
+        imag = readlane_d(sv, 0) / theta;
+        real = readlane_d(cv, 0);
+        s_th = readlane_d(sv, 1); c_th = readlane_d(cv, 1);
+        have_full = true;
+    }
+    const double q[4] = {imag * wx, imag * wy, imag * wz, real};
+    quat_to_rot(q, R);
+    double V[9];
+    if (theta_sq < 1e-20) {
+        for (int i = 0; i < 9; ++i) V[i] = R[i];
+    } else {
+        if (theta == 0) theta = sqrt(theta_sq);
+        if (!have_full) { s_th = sin(theta); c_th = cos(theta); }
+        const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+        double O2[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+        const double c1 = (1.0 - c_th) / theta_sq, c2 = (theta - s_th) / (theta_sq * theta);
+        for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0 ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+    }
+    for (int i = 0; i < 3; ++i) t[i] = V[3 * i] * a[3] + V[3 * i + 1] * a[4] + V[3 * i + 2] * a[5];
+}
+__device__ inline bool is_converged_wave(const double* R, const double* t, double rot_eps, double trans_eps, const int lane) {
+    double v = 0.0;
+    if (lane < 9) v = fabs(R[lane] - (lane % 4 == 0 ? 1.0 : 0.0)) / rot_eps;
+    else if (lane < 12) v = fabs(t[lane - 9]) / trans_eps;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));     // lanes 0..15 hold the twelve terms (and zeros)
+    return readlane_d(v, 0) < 1.0;
+}
 struct AlignShared {
     double scratch[AL_T / 64][NRED + 1];
     double red[NRED + 1];
@@ -1337,44 +1391,58 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
             if (tid < NRED) sh.spec[tid] = sh.red[tid];
             __syncthreads();
         }
-        if (tid == 0) {
-            int kk = 0;
-            for (int r = 0; r < 6; ++r)
-                for (int cc = r; cc < 6; ++cc) { sh.H[6 * r + cc] = sh.spec[kk]; sh.H[6 * cc + r] = sh.spec[kk]; ++kk; }
-            for (int r = 0; r < 6; ++r) sh.b[r] = sh.spec[21 + r];
-            sh.y0 = sh.spec[27];
-            if (sh.lambda < 0.0) {
-                double mx = 0;
-                for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(sh.H[7 * i]));
-                sh.lambda = a.lm_init * mx;
+        if (tid < 64) {   // first wave, one element per lane
+            if (tid < 36) {
+                const int r = tid / 6, c = tid % 6, lo = r < c ? r : c, hi = r < c ? c : r;
+                sh.H[tid] = sh.spec[6 * lo - lo * (lo - 1) / 2 + (hi - lo)];       // spec holds the upper triangle row by row
             }
-            sh.nu = 2.0;
-            sh.accepted = 0;
-            if (leader) for (int i = 0; i < 12; ++i) a.result->lin_pose[i] = sh.x0[i];
+            if (tid < 6) sh.b[tid] = sh.spec[21 + tid];
+            if (tid == 0) {
+                sh.y0 = sh.spec[27];
+                if (sh.lambda < 0.0) {
+                    const int diag[6] = {0, 6, 11, 15, 18, 20};
+                    double mx = 0;
+                    for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(sh.spec[diag[i]]));
+                    sh.lambda = a.lm_init * mx;
+                }
+                sh.nu = 2.0;
+                sh.accepted = 0;
+            }
+            if (blockIdx.x == 0 && tid < 12) a.result->lin_pose[tid] = sh.x0[tid];
         }
         __syncthreads();
 
+        trace_stamp(a.trace, tn, 30);
         // ---------------- LM trials (every workgroup runs the same scalar arithmetic on the same totals)
         bool step_ok = false;
         for (int trial = 0; trial < a.lm_max_iter; ++trial) {
             ++lm_trials;
-            if (tid == 0) {
+            if (tid < 64) {   // every lane of the first wave runs the same solve (LDS reads are broadcasts); lane 0 publishes
                 double Hl[36], nb[6], d[6];
                 for (int i = 0; i < 36; ++i) Hl[i] = sh.H[i];
-                for (int i = 0; i < 6; ++i) { Hl[7 * i] += sh.lambda; nb[i] = -sh.b[i]; }
+                const double lam = sh.lambda;
+                for (int i = 0; i < 6; ++i) { Hl[7 * i] += lam; nb[i] = -sh.b[i]; }
+                trace_stamp(a.trace, tn, 31);
                 if (!solve6(Hl, nb, d)) {
-                    sh.state = 2;
+                    if (tid == 0) sh.state = 2;
                 } else {
-                    sh.state = 0;
-                    se3_exp(d, sh.delta, sh.delta + 9);
-                    for (int i = 0; i < 3; ++i) {
-                        for (int j = 0; j < 3; ++j)
-                            sh.xi[3 * i + j] = sh.delta[3 * i] * sh.x0[j] + sh.delta[3 * i + 1] * sh.x0[3 + j] + sh.delta[3 * i + 2] * sh.x0[6 + j];
-                        sh.xi[9 + i] = sh.delta[3 * i] * sh.x0[9] + sh.delta[3 * i + 1] * sh.x0[10] + sh.delta[3 * i + 2] * sh.x0[11] + sh.delta[9 + i];
-                    }
+                    trace_stamp(a.trace, tn, 32);
+                    double dl[12], x0[12];
+                    se3_exp_wave(d, dl, dl + 9, tid);
+                    trace_stamp(a.trace, tn, 33);
+                    for (int i = 0; i < 12; ++i) x0[i] = sh.x0[i];
                     double den = 0;
-                    for (int i = 0; i < 6; ++i) den += d[i] * (sh.lambda * d[i] - sh.b[i]);
-                    sh.denom = den;
+                    for (int i = 0; i < 6; ++i) den += d[i] * (lam * d[i] - sh.b[i]);
+                    if (tid == 0) {
+                        sh.state = 0;
+                        for (int i = 0; i < 12; ++i) sh.delta[i] = dl[i];
+                        for (int i = 0; i < 3; ++i) {
+                            for (int j = 0; j < 3; ++j)
+                                sh.xi[3 * i + j] = dl[3 * i] * x0[j] + dl[3 * i + 1] * x0[3 + j] + dl[3 * i + 2] * x0[6 + j];
+                            sh.xi[9 + i] = dl[3 * i] * x0[9] + dl[3 * i + 1] * x0[10] + dl[3 * i + 2] * x0[11] + dl[9 + i];
+                        }
+                        sh.denom = den;
+                    }
                 }
             }
             __syncthreads();
@@ -1408,28 +1476,31 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
             trace_stamp(a.trace, tn, 5);   // speculative linearisation done
             grid_sum<NRED + 1>(both, sh, a.sync, epoch, tid, a.trace, &tn);
             if (sh.abort) { failed = 2; break; }
-            if (tid == 0) {
+            if (tid < 64) {   // first wave: the decision is wave-uniform (every lane reads the same totals), the copies are one element per lane
                 const double yi = sh.red[NRED];
                 const double rho = (sh.y0 - yi) / sh.denom;
                 if (rho < 0) {
-                    if (is_converged(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps)) {
-                        sh.state = 1;       // upstream returns true without accepting the step
-                    } else {
-                        sh.lambda = sh.nu * sh.lambda;
-                        sh.nu = 2 * sh.nu;
-                        sh.state = 0;
+                    const bool conv = is_converged_wave(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps, tid);
+                    if (tid == 0) {
+                        if (conv) {
+                            sh.state = 1;       // upstream returns true without accepting the step
+                        } else {
+                            sh.lambda = sh.nu * sh.lambda;
+                            sh.nu = 2 * sh.nu;
+                            sh.state = 0;
+                        }
                     }
                 } else {
-                    for (int i = 0; i < 12; ++i) sh.x0[i] = sh.xi[i];
-                    for (int i = 0; i < NRED; ++i) sh.spec[i] = sh.red[i];
-                    const double f = 2 * rho - 1;
-                    sh.lambda = sh.lambda * fmax(1.0 / 3.0, 1 - f * f * f);
-                    if (leader) {
-                        for (int i = 0; i < 36; ++i) a.result->H_final[i] = sh.H[i];
-                        a.result->cost = yi;
+                    if (tid < 12) sh.x0[tid] = sh.xi[tid];
+                    if (tid < NRED) sh.spec[tid] = sh.red[tid];
+                    if (blockIdx.x == 0 && tid < 36) a.result->H_final[tid] = sh.H[tid];
+                    if (tid == 0) {
+                        const double f = 2 * rho - 1;
+                        sh.lambda = sh.lambda * fmax(1.0 / 3.0, 1 - f * f * f);
+                        if (leader) a.result->cost = yi;
+                        sh.state = 1;
+                        sh.accepted = 1;
                     }
-                    sh.state = 1;
-                    sh.accepted = 1;
                 }
             }
             __syncthreads();
@@ -1438,7 +1509,10 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
         if (failed) break;
         if (!step_ok) { failed = 1; break; }   // "lm not converged"
         ++iterations;
-        if (tid == 0) sh.converged = is_converged(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps) ? 1 : 0;
+        if (tid < 64) {
+            const bool conv = is_converged_wave(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps, tid);
+            if (tid == 0) sh.converged = conv ? 1 : 0;
+        }
         __syncthreads();
         if (sh.converged) break;
         have_lin = sh.accepted != 0 && it + 1 < a.max_iter;

@@ -12,7 +12,7 @@ import pygicp  # noqa: E402
 from gs_icp_slam_amd import _lib, synth  # noqa: E402
 
 cfg = synth.REPLICA if "--tum" not in sys.argv else synth.TUM
-sp = synth.s_pair(cfg, noise=("--tum" in sys.argv))
+sp = (synth.s_pair_survey if "--survey" in sys.argv else synth.s_pair)(cfg, noise=("--tum" in sys.argv))   # --survey: SURVEY 8(d)'s pair (7 LM iterations)
 pw = sp["points_a"].astype(np.float64) @ sp["pose_a"][:3, :3].T + sp["pose_a"][:3, 3]
 
 
@@ -75,7 +75,8 @@ if os.environ.get("GSICP_ALIGN_TRACE"):
     buf = (ctypes.c_ulonglong * 500)()
     n = _lib.load().gsicp_gicp_align_trace(reg._h, buf, 250)
     names_t = {0: "start", 1: "lin begin", 2: "lin compute done", 3: "solve done", 4: "trial cost done", 5: "spec lin done", 10: "wave+LDS reduce, partial stored",
-               11: "barrier passed", 20: "  point loaded", 21: "  nn done", 22: "  maha/J done", 12: "partials summed", 99: "end"}
+               11: "barrier passed", 20: "  point loaded", 21: "  nn done", 22: "  maha/J done", 12: "partials summed", 99: "end",
+               30: "accept/reject + convergence test + H fill done", 31: "damped H in registers", 32: "LDL^T solve done", 33: "se3 exp done"}
     t0 = buf[1]
     prev = t0
     for i in range(n):
