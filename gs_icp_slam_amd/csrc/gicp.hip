@@ -428,7 +428,8 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
     __shared__ KnnGrid s_g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = tid; i < n; i += 1024) {
+#pragma unroll 4
+    for (int i = tid; i < n; i += 1024) {   // (unrolled: the loads of several trips are in flight together — each pass is a chain of n / 1024 latencies otherwise)
         const float4 p = pts[i];
         lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
         hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
@@ -475,6 +476,7 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
     unsigned* cnt = in_lds ? s_cnt : cell_count;
     for (int c = tid; c < ncells; c += 1024) cnt[c] = 0u;
     __syncthreads();
+#pragma unroll 4
     for (int i = tid; i < n; i += 1024) {
         const float4 p = pts[i];
         int cx, cy, cz;
@@ -489,15 +491,20 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
     const int clo = tid * per, chi = (clo + per) < ncells ? (clo + per) : ncells;
     unsigned sum = 0;
     for (int c = clo; c < chi; ++c) sum += cnt[c];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
-        const unsigned v = tid >= off ? s_part[tid - off] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    // exclusive scan of the 1024 partials: in-wave inclusive scan (six DPP / shuffle steps), then the 16 wave totals through LDS —
+    // two barriers instead of the twenty of a Hillis-Steele scan over the whole workgroup
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    unsigned run = s_part[tid] - sum;
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    unsigned before = 0, total_all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const unsigned v = s_part[w]; if (w < wave) before += v; total_all += v; }
+    unsigned run = before + incl - sum;
     unsigned* cur = in_lds ? s_cnt : cell_fill;     // the counters become the fill cursors
     for (int c = clo; c < chi; ++c) {
         const unsigned k = cnt[c];
@@ -505,9 +512,10 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
         cur[c] = run;
         run += k;
     }
-    if (tid == 1023) cell_start[ncells] = s_part[1023];
+    if (tid == 1023) cell_start[ncells] = total_all;
     __threadfence_block();
     __syncthreads();
+#pragma unroll 4
     for (int i = tid; i < n; i += 1024) {
         float4 p = pts[i];
         p.w = __int_as_float(i);
