@@ -381,8 +381,8 @@ def main():
         # design byte count of the kernel as built: 4 strip waves each read the list word (16 B / duplicate), staged
         # 48-byte records, per-pixel state, 48-byte gradient slot writes per (entry, strip)
         design_bytes = 64.0 * D_local + 40.0 * WHr + 48.0 * D_local
-        traffic, traffic_src, note = None, None, ("working set (~60 MB) sits in the 256 MiB Infinity Cache; the kernel is VALU-issue bound, "
-                                                  "the HBM fraction is a formality")
+        traffic, traffic_src, note = None, None, ("working set (~60 MB) sits in the 256 MiB Infinity Cache: the HBM fraction is a formality; the kernel runs "
+                                                  "~80 % VALU-busy and tracks the per-entry dependent chain (DESIGN 3.3)")
         if world == 1 and args.res == "replica" and P == 300_000:
             for tag in ("r02", "r01"):   # PMC passes of this command, collected by tools/capture_profiles.sh (counters cannot be read in-process)
                 tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")

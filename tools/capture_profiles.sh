@@ -20,6 +20,16 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OU
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- $BENCH > /dev/null 2> $OUT/write.err
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY \
           --kernel-trace --output-format csv -d $OUT/sq -o p -- $BENCH > /dev/null 2> $OUT/sq.err
+# each half ALONE under the kernel trace: per-kernel durations without the other half's co-tenancy (the iteration is the sum of these)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_mapper -o bench -- python $ROOT/bench.py --only mapper --steps 50 --warmup 5 --repeats 2 --no-cpu-baseline --no-legs > $OUT/bench_mapper_only_under_rocprof.json 2> $OUT/kt_mapper.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_tracker -o bench -- python $ROOT/bench.py --only tracker --steps 50 --warmup 5 --repeats 2 --no-cpu-baseline --no-legs > $OUT/bench_tracker_only_under_rocprof.json 2> $OUT/kt_tracker.err
+python $ROOT/bench.py --only mapper --no-cpu-baseline --no-legs > $OUT/bench_mapper_only.json 2>> $OUT/bench.err
+python $ROOT/bench.py --only tracker --no-cpu-baseline --no-legs > $OUT/bench_tracker_only.json 2>> $OUT/bench.err
+# the N > 1 iteration (tile movers + both RCCL collectives captured in the graph) on a 1-rank group: the exchange machinery without wire time
+GSICP_BENCH_FORCE_COLLECTIVES=1 python $ROOT/bench.py --only mapper --no-cpu-baseline --no-legs > $OUT/bench_force_collectives.json 2>> $OUT/bench.err
+python $ROOT/tools/rccl_graph_probe.py > $OUT/rccl_graph_probe.json 2>> $OUT/bench.err
+# tracker: phase trace of the persistent LM kernel and the k-NN ring statistics on SURVEY 8(d)'s pair
+(cd $ROOT && GSICP_ALIGN_TRACE=1 GSICP_KNN_STATS=1 timeout 120 python tools/tracker_latency.py --survey > $OUT/tracker_latency_survey.txt 2>&1)
 # the UNTOUCHED reference system on the drop-ins (synthetic sequences in Replica's on-disk layout), with the drop-in call trace
 cd $ROOT
 timeout 600 python tools/run_reference_slam.py --synthetic 400 --timeout 500 --trace $OUT/trace_ref --log $OUT/reference_run_replica.log > $OUT/reference_run_replica.json 2> $OUT/reference_run.err
