@@ -9,7 +9,10 @@ One "step" = one SLAM frame's worth of the hot path on synthetic Replica-shaped 
   mapper  : one full optimisation iteration — activations, GaussianRasterizer forward, the mapping loss
             0.8 L1 + 0.2 (1-SSIM) + 0.1 L1(depth/10), backward, Adam step over the parameter groups, zero_grad; P = 300 000 surfels,
             1200x680                                                                                             [REF mp_Mapper.py:219-248]
-The two halves run concurrently, as the reference's two processes do [REF gs_icp_slam.py:121-131].
+The two halves run concurrently, as the reference's two processes do [REF gs_icp_slam.py:121-131]: inside a timed block the tracker thread
+runs its --steps frames and the main thread its --steps mapper iterations, each at its own pace (the reference's Tracker.run and
+Mapper.run never wait for each other per frame); the block ends when both are done.  `--lockstep` joins them after every step instead
+(round 1's loop; reported as a leg).
 With N > 1 GPUs the mapper's tiles are sharded across ranks (strong scaling; gs_icp_slam_amd/sharded.py) and the tracker runs as a
 replica on every rank (it does not shard — DESIGN.md).
 
@@ -77,6 +80,8 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (tracker-only, mapper-only, eager, drop-in reference loop)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--serial", action="store_true", help="run tracker and mapper back-to-back on one thread (default: concurrently)")
+    ap.add_argument("--lockstep", action="store_true", help="join the tracker frame and the mapper iteration after EVERY step (round 1's timing loop) instead of "
+                    "letting the two halves run their --steps steps at their own pace inside the timed block")
     ap.add_argument("--no-graph", action="store_true", help="drive the mapper iteration eagerly from Python instead of replaying the captured HIP graph")
     ap.add_argument("--only", choices=["tracker", "mapper"], default=None, help="diagnostics: run only one half (the JSON line is then NOT the contract metric)")
     args = ap.parse_args()
@@ -220,9 +225,13 @@ def main():
 
     def tracker_worker():
         while True:
-            if jobs.get() is None:
+            n = jobs.get()
+            if n is None:
                 return
-            done.put(trk.step())
+            r = None
+            for _ in range(n):
+                r = trk.step()
+            done.put(r)
     worker = None
     if not args.serial and args.only is None:
         worker = threading.Thread(target=tracker_worker, daemon=True)
@@ -302,13 +311,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_blocks(fn, steps, repeats):
+    def free_running_block(steps):
+        """`steps` tracker frames on the worker thread and `steps` mapper iterations on this one, each half at its own pace, as the
+        reference's two processes run [REF gs_icp_slam.py:121-131: Tracker.run and Mapper.run never wait for each other per frame]; the
+        block ends when BOTH halves have finished all their steps."""
+        jobs.put(steps)
+        for _ in range(steps):
+            loss, radii = mapper_iteration()
+        T, idx, d2 = done.get()
+        last.update(T=T, loss=loss, radii=radii)
+
+    def timed_blocks(fn, steps, repeats, whole=None):
         out = []
         for _ in range(repeats):
             barrier()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                fn()
+            if whole is not None:
+                whole(steps)
+            else:
+                for _ in range(steps):
+                    fn()
             barrier()
             dt = time.perf_counter() - t0
             if world > 1:
@@ -320,7 +342,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    blocks = timed_blocks(step, args.steps, max(1, args.repeats))
+    free_running = worker is not None and not args.lockstep
+    blocks = timed_blocks(step, args.steps, max(1, args.repeats), whole=free_running_block if free_running else None)
     dt = statistics.median(blocks)
     if mg is not None and (mg.overflowed() or mg.skipped_steps() > 0):
         raise RuntimeError(f"capacity overflowed during the timed region: R = {int(mg.num_rendered.item())} (capacity {mg.capacity}), "
@@ -422,6 +445,12 @@ def main():
             ts = timed_blocks(fn, n, reps)
             return statistics.median(ts) / n
 
+        # -- the same step with both halves joined after EVERY step (round 1's timing loop; the queue hand-shake per step makes it slower and
+        #    bimodal from run to run)
+        if worker is not None and free_running:
+            s_lock = rate(step, 100)
+            legs["lockstep_step"] = {"frames_per_s": round(1.0 / s_lock, 1), "ms_per_step": round(1e3 * s_lock, 4),
+                                     "what": "tracker frame and mapper iteration joined after every step (round-1 loop)"}
         # -- tracker alone, both pairs
         cases = {args.pair: trk}
         other = "basin" if args.pair == "survey" else "survey"
@@ -603,6 +632,8 @@ def main():
                        "tracker_pair": args.pair, "tracker_motion": motions[args.pair], "lm_iterations": it,
                        "gaussians": P, "width": W, "height": H, "duplicates_per_rank": D_local, "visible_gaussians": P_vis,
                        "tracker_mapper_overlap": worker is not None,
+                       "step_coupling": ("free-running: K tracker frames and K mapper iterations run concurrently, each at its own pace; the block ends when both are done"
+                                         if free_running else ("lockstep: both halves joined after every step" if worker is not None else "one half after the other")),
                        "mapper_iteration": (("one hipGraph replay per iteration" + (" (tile all-gather + gradient all-reduce captured inside)" if (world > 1 or force_coll) else ""))
                                             if mg is not None else "eager launches from Python"),
                        "rccl_graph_probe": rccl_graph_probe,
