@@ -48,7 +48,7 @@ std::vector<hipEvent_t> g_prof_pool;
 hipEvent_t g_prof_open[ST_COUNT];
 std::atomic<int> g_prof_enabled{0};
 // stage -> kernel: preprocess = preprocess_kernel; tile_scan_lpt = tile_scan_lpt_kernel; emit = emit_kernel; split_hist / split_colscan /
-// split_scatter = the three multi-split kernels; tile_sort_long / tile_sort = tile_sort_kernel's two size classes (> 512 entries / the rest);
+// split_scatter = the three multi-split kernels; tile_sort = tile_sort_kernel (tile_sort_long: a second size class that no longer exists, never timed);
 // blend_forward = blend_forward_strip_kernel; blend_backward = blend_backward_tile_kernel; preprocess_backward = preprocess_backward_kernel;
 // gicp_* = the tracker's call-level stages (several launches each); loss_pass1 / loss_pass2 = the two loss kernels (pass 1 includes the
 // one-workgroup reduce); adam = adam_tensor_kernel (+ the one-thread step bump)
@@ -110,58 +110,60 @@ __global__ void publish_count_kernel(const uint32_t* __restrict__ total, uint32_
 // ------------------------------------------------------------------------------------------------ binning
 // Single workgroup: exclusive scan of the per-tile duplicate counts -> list ranges, and an LPT dispatch order by a
 // counting sort over 64 length buckets (exact ordering is not needed for load balance).  Any T; one launch.
-constexpr int LPT_BUCKETS = 64;
+constexpr int LPT_BUCKETS = 64;   // = the wave size (the bucket scan below runs on one wave)
 __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int tile_mod, int tile_rem, const uint32_t* __restrict__ tile_count,
-                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ order,
-                                                             uint32_t* __restrict__ n_front /* tiles at the head of `order` that may exceed long_min */,
-                                                             uint32_t long_min) {
+                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
     __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
     __shared__ uint32_t s_hist[LPT_BUCKETS];
     __shared__ uint32_t s_maxlen;
-    __shared__ uint32_t s_front;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { s_carry = 0; s_maxlen = 0; s_front = 0; }
+    if (tid == 0) s_maxlen = 0;
     if (tid < LPT_BUCKETS) s_hist[tid] = 0;
     __syncthreads();
-    for (int base = 0; base < T; base += 1024) {
-        const int t = base + tid;
-        const uint32_t c = t < T ? tile_count[t] : 0u;
-        uint32_t incl = c;   // wave inclusive scan
+    // exclusive scan in ONE pass: thread i owns the `per` consecutive tiles starting at i * per (one wave scan + 16 wave totals, two barriers,
+    // whatever T is; a 1024-tile-per-round loop cost three barriers per round)
+    {
+        const int per = (T + 1023) / 1024;
+        const int t0 = tid * per, t1 = (t0 + per) < T ? (t0 + per) : T;
+        uint32_t sum = 0, wmax = 0;
+        for (int t = t0; t < t1; ++t) { const uint32_t c = tile_count[t]; sum += c; wmax = c > wmax ? c : wmax; }
+        uint32_t incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off, 64);
             if (lane >= off) incl += o;
         }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t wave_off = 0;
-        for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
-        const uint32_t start = s_carry + wave_off + incl - c;
-        if (t < T) ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);   // empty tiles read (0,0), as the reference leaves them
-        uint32_t wmax = c;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(wmax, off, 64); wmax = o > wmax ? o : wmax; }
+        if (lane == 63) s_wave[wave] = incl;
         if (lane == 0 && wmax > 0) atomicMax(&s_maxlen, wmax);
         __syncthreads();
-        if (tid == 1023) s_carry = start + c;
-        __syncthreads();
+        uint32_t start = incl - sum;
+        for (int w = 0; w < wave; ++w) start += s_wave[w];
+        for (int t = t0; t < t1; ++t) {
+            const uint32_t c = tile_count[t];
+            ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);   // empty tiles read (0,0), as the reference leaves them
+            start += c;
+        }
     }
     // LPT order over this rank's tiles
     const uint32_t maxlen = s_maxlen;
     const uint32_t div = maxlen / LPT_BUCKETS + 1;
     const int n_local = (T - tile_rem + tile_mod - 1) / tile_mod;
-    const uint32_t front_bucket = (long_min + 1) / div;   // every tile longer than long_min sits in this length bucket or a longer one
     for (int i = tid; i < n_local; i += 1024) {
         const uint32_t c = tile_count[i * tile_mod + tile_rem];
         atomicAdd(&s_hist[LPT_BUCKETS - 1 - (c / div)], 1u);     // bucket 0 = longest lists
-        if (c / div >= front_bucket && c > 0) atomicAdd(&s_front, 1u);
     }
     __syncthreads();
-    if (tid == 0 && n_front) *n_front = s_front;             // those tiles are contiguous at the head of the LPT order
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int b = 0; b < LPT_BUCKETS; ++b) { const uint32_t h = s_hist[b]; s_hist[b] = run; run += h; }
+    if (tid < LPT_BUCKETS) {   // exclusive scan of the 64 bucket counts on the first wave (LPT_BUCKETS == 64)
+        const uint32_t h = s_hist[tid];
+        uint32_t incl = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        s_hist[tid] = incl - h;
     }
     __syncthreads();
     for (int i = tid; i < n_local; i += 1024) {
@@ -331,12 +333,11 @@ __device__ inline void bitonic_pairs(unsigned long long* __restrict__ s_key, uin
 }
 
 // One workgroup per tile: sort the tile's list by (depth bits, Gaussian id) — a total order, so the result is unique.
-// Lists up to SORT_CAP entries are bitonic-sorted in LDS; longer ones are sorted in SORT_CAP-entry chunks and merged by rank
+// Lists up to CAP (= SORT_SMALL) entries are bitonic-sorted in LDS; longer ones are sorted in CAP-entry chunks and merged by rank
 // (binary searches across the sorted chunks) — not reached by the scenes in BASELINE.json, whose longest lists are a few hundred entries.
-constexpr int SORT_CAP = 4096;     // long-list kernel: 1024 threads, 48 KB LDS, a small persistent grid over the head of the LPT order
-constexpr int SORT_SMALL = 1024;   // short-list kernel: 256 threads (one wave does all the work of a <= 128-entry list; the others only meet it at
-                                   // three barriers), 12 KB LDS -> many workgroups per CU.  With the pair-per-thread network a 1024-entry list costs this
-                                   // class ~6 us, so the long class only sees lists the BASELINE scenes never produce
+constexpr int SORT_SMALL = 1024;   // LDS capacity of the sort kernel: 256 threads (one wave does all the work of a <= 128-entry list; the others only meet
+                                   // it at three barriers), 12 KB LDS -> many workgroups per CU.  With the pair-per-thread network a 1024-entry list costs
+                                   // ~6 us; longer lists (none in the BASELINE scenes) take the chunk-sort + rank-merge path below
 template <int CAP, int THREADS, int MIN_N>
 __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uint32_t* __restrict__ s_val, const uint32_t tile,
                                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ sc_keys, const uint32_t* __restrict__ sc_vals,
@@ -344,7 +345,7 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
                                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ list_gauss) {
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (n <= MIN_N || (MIN_N == 0 && n > CAP)) return;   // the other size class's kernel handles this tile
+    if (n <= MIN_N) return;   // (MIN_N > 0: a size class that leaves the short lists to another launch; not used by the shipped path)
     const int tid = threadIdx.x;
     if (n > CAP) {
         // Long list (> CAP entries: far beyond the BASELINE scenes, whose longest lists are a few hundred entries).  Chunks of CAP entries
@@ -420,10 +421,8 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
         list_gauss[range.x + i] = (uint32_t)s_key[i];   // low word of the sort key = Gaussian id
     }
 }
-// The long class (MIN_N > 0) runs a small persistent grid over the head of the LPT order only (`limit_dev` = the number of tiles that may be
-// longer than MIN_N, counted by tile_scan_lpt_kernel) with 1024 threads per list: a bitonic stage then costs one compare-exchange and one
-// barrier per thread instead of four, which is what a handful of 600-1000-entry lists on the critical path are made of (37 -> 9 us when the
-// trained map pushes a few tiles past 512 entries).  The short class keeps one 128-thread workgroup per tile.
+// One workgroup per tile of the LPT order (grid-stride, so a smaller persistent grid also works; `limit_dev`, optional, bounds the
+// number of tiles read from the device).
 template <int CAP, int THREADS, int MIN_N>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int n_tiles, const uint32_t* __restrict__ limit_dev, const uint32_t* __restrict__ order,
                                                             const uint2* __restrict__ ranges, const uint32_t* __restrict__ sc_keys,
@@ -907,8 +906,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     }
     {
         ProfileScope ps(ST_RANGES, stream);
-        hipLaunchKernelGGL(tile_scan_lpt_kernel, dim3(1), dim3(1024), 0, stream, T, tile_mod, tile_rem, tile_count, ranges, order, total_counter + 1,
-                           (uint32_t)SORT_SMALL);
+        hipLaunchKernelGGL(tile_scan_lpt_kernel, dim3(1), dim3(1024), 0, stream, T, tile_mod, tile_rem, tile_count, ranges, order);
     }
     if (num_rendered > 0) {
         {
@@ -917,14 +915,9 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                                entry_bits, block_hist, ranges, (uint32_t*)(bin + BL.scatter_keys), (uint32_t*)(bin + BL.scatter_vals));
         }
         const int n_local = (T - tile_rem + tile_mod - 1) / tile_mod;
-        // two size classes over the same (LPT-ordered) tile list; each kernel skips the other class's tiles.  (They touch disjoint lists, but
-        // running the long class on a side stream between fork / join events — two parallel branches of the captured hipGraph — made the
-        // replayed iteration 0.71 ms instead of 0.40 ms on this stack: cross-stream edges in a graph are far dearer than the 23 us they hide.)
-        { ProfileScope ps(ST_TILE_SORT_LONG, stream);
-          hipLaunchKernelGGL((tile_sort_kernel<SORT_CAP, 512, SORT_SMALL>), dim3(n_local < 64 ? n_local : 64), dim3(512), 0, stream, n_local,
-                             (const uint32_t*)(total_counter + 1), order, ranges,
-                             (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
-                             (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss)); }
+        // ONE class: lists up to SORT_SMALL entries (everything the BASELINE scenes produce: their longest lists are ~500 entries) are sorted
+        // in LDS, longer ones in SORT_SMALL-entry chunks merged by rank.  A second, persistent 512-thread kernel for the long lists cost a
+        // 4.5 us launch in EVERY iteration to find nothing to do (kernels in a replayed graph cost ~4 us each whatever they compute).
         { ProfileScope ps(ST_TILE_SORT, stream);
           hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 256, 0>), dim3(n_local), dim3(256), 0, stream, n_local, (const uint32_t*)nullptr, order, ranges,
                              (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
