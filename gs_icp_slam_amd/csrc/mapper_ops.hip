@@ -555,6 +555,13 @@ __global__ __launch_bounds__(256) void rows_move_kernel(int P, const int* __rest
         if (PACK) *flag = (*n_vis > row_capacity || (guard_count && *guard_count > guard_limit)) ? 1.f : 0.f;
         else if (overflow_out) *overflow_out = *flag > 0.f ? 1u : 0u;      // after the all-reduce: some rank overflowed
     }
+    if (PACK) {   // rows behind the visible count are never read back, but they ARE summed in place by every all-reduce: keep them zero
+        const int nv = *n_vis;
+        for (long long z = (long long)nv + i; z < row_capacity; z += (long long)gridDim.x * 256) {
+            float* __restrict__ zr = packed + (size_t)z * t.row_floats;
+            for (int c = 0; c < t.row_floats; ++c) zr[c] = 0.f;
+        }
+    }
     const bool k = i < P && radii[i] > 0;
     const unsigned long long b = __ballot(k);
     if (lane == 0) s_w[wave] = (unsigned)__popcll(b);

@@ -317,7 +317,7 @@ int gsicp_store_compact(int n, const unsigned char* keep, int n_arrays, const vo
  *     with radii > 0; gsicp_rows_pack copies those rows of n_arrays (<= 8) row-major (P, row_width[a]) float arrays, in ascending
  *     Gaussian order, into packed[row_capacity][sum of widths] and sets the flag word packed[row_capacity * sum] to 1.0 when this
  *     rank overflowed (more visible rows than row_capacity, or *guard_count > guard_limit — the rasteriser's duplicate count and
- *     capacity), else 0.0.  All-reduce (sum) the row_capacity * sum + 1 floats; gsicp_rows_unpack writes the summed rows back in
+ *     capacity), else 0.0.  Rows behind the visible count are zeroed.  All-reduce (sum) the row_capacity * sum + 1 floats; gsicp_rows_unpack writes the summed rows back in
  *     place (rows with radii <= 0 are left alone: their gradient is exactly zero on every rank) and *overflow_out = 1 when ANY rank
  *     flagged an overflow (pass it to gsicp_adam_step_guarded with guard_limit 0 so every rank skips the same step), else 0.
  *     `scratch` (gsicp_rows_pack_scratch_bytes(P)) carries the scan of pack to unpack.  src / dst / row_width are HOST arrays.

@@ -78,7 +78,10 @@ def test_row_movers_sum_the_visible_rows_of_emulated_ranks_and_flag_overflow(hip
             ptrs = (ctypes.c_void_p * len(widths))(*[x.data_ptr() for x in arrays[r]])
             _lib.check(lib.gsicp_rows_pack(P, _p(radii), len(widths), ptrs, cw, _p(pk), R, _p(count), guard_limit, _p(scratch), _stream()), "pack")
             packed.append(pk)
-        return torch.nan_to_num(torch.stack(packed), nan=0.0).sum(0)     # rows behind n_vis are never written: the sum ignores them
+        stacked = torch.stack(packed)
+        if R > n_vis:      # rows behind the visible count are zeroed by the pack (they are summed in place by every all-reduce)
+            assert not bool(torch.isnan(stacked[:, n_vis * Wt: R * Wt]).any()) and not bool(stacked[:, n_vis * Wt: R * Wt].any())
+        return torch.nan_to_num(stacked, nan=0.0).sum(0)
 
     R = n_vis + 11
     total = exchange(R, 100)
