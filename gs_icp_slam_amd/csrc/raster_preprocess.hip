@@ -354,6 +354,24 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     float gs[NGRAD];
 #pragma unroll
     for (int c = 0; c < NGRAD; ++c) gs[c] = 0.f;
+    // Everything a visible Gaussian needs later is requested NOW, together with the first records of its run: the kernel is one residency
+    // wave of threads, so its duration is the length of one thread's chain of dependent memory latencies (radii -> run bounds -> records ->
+    // splat record -> parameters -> SH); issuing the independent ones side by side shortens that chain by two hops.
+    SplatRec r_early;
+    r_early.px = r_early.py = r_early.depth = r_early.hx = r_early.ca = r_early.cb = r_early.cc = r_early.opacity = 0.f;
+    r_early.r = r_early.g = r_early.b = r_early.hy = 0.f;
+    float p_early[3] = {0.f, 0.f, 0.f}, sc_early[3] = {1.f, 1.f, 1.f}, q_early[4] = {0.f, 0.f, 0.f, 1.f};
+    if (visible) {
+        r_early = a.rec[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p_early[k] = a.means3D[3 * i + k];
+        if (!a.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sc_early[k] = a.scales[3 * i + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q_early[k] = a.rotations[4 * i + k];
+        }
+    }
     {
         const uint32_t n_slots = (!visible || *a.total_counter > a.capacity) ? 0u : a.tiles_touched[i];
         const float4* es = (const float4*)a.entry_sum + 3 * (size_t)a.slot_base[i];
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     // gs = moment sums of h = G dL/dalpha over every pixel this Gaussian blends: [h dx, h dy, h dx dx, h dx dy, h dy dy, h, ...]
     // (blend_backward_tile_kernel); the per-Gaussian constants turn them into the screen-space gradients
     if (visible) {
-        const SplatRec r = a.rec[i];
+        const SplatRec r = r_early;
         const float hx = gs[0], hy = gs[1], hxx = gs[2], hxy = gs[3], hyy = gs[4];
         gs[0] = r.opacity * (-hx * r.ca - hy * r.cb) * (0.5f * (float)a.W);
         gs[1] = r.opacity * (-hy * r.cc - hx * r.cb) * (0.5f * (float)a.H);
@@ -389,14 +407,14 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     }
     a.dL_dmean2D[3 * i] = gs[0]; a.dL_dmean2D[3 * i + 1] = gs[1]; a.dL_dmean2D[3 * i + 2] = 0.f;
     a.dL_dconic[4 * i] = gs[2]; a.dL_dconic[4 * i + 1] = gs[3]; a.dL_dconic[4 * i + 2] = gs[4]; a.dL_dconic[4 * i + 3] = 0.f;
-    a.dL_dopacity[i] = (a.raw_params && visible) ? gs[5] * a.rec[i].opacity * (1.f - a.rec[i].opacity) : gs[5];   // sigmoid' = o (1 - o)
+    a.dL_dopacity[i] = (a.raw_params && visible) ? gs[5] * r_early.opacity * (1.f - r_early.opacity) : gs[5];   // sigmoid' = o (1 - o)
     a.dL_dcolors[3 * i] = gs[6]; a.dL_dcolors[3 * i + 1] = gs[7]; a.dL_dcolors[3 * i + 2] = gs[8];
     a.dL_ddepths[i] = gs[9];
     if (visible) {
         Cam cam;
         load_cam(a.view, a.proj, cam);
         const float fx = (float)a.W / (2.f * a.tanfovx), fy = (float)a.H / (2.f * a.tanfovy);
-        const float p[3] = {a.means3D[3 * i], a.means3D[3 * i + 1], a.means3D[3 * i + 2]};
+        const float p[3] = {p_early[0], p_early[1], p_early[2]};
         float c6[6];
         float q[4] = {0.f, 0.f, 0.f, 1.f}, sc[3] = {1.f, 1.f, 1.f};
         float q_raw[4] = {0.f, 0.f, 0.f, 1.f}, q_norm = 1.f;
@@ -405,9 +423,9 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
             for (int k = 0; k < 6; ++k) c6[k] = a.cov3D_precomp[6 * i + k];
         } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) sc[k] = a.scales[3 * i + k];
+            for (int k = 0; k < 3; ++k) sc[k] = sc_early[k];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = a.rotations[4 * i + k];
+            for (int k = 0; k < 4; ++k) q[k] = q_early[k];
             if (a.raw_params) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) sc[k] = expf(sc[k]);
