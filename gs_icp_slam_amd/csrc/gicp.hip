@@ -804,9 +804,37 @@ __global__ __launch_bounds__(64) void cov_eig_kernel(int n, int k, const float4*
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= n) return;
     const int kk = k < n ? k : n;
+    double mu[3] = {0, 0, 0};
+    double raw[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+    if (kk <= 32) {
+        // k <= 32 (the reference uses 20): the whole neighbour row lives in registers.  Distances, indices and then ALL point gathers are issued
+        // side by side — three memory latencies for the thread instead of one or two per group of four neighbours, twice over (this kernel is
+        // one wave per SIMD: its duration IS the thread's chain of dependent latencies).  Sums in rank order: bit-identical to the general path.
+        const float* drow = nbr_d2 + (size_t)q * 64;
+        const int* irow = nbr_idx + (size_t)q * 64;
+        float d[32];
+        int id[32];
+        float4 P[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { d[u] = u < kk ? drow[u] : FLT_MAX; id[u] = irow[u < kk ? u : 0]; }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) P[u] = pts[id[u]];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) if (u < kk && u == cnt && d[u] <= max_d2) ++cnt;   // stops counting at the first neighbour beyond the radius
+#pragma unroll
+        for (int u = 0; u < 32; ++u) if (u < cnt) { mu[0] += (double)P[u].x; mu[1] += (double)P[u].y; mu[2] += (double)P[u].z; }
+        mu[0] /= cnt; mu[1] /= cnt; mu[2] /= cnt;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            if (u < cnt) {
+                const double dx = (double)P[u].x - mu[0], dy = (double)P[u].y - mu[1], dz = (double)P[u].z - mu[2];
+                raw[0] += dx * dx; raw[1] += dx * dy; raw[2] += dx * dz; raw[3] += dy * dy; raw[4] += dy * dz; raw[5] += dz * dz;
+            }
+        }
+    } else {
     // how many of the (distance-sorted) neighbours lie inside the k-NN radius: the row is scanned with independent loads first, so that the
     // point gathers below are not serialised behind a data-dependent exit
-    int cnt = 0;
     {
         const float* drow = nbr_d2 + (size_t)q * 64;
         for (int j = 0; j < kk; j += 4) {
@@ -819,7 +847,6 @@ __global__ __launch_bounds__(64) void cov_eig_kernel(int n, int k, const float4*
     }
     const int* irow = nbr_idx + (size_t)q * 64;
     // four gathers in flight per trip; the additions keep the rank order (bit-identical to the one-at-a-time loop and to the oracle)
-    double mu[3] = {0, 0, 0};
     for (int j = 0; j < cnt; j += 4) {
         float4 p[4];
 #pragma unroll
@@ -828,7 +855,6 @@ __global__ __launch_bounds__(64) void cov_eig_kernel(int n, int k, const float4*
         for (int u = 0; u < 4; ++u) if (j + u < cnt) { mu[0] += (double)p[u].x; mu[1] += (double)p[u].y; mu[2] += (double)p[u].z; }
     }
     mu[0] /= cnt; mu[1] /= cnt; mu[2] /= cnt;
-    double raw[6] = {0, 0, 0, 0, 0, 0};
     for (int j = 0; j < cnt; j += 4) {
         float4 p[4];
 #pragma unroll
@@ -841,6 +867,7 @@ __global__ __launch_bounds__(64) void cov_eig_kernel(int n, int k, const float4*
             }
         }
     }
+    }   // general path (k > 32)
 #pragma unroll
     for (int d = 0; d < 6; ++d) raw[d] /= cnt;
     double ev[3], V[9], qd[4], out6[6];
