@@ -428,11 +428,28 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
     __shared__ KnnGrid s_g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    // A depth frame's cloud (<= KNN_KEEP * 1024 points) stays in registers across the three passes: one trip to memory instead of three
+    constexpr int KNN_KEEP = 12;
+    const bool keep = n <= KNN_KEEP * 1024;
+    float4 kept[KNN_KEEP];
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KNN_KEEP; ++u) { const int i = tid + u * 1024; kept[u] = pts[i < n ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < KNN_KEEP; ++u) {
+            if (tid + u * 1024 < n) {
+                const float4 p = kept[u];
+                lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+                hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+            }
+        }
+    } else {
 #pragma unroll 4
-    for (int i = tid; i < n; i += 1024) {   // (unrolled: the loads of several trips are in flight together — each pass is a chain of n / 1024 latencies otherwise)
-        const float4 p = pts[i];
-        lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
-        hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+        for (int i = tid; i < n; i += 1024) {   // (unrolled: the loads of several trips are in flight together — each pass is a chain of n / 1024 latencies otherwise)
+            const float4 p = pts[i];
+            lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+            hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+        }
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -476,14 +493,28 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
     unsigned* cnt = in_lds ? s_cnt : cell_count;
     for (int c = tid; c < ncells; c += 1024) cnt[c] = 0u;
     __syncthreads();
+    int kept_cell[KNN_KEEP];
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KNN_KEEP; ++u) {
+            kept_cell[u] = 0;
+            if (tid + u * 1024 < n) {
+                int cx, cy, cz;
+                knn_cell_of(g, kept[u].x, kept[u].y, kept[u].z, cx, cy, cz);
+                kept_cell[u] = (cz * g.ny + cy) * g.nx + cx;
+                atomicAdd(&cnt[kept_cell[u]], 1u);
+            }
+        }
+    } else {
 #pragma unroll 4
-    for (int i = tid; i < n; i += 1024) {
-        const float4 p = pts[i];
-        int cx, cy, cz;
-        knn_cell_of(g, p.x, p.y, p.z, cx, cy, cz);
-        const int c = (cz * g.ny + cy) * g.nx + cx;
-        cell_of[i] = c;
-        atomicAdd(&cnt[c], 1u);
+        for (int i = tid; i < n; i += 1024) {
+            const float4 p = pts[i];
+            int cx, cy, cz;
+            knn_cell_of(g, p.x, p.y, p.z, cx, cy, cz);
+            const int c = (cz * g.ny + cy) * g.nx + cx;
+            cell_of[i] = c;
+            atomicAdd(&cnt[c], 1u);
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -515,11 +546,23 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
     if (tid == 1023) cell_start[ncells] = total_all;
     __threadfence_block();
     __syncthreads();
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < KNN_KEEP; ++u) {
+            const int i = tid + u * 1024;
+            if (i < n) {
+                float4 p = kept[u];
+                p.w = __int_as_float(i);
+                sorted[atomicAdd(&cur[kept_cell[u]], 1u)] = p;
+            }
+        }
+    } else {
 #pragma unroll 4
-    for (int i = tid; i < n; i += 1024) {
-        float4 p = pts[i];
-        p.w = __int_as_float(i);
-        sorted[atomicAdd(&cur[cell_of[i]], 1u)] = p;
+        for (int i = tid; i < n; i += 1024) {
+            float4 p = pts[i];
+            p.w = __int_as_float(i);
+            sorted[atomicAdd(&cur[cell_of[i]], 1u)] = p;
+        }
     }
 }
 
