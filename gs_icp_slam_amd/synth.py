@@ -111,7 +111,11 @@ DEFAULT_POSE_A = se3((12.0, 28.0, 0.0), (-0.9, -0.2, -1.1))
 
 
 def checker_colors(points_w):
-    c = (np.floor(points_w * 4.0).astype(np.int64).sum(-1) & 1).astype(np.float32)
+    """25 cm 3-D checker + a smooth tint.  The lattice is offset by 0.31 cells: every wall and cuboid face of the analytic room lies on a
+    multiple of 0.1 m, i.e. ON a lattice plane of an un-offset checker (x = 3.0 -> floor(12.0 +- 1e-15)), where the cell parity of a
+    ray-cast hit point is decided by its last rounding bit — that was salt-and-pepper noise of +-0.3 on half the pixels of rounds 1-2's
+    synthetic images and capped every PSNR measured on them at ~18 dB (profiles/r03_map_quality.md)."""
+    c = (np.floor(points_w * 4.0 + 0.31).astype(np.int64).sum(-1) & 1).astype(np.float32)
     base = 0.25 + 0.5 * c[:, None]
     tint = 0.5 + 0.5 * np.sin(points_w * np.array([1.3, 2.1, 0.7]))
     return np.clip(base * 0.6 + 0.4 * tint, 0, 1).astype(np.float32)

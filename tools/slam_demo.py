@@ -42,6 +42,15 @@ def main():
     ap.add_argument("--keyframe-freq", type=int, default=10)
     ap.add_argument("--capacity", type=int, default=400_000, help="map capacity in Gaussians")
     ap.add_argument("--list-capacity", type=int, default=1 << 22, help="duplicate-list capacity of the sync-free rasteriser")
+    ap.add_argument("--eval-every", type=int, default=0, help="map-quality checkpoint every this many mapper iterations: PSNR / SSIM of the map "
+                    "rendered at the ESTIMATED poses of the frames tracked so far, computed the way the reference's end-of-run pass does "
+                    "[REF mp_Mapper.py:335-420]")
+    ap.add_argument("--eval-stride", type=int, default=8, help="checkpoints evaluate every this-many-th tracked frame (the final one: every frame)")
+    ap.add_argument("--post-iters", type=int, default=0, help="keep mapping on random keyframes for this many iterations after the last frame (shows the plateau)")
+    ap.add_argument("--scale-semantics", choices=["stddev", "variance"], default="stddev")
+    ap.add_argument("--json", default=None, help="write the run summary and the quality curve here")
+    ap.add_argument("--no-asserts", action="store_true")
+    ap.add_argument("--dump", default=None, help="directory for side-by-side (ground truth | render | accumulated alpha) PNGs of a few frames at the final checkpoint")
     args = ap.parse_args()
 
     import torch
@@ -88,6 +97,8 @@ def main():
     reg = pygicp.FastGICP()
     reg.set_max_correspondence_distance(cfg["max_corr"])
     reg.set_max_knn_distance(99999.0)
+    if args.scale_semantics != "stddev":
+        reg.set_scale_semantics(args.scale_semantics)
 
     # ------------------------------------------------------------------------------------------ frame 0
     d16_dev, rgb_dev = upload(0)
@@ -138,6 +149,77 @@ def main():
                 prunes += 1
                 print(f"    prune at iteration {train_iter}: {before} -> {store.n} Gaussians (same buffers, same graph)")
 
+    # ---- map quality the way the reference's end-of-run pass measures it [REF mp_Mapper.py:335-420]: render the map at the ESTIMATED pose of a
+    # frame, clamp to [0,1], mask both images with gt depth > 0, PSNR = -10 log10(mean squared error), SSIM with the reference's window
+    from gs_icp_slam_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from gs_icp_slam_amd.loss import mapper_loss_and_grads
+    est_poses = {0: poses[0].copy()}
+    curve = []
+
+    def evaluate(frame_ids, dump_ids=()):
+        ps, ss, l1d = [], [], []
+        with torch.no_grad():
+            a = dict(means3D=store.live("xyz"), shs=store.live("f_dc"), opacities=torch.sigmoid(store.live("opacity")),
+                     scales=torch.exp(store.live("scaling")), rotations=torch.nn.functional.normalize(store.live("rotation")))
+            for k in frame_ids:
+                cam = synth.make_camera(W, H, cfg["fx"], cfg["fy"], est_poses[k])
+                rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                                                   bg=torch.zeros(3, device=dev), scale_modifier=1.0,
+                                                   viewmatrix=torch.from_numpy(cam["viewmatrix"]).to(dev),
+                                                   projmatrix=torch.from_numpy(cam["projmatrix"]).to(dev), sh_degree=0,
+                                                   campos=torch.from_numpy(cam["campos"]).to(dev), prefiltered=False, debug=False)
+                depth, color, _r, _u = GaussianRasterizer(rs)(means3D=a["means3D"], means2D=torch.zeros_like(a["means3D"]), shs=a["shs"],
+                                                             opacities=a["opacities"], scales=a["scales"], rotations=a["rotations"])
+                d16_k, rgb_k = upload(k)
+                gt = (rgb_k.permute(2, 0, 1).float() / 255.0)
+                gtd = (d16_k.view(torch.int16).to(torch.int32).bitwise_and(0xFFFF).float() / np.float32(cfg["depth_scale"]))[None]
+                mask = gtd > 0
+                ours, gt = torch.clamp(color, 0.0, 1.0) * mask, gt * mask
+                ps.append(float(-10.0 * torch.log10(torch.mean((gt - ours) ** 2))))
+                parts, _gc, _gd = mapper_loss_and_grads(ours.contiguous(), depth.contiguous(), gt.contiguous(), gtd.contiguous())
+                ss.append(float(parts[2]))
+                l1d.append(float(torch.abs(depth - gtd)[mask].mean()))
+                if dump_ids and k in dump_ids:
+                    from PIL import Image
+                    _d2, acc, _r2, _u2 = GaussianRasterizer(rs)(means3D=a["means3D"], means2D=torch.zeros_like(a["means3D"]),
+                                                               colors_precomp=torch.ones_like(a["means3D"]), opacities=a["opacities"],
+                                                               scales=a["scales"], rotations=a["rotations"])
+                    row = torch.cat([gt, ours, acc.clamp(0, 1)], dim=2)[:, ::2, ::2]
+                    os.makedirs(args.dump, exist_ok=True)
+                    Image.fromarray((row.permute(1, 2, 0) * 255).byte().cpu().numpy(), "RGB").save(os.path.join(args.dump, f"frame{k:04d}_it{train_iter}.png"))
+        return dict(psnr=float(np.mean(ps)), psnr_min=float(np.min(ps)), ssim=float(np.mean(ss)), depth_l1_m=float(np.mean(l1d)), frames=len(ps))
+
+    def checkpoint(final=False):
+        ids = sorted(est_poses)
+        if not final:
+            ids = ids[:: max(1, args.eval_stride)]
+        q = evaluate(ids, dump_ids=(ids[0], ids[len(ids) // 2], ids[-1]) if (final and args.dump) else ())
+        if final:
+            with torch.no_grad():
+                op, sc = torch.sigmoid(store.live("opacity")).reshape(-1), torch.exp(store.live("scaling"))
+                qs = torch.tensor([0.05, 0.5, 0.95], device=dev)
+                q["opacity_quantiles_5_50_95"] = [float(v) for v in torch.quantile(op[:: max(1, op.numel() // 200000)], qs)]
+                q["max_scale_m_quantiles_5_50_95"] = [float(v) for v in torch.quantile(sc.max(dim=1).values[:: max(1, op.numel() // 200000)], qs)]
+                q["min_scale_m_quantiles_5_50_95"] = [float(v) for v in torch.quantile(sc.min(dim=1).values[:: max(1, op.numel() // 200000)], qs)]
+        q.update(iteration=train_iter, frames_tracked=len(est_poses), gaussians=store.n, keyframes=len(keyframes), final=final)
+        curve.append(q)
+        print(f"    quality at iteration {train_iter} ({len(est_poses)} frames tracked, {store.n} Gaussians): PSNR {q['psnr']:.2f} dB "
+              f"(worst frame {q['psnr_min']:.2f}), SSIM {q['ssim']:.3f}, depth L1 {1e3 * q['depth_l1_m']:.1f} mm over {q['frames']} frames")
+
+    _map_some_plain = map_some
+
+    def map_some(n):   # noqa: F811 — the same loop, cut at the checkpoints
+        if args.eval_every <= 0:
+            return _map_some_plain(n)
+        while n > 0:
+            m = min(n, args.eval_every - train_iter % args.eval_every)
+            _map_some_plain(m)
+            n -= m
+            if train_iter % args.eval_every == 0:
+                checkpoint()
+
+    if args.eval_every > 0:
+        checkpoint()
     map_some(20)
     print(f"frame 0: {pw.shape[0]} points -> {store.n} Gaussians; first losses {losses[:1]}")
 
@@ -157,6 +239,7 @@ def main():
         worst = (max(worst[0], ang), max(worst[1], mm))
         ratio, new_idx = overlap_statistics(torch.from_numpy(d2), 5e-4, 5e-5)
         pose_est = np.asarray(T, np.float64)
+        est_poses[k] = pose_est.copy()
         tracking_kf = k >= args.frames - 1 or ratio < args.keyframe_th
         since_tracking_kf = 0 if tracking_kf else since_tracking_kf + 1
         mapping_kf = (not tracking_kf) and since_tracking_kf % args.keyframe_freq == 0
@@ -191,6 +274,11 @@ def main():
         print(line)
     torch.cuda.synchronize()
     t_loop = time.perf_counter() - t_loop
+    if args.post_iters > 0:
+        map_some(args.post_iters)
+        torch.cuda.synchronize()
+    if args.eval_every > 0:
+        checkpoint(final=True)
     assert not mg.overflowed(), "duplicate-list capacity too small"
     recaptures = captures - 1 + (0 if mg.graph is graph_obj else 1)
     print(f"losses every 25 iterations: {[round(x, 4) for x in losses]}")
@@ -198,6 +286,18 @@ def main():
           f"{store.n} Gaussians, graph captures {captures}, re-captures {recaptures}, skipped optimiser steps {mg.skipped_steps()}")
     print(f"worst pose error {worst[0]:.4f} deg / {worst[1]:.3f} mm; loop wall {t_loop:.2f} s = {(args.frames - 1) / t_loop:.1f} frames/s "
           f"with {args.iters} mapper iterations per frame (frame maker before the loop: {t_gen:.1f} s)")
+    if args.json:
+        import json
+        with open(args.json, "w") as fh:
+            json.dump(dict(frames=args.frames, iters_per_frame=args.iters, post_iters=args.post_iters, prune_every=args.prune_every,
+                           scale_semantics=args.scale_semantics, tracking_keyframes=n_track_kf, mapping_keyframes=n_map_kf, prunes=prunes,
+                           mapper_iterations=train_iter, gaussians=store.n, graph_captures=captures, recaptures=recaptures,
+                           skipped_steps=mg.skipped_steps(), worst_pose_error_deg_mm=[worst[0], worst[1]], loop_wall_s=t_loop,
+                           losses_every_25=losses, quality_curve=curve, data="synthetic analytic room, Replica-shaped 1200x680, noise-free",
+                           note="PSNR / SSIM as [REF mp_Mapper.py:335-420] computes them (estimated poses, gt-depth mask); mapper = one captured "
+                                "hipGraph per iteration (render_3 + l1/ssim/depth loss + Adam with the reference's learning rates)"), fh, indent=1)
+    if args.no_asserts:
+        return
     assert recaptures == 0, "the mapper graph had to be re-captured"
     assert worst[0] < 0.05 and worst[1] < 1.5, "tracking drifted"
     if len(losses) >= 4:
