@@ -66,6 +66,20 @@ def _torch_ssim(img, gt, window):
     return (((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
 
 
+def _spawn_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver: RCCL needs it
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,8 +100,30 @@ def main():
     ap.add_argument("--only", choices=["tracker", "mapper"], default=None, help="diagnostics: run only one half (the JSON line is then NOT the contract metric)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it (the contract's plain form): start the N ranks ourselves — one process per
+    # GPU under torch.distributed.run on 127.0.0.1 with a free port — and pass their output through (rank 0 prints the one JSON line).  Under
+    # torchrun (WORLD_SIZE set) this is skipped and the environment decides.  GSICP_BENCH_BACKEND=gloo runs the N ranks on however many GPUs
+    # the box has (functional rehearsal of the N > 1 path on a 1-GPU box).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _spawn_ranks(args.gpus)
+
     import torch
     import torch.distributed as dist
+    if os.environ.get("GSICP_BENCH_SPAWN_PROBE") == "1":
+        # launcher rehearsal (tests/test_bench_cli.py, no GPU needed): join a gloo group, report who is there, stop before any device work
+        w, r = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        seen = [(r, os.getpid())]
+        if w > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=r, world_size=w)
+            got = [None] * w
+            dist.all_gather_object(got, (r, os.getpid()))
+            seen = got
+            dist.destroy_process_group()
+        if r == 0:
+            print(json.dumps({"spawn_probe": True, "n_gpus": w, "requested_gpus": args.gpus, "ranks": [s_[0] for s_ in seen],
+                              "distinct_processes": len({s_[1] for s_ in seen}), "steps": args.steps, "warmup": args.warmup}))
+        return 0
     from gs_icp_slam_amd import _lib, synth
     from gs_icp_slam_amd.activations import activate
     from gs_icp_slam_amd.loss import mapper_loss_and_grads
@@ -657,4 +693,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -179,6 +179,7 @@ class GaussianStore:
         lib = _lib.load()
         if self.n == 0:
             return self.params
+        n_old = self.n
         keep = (~remove_mask.reshape(-1)[: self.n].to(device=self.device, dtype=torch.bool)).contiguous().view(torch.uint8)
         src, dst = self._sets[self._cur], self._sets[self._cur ^ 1]
         keys = list(src.keys())
@@ -208,6 +209,15 @@ class GaussianStore:
                 for k in keys:
                     if src[k][0].numel() > 0 and self.n > 0:
                         src[k][: self.n].copy_(dst[k][: self.n])
+                # the freed tail [n_new, n_old) still holds copies of old Gaussians; a consumer that ignores `live_count` (torch.optim.Adam,
+                # a custom rasteriser factory, a checkpoint written from `params` instead of `live()`) would render / update them.  Make them
+                # inert: opacity far below every threshold (sigmoid(-30) = 1e-13 < 1/255: culled by the rasteriser), moments zero.
+                if n_old > self.n:
+                    src[("p", "opacity")][self.n:n_old].fill_(-30.0)
+                    for name in PARAM_NAMES:
+                        if src[("m", name)][0].numel() > 0:
+                            src[("m", name)][self.n:n_old].zero_()
+                            src[("v", name)][self.n:n_old].zero_()
             return self.params
         self._cur ^= 1
         self._rebind()

@@ -9,8 +9,10 @@ once (`torch.cuda.CUDAGraph`, i.e. hipGraph) and replayed with one launch per it
 What changes from iteration to iteration in the reference — the keyframe: camera matrices and the two target images —
 lives in static device buffers that `set_view()` overwrites before `step()`.  Everything with a fixed address (parameters,
 Adam state, learning rates, step count) is updated in place by the replay.  The graph is valid while the parameter tensors
-are the ones captured: after the map grows or is pruned (new parameter tensors, [REF scene/gaussian_model.py:409-492]) build
-a new MapperIterationGraph — capture costs about three eager iterations of time but applies NO optimiser update (warm-up is rolled back).
+are the ones captured.  Over a `GaussianStore(stable=True)` (full-capacity buffers, live count on the device: pass `live_count=`) that is the
+WHOLE RUN — keyframe growth and pruning change no pointer and no launch grid, so nothing is ever re-captured.  Over reference-style storage
+(new parameter tensors after every append / prune [REF scene/gaussian_model.py:409-492]) build a new MapperIterationGraph after each change —
+capture costs about three eager iterations of time but applies NO optimiser update (warm-up is rolled back).
 
 Several GPUs: pass `rasterizer_factory=lambda rs: ShardedGaussianRasterizer(rs, vis_capacity=R)` (sharded.py).  Its two RCCL collectives
 have static sizes and are captured with everything else; the overflow guard then is the all-reduced flag, identical on every rank.
@@ -76,8 +78,6 @@ class MapperIterationGraph:
         # live_count[0] rows are Gaussians.  Growth and pruning then change that number and rows in place — no pointer, shape or launch grid
         # of the captured iteration changes, so ONE capture serves the whole run [REF mp_Mapper.py:161-195, 244-245 append / prune].
         self.live_count = live_count
-        if live_count is not None:
-            optimizer.set_live_rows(live_count)
         self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
         self._warmup = int(warmup)
         # device-side overflow guard: a replay whose duplicate count exceeds the capacity renders nothing; the Adam kernels
@@ -90,7 +90,11 @@ class MapperIterationGraph:
         shared_guard = self.rasterizer.overflow_guard() if hasattr(self.rasterizer, "overflow_guard") else None
         if shared_guard is not None:     # tile-sharded across GPUs (sharded.py, static exchange): 1 when ANY rank overflowed, so all ranks skip alike
             self._guard_count, self._guard_limit = shared_guard
-        optimizer.set_overflow_guard(self._guard_count, self._guard_limit)
+        # The guard and the live-row count are bound to the optimiser only WHILE this graph's launches are issued (capture(), warm-up included)
+        # and what was bound before is restored afterwards: an eager step() on the same optimiser later is gated by whatever ITS
+        # caller bound (GaussianStore.attach binds the store's live count), not by the count the last replay happened to leave behind.
+        if optimizer.skipped_steps is None or optimizer.skipped_steps.device != self._guard_count.device:
+            optimizer.skipped_steps = torch.zeros(1, dtype=torch.int32, device=self._guard_count.device)
         # screen-space gradient holder [REF gaussian_renderer/__init__.py:227]: the reference makes a fresh zero tensor per call;
         # its VALUE is never read by the rasteriser, so one static tensor serves every replay
         self._means2D = torch.zeros_like(params["means3D"], requires_grad=True)
@@ -147,11 +151,12 @@ class MapperIterationGraph:
         but are NOT optimiser steps of the caller's schedule: parameters, both moments and the step counters are snapshotted before and
         restored after, so capturing (and re-capturing after the map changed) applies zero updates — the reference performs exactly one
         update per loop iteration [REF mp_Mapper.py:219-248]."""
+        with self.optimizer.scoped_bindings(guard=(self._guard_count, self._guard_limit), live_rows=self.live_count):
+            return self._capture()   # the launches captured inside read THIS graph's count / limit / live rows
+
+    def _capture(self):
         dev = self.params["means3D"].device
         self.optimizer.zero_grad(set_to_none=True)
-        self.optimizer.set_overflow_guard(self._guard_count, self._guard_limit)   # the launches captured below read THIS graph's count / limit
-        if self.live_count is not None:
-            self.optimizer.set_live_rows(self.live_count)
         snap_p = {k: v.detach().clone() for k, v in self.params.items()}
         snap_s = {}
         for p in self.params.values():

@@ -28,6 +28,25 @@ class FusedAdam(torch.optim.Optimizer):
         self.skipped_steps = None   # device int32[1], sticky: steps skipped by the guard since construction (read it whenever convenient)
         self._live_rows = None      # device int32[1]: parameters are capacity-backed, only this many leading rows are updated
 
+    def scoped_bindings(self, guard=None, live_rows=None):
+        """Context manager: bind an overflow guard and / or a live-row count for the launches issued inside (a graph capture), then restore
+        what was bound before — so that eager steps on the same optimiser afterwards are not silently gated by a graph's last replay."""
+        opt = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.prev = (opt._guard, opt._live_rows)
+                if guard is not None:
+                    opt.set_overflow_guard(*guard)
+                if live_rows is not None:
+                    opt.set_live_rows(live_rows)
+                return opt
+
+            def __exit__(self_, *exc):
+                opt._guard, opt._live_rows = self_.prev
+                return False
+        return _Scope()
+
     def set_live_rows(self, n_dev):
         """Capturable path: the parameter tensors are the full-capacity buffers of a preallocated map (GaussianStore); update only the
         first n_dev[0] rows of each.  n_dev changes on the device (append / prune) without any pointer or launch changing."""
@@ -121,9 +140,10 @@ class FusedAdam(torch.optim.Optimizer):
                 _lib.check(lib.gsicp_adam_step_guarded(n, P, G, M, V, N, ctypes.c_void_p(lr_dev.data_ptr()), b1, b2, eps,
                                                        ctypes.c_void_p(items[0][5].data_ptr()), int(last_of[sp] == li), guard_ptr, guard_lim,
                                                        skip_ptr, live_ptr, RW, stream), "gsicp_adam_step_guarded")
-        if not capturing:
-            for key in [k for k in self._lr_dev if k not in live_keys]:
-                del self._lr_dev[key]
+        # Device lr arrays are NEVER freed: a captured MapperIterationGraph holds their addresses, and an eager step() that happens
+        # to see fewer gradients (zero_grad(set_to_none=True), different chunking) must not hand that memory back to the caching allocator
+        # while a graph may still replay.  One entry is <= 8 doubles; the number of distinct buckets an optimiser ever sees is a handful.
+        del live_keys
 
     @torch.no_grad()
     def step(self, closure=None):

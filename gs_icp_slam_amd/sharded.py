@@ -134,6 +134,14 @@ def _static_exchange_cuda(grads, radii, holder, group):
         _lib.check(lib.gsicp_rows_unpack(P, _p(radii), len(grads), ptrs, holder.c_widths, _p(holder.packed), R, _p(holder.scratch),
                                          _p(holder.overflow), _stream(dev)), "gsicp_rows_unpack")
     holder.last_volume_bytes = holder.packed.numel() * 4
+    # Nobody asked for overflow_guard() (e.g. eager use with torch.optim.Adam, or a graph built before the guard was wired): an overflowing
+    # rank's rows beyond R stayed rank-local and the replicas would drift apart silently.  Outside capture that is checked here
+    # — one 4-byte read-back per backward, only on this unguarded eager path — and refused loudly.
+    if not holder.guard_requested and not torch.cuda.is_current_stream_capturing():
+        if int(holder.overflow.item()) != 0:
+            raise RuntimeError(f"ShardedGaussianRasterizer: static gradient exchange overflowed (visible rows > vis_capacity = {R}, or a rank's "
+                               "duplicate lists overflowed) and no overflow guard is bound to the optimiser: use FusedAdam.set_overflow_guard("
+                               "*rasterizer.overflow_guard()) / MapperIterationGraph, or raise vis_capacity, or use compact_grads=True")
 
 
 def _static_exchange_torch(grads, radii, holder, group):
@@ -229,6 +237,7 @@ class _Holder:
     table = None
     vis_capacity = 0
     guard = None          # (int32[1] device tensor: this rank's duplicate count, its capacity) or None
+    guard_requested = False   # overflow_guard() was handed out: the caller's optimiser skips overflowing steps on all ranks alike
     static_key = None
     packed = scratch = overflow = c_widths = None
 
@@ -262,6 +271,7 @@ class ShardedGaussianRasterizer(nn.Module):
         otherwise (the caller then guards on this rank's own duplicate count)."""
         if not (self.collective and self.holder.vis_capacity):
             return None
+        self.holder.guard_requested = True
         if self.holder.overflow is None:
             dev = self.raster_settings.viewmatrix.device
             self.holder.overflow = torch.zeros(1, dtype=torch.int32, device=dev)

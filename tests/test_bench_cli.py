@@ -19,3 +19,27 @@ def test_scripts_the_bench_and_the_capture_depend_on_compile():
     for rel in ("bench.py", "__graft_entry__.py", "tools/rccl_graph_probe.py", "tools/collect_profiles.py", "tools/tracker_latency.py",
                 "tools/run_reference_slam.py", "tools/slam_demo.py"):
         py_compile.compile(os.path.join(ROOT, rel), doraise=True)
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2 ...` — the driver's plain form — must start two ranks by itself (it silently ran one).  The probe
+    mode stops each rank after the rendezvous, before any device work, so this runs without a GPU."""
+    import json
+    env = dict(os.environ, GSICP_BENCH_SPAWN_PROBE="1", GSICP_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks"] == [0, 1] and res["distinct_processes"] == 2 and res["steps"] == 3 and res["warmup"] == 1
+
+
+def test_under_torchrun_the_environment_decides_and_nothing_is_respawned():
+    import json
+    env = dict(os.environ, GSICP_BENCH_SPAWN_PROBE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 1 and res["distinct_processes"] == 1

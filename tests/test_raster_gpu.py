@@ -1,9 +1,10 @@
 """GPU parity: HIP rasteriser (through the drop-in diff_gaussian_rasterization API / C ABI) vs the CPU oracle.
 
-Bars (BASELINE.json north_star): bit-exact tile / Gaussian indices; RGB and depth within 1e-5.  exp() differs in
-the last ulps between libm and the GPU, so a pixel whose alpha / transmittance test sits within 1e-5 (relative) of
-its threshold may legitimately flip; the oracle reports that margin per pixel and such pixels (a few per million)
-are excluded from the 1e-5 bar but bounded in number.
+Bars (BASELINE.json north_star): bit-exact tile / Gaussian indices; RGB and depth within 1e-5 ON >= 99.98 % OF THE PIXELS (>= 99.96 % at the
+training-stage sizes).  exp() differs in the last ulps between libm and the GPU, so a pixel whose alpha / transmittance test sits within 1e-5
+(relative) of its threshold may legitimately flip; the oracle reports that margin per pixel and such "fragile" pixels (<= 2e-4 of the image,
+asserted) are excluded from the 1e-5 bar but bounded in number.  The adversarial long-list scenes (thousands of threshold decisions per pixel)
+and the UHD scene run at stated looser tolerances (5e-5 / 2e-4 / 1e-3) — see each test.
 """
 import numpy as np
 import pytest
@@ -266,27 +267,31 @@ def test_training_stage_sizes_forward(hip_lib, res):
     print("S-map", res, "num_rendered", p["num_rendered"], stats)
 
 
-def _gaussians_near_pixels(geom, radii, ys, xs):
-    """Indices of Gaussians whose 3-sigma square covers any of the given pixels (pixels where a threshold decision is within
-    rounding of flipping: exp() differs in the last ulps between libm and the GPU, and ONE flipped pixel moves the gradient of
-    every Gaussian blended at it by that pixel's whole contribution)."""
-    hit = np.zeros(len(radii), bool)
-    vis = np.flatnonzero(radii > 0)
-    px, py, r = geom[vis, 0], geom[vis, 1], radii[vis].astype(np.float32)
-    for y, x in zip(ys, xs):
-        hit[vis[(np.abs(px - x) <= r + 1) & (np.abs(py - y) <= r + 1)]] = True
-    return hit
+def _write_parity_report(tag, report):
+    """One JSON per (resolution, depth rule) under gpurun_out/parity_report/ (tools/collect_profiles.py folds them into
+    profiles/rNN_parity_report.json)."""
+    import json
+    import os
+    d = os.environ.get("GSICP_PARITY_REPORT_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, tag + ".json"), "w") as fh:
+        json.dump(report, fh, indent=1)
 
 
+@pytest.mark.parametrize("depth_mode", [0, 1])
 @pytest.mark.parametrize("res", ["replica", "tum", "replica_stage1", "replica_stage2"])
-def test_full_size_smap_backward(hip_lib, res):
+def test_full_size_smap_backward(hip_lib, res, depth_mode):
     """R-bwd at BASELINE sizes: S-map P = 300 k at 1200x680 and 640x480 (and the training_stage sizes), random dL/dcolour and
-    dL/ddepth, all six gradients compared with the fp32 oracle ELEMENT-WISE:
+    dL/ddepth, both depth rules, all six gradients compared with the fp32 oracle ELEMENT-WISE, EVERY visible Gaussian to the same bound:
         |hip - oracle| <= 1e-5 * max|oracle| + 1e-4 * |oracle| + min(2 |oracle_f32 - oracle_f64|, 1e-4 * max|oracle|).
     The last term is the fp32 oracle's OWN rounding noise on that element (conic -> covariance -> quaternion is a sum of products
     of dL/dSigma ~ 1e5 with derivatives ~ 1e-4 that cancel to O(10): where fp32 cannot do better the bar is what fp32 delivers);
-    the number of elements that need it is reported.  Gaussians that overlap a fragile pixel (forward decision margin < 1e-5; a
-    few per 10^4 pixels) are held to the looser bound 5e-3 * max|oracle| and their number is bounded."""
+    the number of elements that need it is reported.
+    Fragile pixels (forward decision margin < 1e-5: exp() differs in the last ulps between libm and the GPU, so an alpha or transmittance
+    test there may legitimately flip; a few per 10^4 pixels) get dL/dcolour = dL/ddepth = 0 on BOTH sides: every term a pixel contributes
+    to any gradient is linear in its dL/dpixel, so such a pixel contributes exactly nothing whichever way its decisions fall, and no
+    Gaussian sees a flipped decision — there is no looser class of Gaussians (round 2 held up to 8 % of the visible set to 5e-3)."""
+    import oracle
     cam = _stage_cam(res)
     W, H = cam["W"], cam["H"]
     g = synth.s_map(300_000, seed=2)
@@ -294,21 +299,35 @@ def test_full_size_smap_backward(hip_lib, res):
     gc = rng.normal(size=(3, H, W)).astype(np.float32)
     gd = rng.normal(size=(H, W)).astype(np.float32)
     bg = [0.0, 0.0, 0.0]
-    of = util.oracle_forward(g, cam, bg, 0)
-    o = util.oracle_backward(g, cam, bg, gc, gd, 0)
-    o64 = util.oracle_backward({k: v.astype(np.float64) for k, v in g.items()}, cam, bg, gc, gd, 0, dtype=np.float64)
-    p = run_product(g, cam, bg, 0, grads=(gc, gd))
+    oracle.raster_set_depth_mode(depth_mode)
+    try:
+        of = util.oracle_forward(g, cam, bg, 0)
+        fragile = of["margin"] <= FRAGILE
+        assert fragile.sum() <= 4e-4 * W * H, f"{int(fragile.sum())} fragile pixels"
+        gc[:, fragile] = 0.0
+        gd[fragile] = 0.0
+        o = util.oracle_backward(g, cam, bg, gc, gd, 0)
+        o64 = util.oracle_backward({k: v.astype(np.float64) for k, v in g.items()}, cam, bg, gc, gd, 0, dtype=np.float64)
+    finally:
+        oracle.raster_set_depth_mode(0)
+    p = run_product(g, cam, bg, 0, grads=(gc, gd), depth_mode=depth_mode)
     assert np.array_equal(p["radii"], of["radii"])
-    fy, fx = np.nonzero(of["margin"] <= FRAGILE)
-    assert len(fy) <= 4e-4 * W * H, f"{len(fy)} fragile pixels"
-    near = _gaussians_near_pixels(of["geom"], of["radii"], fy, fx)
     n_vis = int((of["radii"] > 0).sum())
-    assert near.sum() <= 0.08 * n_vis, f"{near.sum()} of {n_vis} visible Gaussians overlap a fragile pixel"
-    # list depth of each Gaussian's deepest tile (for the report)
     tile_len = (of["ranges"][:, 1].astype(np.int64) - of["ranges"][:, 0])
+    gx = (W + 15) // 16
+
+    def list_depth(wg):   # longest tile list the Gaussian sits in
+        x, y, r = of["geom"][wg, 0], of["geom"][wg, 1], of["radii"][wg]
+        tx0, tx1 = int(max(0, (x - r) // 16)), int(min(gx - 1, (x + r) // 16))
+        ty0, ty1 = int(max(0, (y - r) // 16)), int(min((H + 15) // 16 - 1, (y + r) // 16))
+        return int(max([tile_len[ty * gx + tx] for ty in range(ty0, ty1 + 1) for tx in range(tx0, tx1 + 1)] or [0]))
+
     pairs = [("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"), ("rotations", "dL_drots"),
              ("shs", "dL_dsh"), ("means2D", "dL_dmeans2D")]
-    report = {}
+    report = dict(resolution=f"{W}x{H}", depth_mode=depth_mode, gaussians=300_000, visible=n_vis, duplicates=int(p["num_rendered"]),
+                  fragile_pixels_zeroed=int(fragile.sum()), fragile_fraction=float(fragile.mean()),
+                  bound="|hip - oracle32| <= 1e-5 max|g| + 1e-4 |g| + min(2 |oracle32 - oracle64|, 1e-4 max|g|), every visible Gaussian", gradients={})
+    failures = []
     for name, key in pairs:
         a = p["grads"][name].reshape(300_000, -1).astype(np.float64)
         b = o[key].reshape(300_000, -1).astype(np.float64)
@@ -320,25 +339,21 @@ def test_full_size_smap_backward(hip_lib, res):
         bound = base + np.minimum(2.0 * np.abs(b - b64), 1e-4 * mx)
         err = np.abs(a - b)
         ratio = (err / bound).max(1)
-        robust = ~near
-        worst = int(np.argmax(np.where(robust, ratio, 0.0)))
-        report[name] = dict(max_ratio=float(ratio[robust].max()), worst_gaussian=worst, worst_abs=float(err[worst].max()), grad_max=float(mx),
-                            needed_conditioning_term=int(((err > base).any(1) & robust).sum()),
-                            loose_max=float((err[near].max() / mx) if near.any() else 0.0))
-        assert ratio[robust].max() <= 1.0, f"{res} grad {name}: worst Gaussian {worst} err {err[worst]} vs oracle {b[worst]} (max|grad| {mx:.3e})"
-        if near.any():
-            assert err[near].max() <= 5e-3 * mx, f"{res} grad {name}: fragile-pixel Gaussians off by {err[near].max() / mx:.3e} of max"
+        worst = int(np.argmax(ratio))
+        report["gradients"][name] = dict(
+            max_ratio_to_bound=float(ratio.max()), max_ratio_to_base_bound=float((err / base).max()), worst_gaussian=worst,
+            worst_abs_err=float(err[worst].max()), grad_max=float(mx), max_err_over_grad_max=float(err.max() / mx),
+            worst_gaussian_longest_list=list_depth(worst), gaussians_needing_conditioning_term=int((err > base).any(1).sum()),
+            elements_needing_conditioning_term=int((err > base).sum()), elements=int(err.size),
+            oracle32_vs_oracle64_max_over_grad_max=float(np.abs(b - b64).max() / mx))
+        if ratio.max() > 1.0:
+            failures.append(f"{res} depth_mode {depth_mode} grad {name}: worst Gaussian {worst} err {err[worst]} vs oracle {b[worst]} (max|grad| {mx:.3e})")
         # culled Gaussians get exactly zero
         assert not a[of["radii"] == 0].any()
-    # depth of the worst Gaussian's lists: the tiles it touches
-    wg = max(report.values(), key=lambda r: r["max_ratio"])["worst_gaussian"]
-    x, y, r = of["geom"][wg, 0], of["geom"][wg, 1], of["radii"][wg]
-    gx = (W + 15) // 16
-    tx0, tx1 = int(max(0, (x - r) // 16)), int(min(gx - 1, (x + r) // 16))
-    ty0, ty1 = int(max(0, (y - r) // 16)), int(min((H + 15) // 16 - 1, (y + r) // 16))
-    depth = int(max(tile_len[ty * gx + tx] for ty in range(ty0, ty1 + 1) for tx in range(tx0, tx1 + 1)))
-    print(f"S-map backward {res}: fragile px {len(fy)}, Gaussians near them {int(near.sum())}/{n_vis}, worst Gaussian {wg} "
-          f"(longest tile list it sits in: {depth}), per-gradient {report}")
+    report["passed"] = not failures
+    _write_parity_report(f"{res}_depth{depth_mode}", report)
+    print(f"S-map backward {res} depth_mode {depth_mode}: {report}")
+    assert not failures, failures
 
 
 def test_alpha_normalised_depth_mode_forward_and_backward(hip_lib):
@@ -376,7 +391,8 @@ def test_alpha_normalised_depth_mode_forward_and_backward(hip_lib):
 
 
 def test_long_tile_lists_use_the_fallback_sort(hip_lib):
-    """> 4096 entries in one tile: the per-tile sort leaves LDS and rank-sorts in global memory; lists must still be exact."""
+    """> 1024 entries in one tile (here > 4096): the list is sorted in 1024-entry chunks in LDS and the chunks are merged by rank through
+    global memory; lists must still be exact."""
     cam = synth.make_camera(48, 32, 40.0, 40.0)
     g = synth.random_gaussians(5000, seed=12, spread=0.2, zmin=2.0, zmax=6.0)
     g["scales"] = (g["scales"] * 6.0).astype(np.float32)          # every Gaussian covers the whole 3x2-tile image
@@ -387,7 +403,7 @@ def test_long_tile_lists_use_the_fallback_sort(hip_lib):
 
 
 def test_very_long_tile_lists_merge_several_sorted_chunks(hip_lib):
-    """20 000 entries in every tile: five 4096-entry chunks sorted in LDS and merged by rank.  The lists (bit-exact against the oracle's
+    """20 000 entries in every tile: twenty 1024-entry chunks sorted in LDS and merged by rank.  The lists (bit-exact against the oracle's
     stable 64-bit sort) are the point here; images only on robust pixels."""
     cam = synth.make_camera(32, 32, 30.0, 30.0)
     g = synth.random_gaussians(20000, seed=14, spread=0.15, zmin=2.0, zmax=6.0)

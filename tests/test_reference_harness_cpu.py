@@ -92,3 +92,67 @@ def test_numpy1_shim_restores_what_the_reference_relies_on():
             "print('shim ok')\n")
     r = subprocess.run([sys.executable, "-W", "ignore", "-c", code], env=dict(os.environ, PYTHONPATH=STUBS), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "shim ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_tum_layout_is_read_by_the_references_own_tum_loader(tmp_path):
+    """The reference's TUM branch — TrajManager('tum', ...) -> tum_load_poses -> parse_list (np.unicode_) -> associate_frames
+    [REF utils/traj_utils.py:63-137] — executed UNMODIFIED (byte-code) on a synthetic sequence in TUM's on-disk layout: every frame is
+    kept (30 Hz > 1/32 s), each frame is associated with its own depth image and its own ground-truth sample (not one of the in-between
+    100 Hz samples), and the poses come back as written."""
+    ref = _reference_dir()
+    sys.path.insert(0, ROOT)
+    from tools.make_synth_dataset import write_dataset, tum_stamp
+    out = str(tmp_path / "tumseq")
+    cfg, poses = write_dataset(out, frames=4, shape="tum", layout="tum")
+    assert sorted(os.listdir(out)) == ["caminfo.txt", "depth", "depth.txt", "groundtruth.txt", "rgb", "rgb.txt"]
+    assert open(os.path.join(out, "caminfo.txt")).readlines()[2].split()[8] == "tum"
+    code = ("import sys, json; sys.path.insert(0, %r)\n"
+            "from utils.traj_utils import TrajManager\n"
+            "tm = TrajManager('tum', %r)\n"
+            "print('RESULT ' + json.dumps(dict(poses=tm.gt_poses.tolist(), color=tm.color_paths, depth=tm.depth_paths)))\n") % (ref, out)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, STUBS]), MPLBACKEND="Agg")
+    r = subprocess.run([sys.executable, "-W", "ignore", "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert [os.path.basename(p) for p in got["color"]] == [tum_stamp(i) + ".png" for i in range(4)]
+    assert [os.path.basename(p) for p in got["depth"]] == [tum_stamp(i, 0.011) + ".png" for i in range(4)]
+    np.testing.assert_allclose(np.array(got["poses"]), np.stack(poses), rtol=0, atol=2e-8)      # %.9f text + quaternion round trip
+    sys.path.insert(0, STUBS)
+    try:
+        import cv2
+        import open3d as o3d
+        from gs_icp_slam_amd import synth
+        rgb = cv2.imread(got["color"][1])                                            # [REF mp_Tracker.py:355]
+        depth = np.array(o3d.io.read_image(got["depth"][1]))                         # [REF mp_Tracker.py:356]
+    finally:
+        sys.path.remove(STUBS)
+        for name in ("cv2", "open3d", "open3d.io"):
+            sys.modules.pop(name, None)
+    want_rgb, want_d16 = synth.render_frame(cfg, poses[1])
+    assert np.array_equal(depth, want_d16) and np.array_equal(rgb[..., ::-1], want_rgb)     # PNG: lossless
+
+
+def test_flag_sets_follow_the_dataset_not_the_harness_mode(tmp_path):
+    """A REAL TUM path gets tum.sh's flags [REF tum.sh:135-142], a Replica path replica.sh's [REF replica.sh:135-142]."""
+    sys.path.insert(0, ROOT)
+    from tools import run_reference_slam as h
+    tum_cfg, rep_cfg = tmp_path / "tum.txt", tmp_path / "rep.txt"
+    tum_cfg.write_text("## camera parameters\nW H fx fy cx cy depth_scale depth_trunc dataset_type\n640 480 517.3 516.5 318.6 255.3 5000.0 3.0 tum\n")
+    rep_cfg.write_text("## camera parameters\nW H fx fy cx cy depth_scale depth_trunc dataset_type\n1200 680 600.0 600.0 599.5 339.5 6553.5 12.0 replica\n")
+    assert h.flags_for(str(tum_cfg)) == dict(keyframe_th=0.81, knn_maxd=99999.0, overlapped_th=1e-3, max_correspondence_distance=0.03,
+                                             trackable_opacity_th=0.09, overlapped_th2=1e-3, downsample_rate=5)
+    assert h.flags_for(str(rep_cfg)) == dict(keyframe_th=0.7, knn_maxd=99999.0, overlapped_th=5e-4, max_correspondence_distance=0.02,
+                                             trackable_opacity_th=0.05, overlapped_th2=5e-5, downsample_rate=10)
+    assert h.flags_for(str(rep_cfg), shape="tum") == h.TUM_FLAGS       # TUM-shaped sensor written in Replica's layout
+
+
+def test_subset_of_a_cached_sequence_is_the_sequence_prefix(tmp_path):
+    sys.path.insert(0, ROOT)
+    from tools.make_synth_dataset import write_dataset, subset_dataset
+    full, part = str(tmp_path / "full"), str(tmp_path / "part")
+    write_dataset(full, frames=3, shape="tum")
+    subset_dataset(full, 2, part)
+    assert sorted(os.listdir(os.path.join(part, "images"))) == ["frame000000.jpg", "frame000001.jpg"]
+    assert len(open(os.path.join(part, "traj.txt")).readlines()) == 2
+    assert open(os.path.join(part, "images", "frame000001.jpg"), "rb").read() == open(os.path.join(full, "images", "frame000001.jpg"), "rb").read()

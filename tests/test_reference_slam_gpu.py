@@ -42,7 +42,10 @@ def test_untouched_reference_two_process_run_replica_shaped():
     assert res["psnr"] is not None and res["psnr"] > 5.0       # a few seconds of mapping only: the number just has to be produced
 
 
-def test_untouched_reference_two_process_run_tum_shaped():
+def test_untouched_reference_two_process_run_tum_layout_and_flags():
+    """The reference's TUM branch end to end: dataset tag `tum`, rgb/ depth/ rgb.txt depth.txt groundtruth.txt read by its own association
+    loader [REF utils/traj_utils.py:63-137; mp_Tracker.py:353-359], the flags of tum.sh [REF tum.sh:135-142], sensor-noise model + 15 % holes."""
     res = _run(["--synthetic", "20", "--shape", "tum", "--noise"])
+    assert res["dataset_type"] == "tum" and res["flags"]["trackable_opacity_th"] == 0.09 and res["flags"]["overlapped_th2"] == 1e-3
     assert res["processes_that_loaded_it"] >= 3
     assert res["ate_rmse_cm"] < 6.0     # sensor-noise model with 15 % holes; the real fr1_desk figure of the paper is 2.7 cm

@@ -11,5 +11,7 @@ REF=${GSICP_REFERENCE:-/root/reference}
 for scene in room0 office0; do
   python "$HERE/tools/run_reference_slam.py" --dataset "$DATA/Replica/$scene" --config "$REF/configs/Replica/caminfo.txt" --timeout 3600
 done
-# TUM: utils/traj_utils.py uses np.unicode_, removed in NumPy 2 — needs numpy<2 on the run box, the file is not edited
+# TUM: the harness reads the dataset type off the config's third line and passes tum.sh's flags [REF tum.sh:135-142]; utils/traj_utils.py uses
+# np.unicode_ (removed in NumPy 2), which tests/refstubs/sitecustomize.py restores by environment — the file is not edited.  The
+# reference's TUM loader branch is exercised on a synthetic TUM-layout sequence by tests/test_reference_slam_gpu.py.
 python "$HERE/tools/run_reference_slam.py" --dataset "$DATA/TUM/rgbd_dataset_freiburg1_desk" --config "$REF/configs/TUM/rgbd_dataset_freiburg1_desk.txt" --timeout 3600

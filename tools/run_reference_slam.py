@@ -32,14 +32,34 @@ def find_reference(explicit=None):
     return None
 
 
+# the flag sets the reference's own launch scripts pass
+REPLICA_FLAGS = dict(keyframe_th=0.7, knn_maxd=99999.0, overlapped_th=5e-4, max_correspondence_distance=0.02, trackable_opacity_th=0.05,
+                     overlapped_th2=5e-5, downsample_rate=10)      # [REF replica.sh:135-142; replica_unlimit.sh:135-142]
+TUM_FLAGS = dict(keyframe_th=0.81, knn_maxd=99999.0, overlapped_th=1e-3, max_correspondence_distance=0.03, trackable_opacity_th=0.09,
+                 overlapped_th2=1e-3, downsample_rate=5)           # [REF tum.sh:135-142; tum_unlimit.sh]
+
+
+def dataset_type(config):
+    """`replica` / `tum`: the ninth token of the camera config's third line — what the reference itself branches on [REF gs_icp_slam.py:52-72]."""
+    try:
+        with open(config) as fh:
+            return fh.readlines()[2].split()[8].strip().lower()
+    except Exception:
+        return "replica"
+
+
+def flags_for(config, shape=None):
+    """Flags by the DATASET (a real fr1_desk path gets tum.sh's flags, not Replica's).  A TUM-shaped sequence written in Replica's layout
+    (`--shape tum --layout replica`) still gets tum.sh's flags: they belong to the sensor (640x480, stride 5, 3 cm gate), not to the file layout."""
+    return dict(TUM_FLAGS if (dataset_type(config) == "tum" or shape == "tum") else REPLICA_FLAGS)
+
+
 def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_flags=(), flags=None, trace_dir=None, omp_threads=1):
     name = "gs_icp_slam_unlimit" if unlimit else "gs_icp_slam"
     script = os.path.join(reference, name + ".py")
     if not os.path.exists(script):
         script += "c"
-    # the flags replica.sh / replica_unlimit.sh pass [REF replica.sh:135-142]
-    f = dict(keyframe_th=0.7, knn_maxd=99999.0, overlapped_th=5e-4, max_correspondence_distance=0.02, trackable_opacity_th=0.05,
-             overlapped_th2=5e-5, downsample_rate=10)
+    f = flags_for(config)
     f.update(flags or {})
     cmd = [sys.executable, "-W", "ignore", script, "--dataset_path", dataset, "--config", config, "--output_path", output]
     for k, v in f.items():
@@ -60,6 +80,8 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
         env.setdefault("OMP_NUM_THREADS", str(omp_threads))
         env.setdefault("MKL_NUM_THREADS", str(omp_threads))
     if trace_dir:
+        trace_dir = os.path.abspath(trace_dir)     # the reference runs with its own tree as working directory
+        os.makedirs(trace_dir, exist_ok=True)
         env["GSICP_CALL_TRACE"] = trace_dir
     t0 = time.time()
     p = subprocess.Popen(cmd, cwd=reference, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
@@ -89,6 +111,10 @@ def main():
     ap.add_argument("--output", default=None)
     ap.add_argument("--synthetic", type=int, default=0, help="write and use a synthetic Replica-layout sequence of this many frames")
     ap.add_argument("--shape", choices=["replica", "tum"], default="replica")
+    ap.add_argument("--layout", choices=["replica", "tum"], default=None, help="on-disk layout of the synthetic sequence (default: the shape's own; "
+                    "`tum` = rgb/ depth/ rgb.txt depth.txt groundtruth.txt and dataset tag `tum`, the reference's TUM loader branch)")
+    ap.add_argument("--cache", default=None, help="directory that keeps synthetic sequences between runs: a run of N frames re-uses (symlinks) the "
+                    "first N frames of a longer cached sequence of the same kind instead of ray-casting again")
     ap.add_argument("--noise", action="store_true")
     ap.add_argument("--limit30", action="store_true", help="run gs_icp_slam.py (tracker capped at 30 FPS [REF mp_Tracker.py:323]) instead of the _unlimit variant")
     ap.add_argument("--timeout", type=float, default=600.0)
@@ -105,11 +131,25 @@ def main():
     if a.synthetic > 0:
         sys.path.insert(0, ROOT)
         from tools.make_synth_dataset import write_dataset
+        from tools.make_synth_dataset import subset_dataset
+        layout = a.layout or a.shape
         tmp = tempfile.mkdtemp(prefix="gsicp_synth_")
-        cfg, _ = write_dataset(tmp, a.synthetic, a.shape, a.noise)
+        cached = None
+        if a.cache and layout == "replica":
+            kind = f"{a.shape}_{'noisy' if a.noise else 'clean'}_"
+            os.makedirs(a.cache, exist_ok=True)
+            have = sorted((int(d[len(kind):]), d) for d in os.listdir(a.cache) if d.startswith(kind) and d[len(kind):].isdigit())
+            fit = [d for n, d in have if n >= a.synthetic]
+            if fit:
+                cached = os.path.join(a.cache, fit[0])
+            else:
+                cached = os.path.join(a.cache, kind + str(a.synthetic))
+                write_dataset(cached, a.synthetic, a.shape, a.noise, layout=layout)
+            subset_dataset(cached, a.synthetic, tmp)
+        else:
+            write_dataset(tmp, a.synthetic, a.shape, a.noise, layout=layout)
         a.dataset, a.config = tmp, os.path.join(tmp, "caminfo.txt")
-        if a.shape == "tum":   # [REF tum.sh:135-142]
-            flags = dict(keyframe_th=0.81, overlapped_th=1e-3, max_correspondence_distance=0.03, overlapped_th2=1e-4, downsample_rate=5)
+        flags = flags_for(a.config, a.shape)
     if not a.dataset or not os.path.isdir(a.dataset):
         print(json.dumps({"status": "not measured", "why": f"dataset {a.dataset!r} not present on this machine"}))
         return 0
@@ -118,7 +158,8 @@ def main():
     out_dir = a.output or tempfile.mkdtemp(prefix="gsicp_out_")
     res, log = run(ref, a.dataset, a.config, out_dir, unlimit=not a.limit30, timeout=a.timeout, flags=flags, trace_dir=a.trace, omp_threads=a.omp_threads)
     res.update(status="measured" if res["returncode"] == 0 and res["system_fps"] is not None else "failed", dataset=a.dataset,
-               data="synthetic" if a.synthetic else "real", frames=a.synthetic or None)
+               data="synthetic" if a.synthetic else "real", frames=a.synthetic or None, dataset_type=dataset_type(a.config),
+               flags=flags or flags_for(a.config), entry="gs_icp_slam.py (30 FPS cap)" if a.limit30 else "gs_icp_slam_unlimit.py")
     if a.log:
         with open(a.log, "w") as fh:
             fh.write(log)
