@@ -430,7 +430,7 @@ def main():
         b_r7 = 44.0 * D_local + 40.0 * WHr + 44.0 * P_vis                       # blend backward (R7)
         b_bwd = b_r7 + 184.0 * P                                                # + R8/R9
         b_fwd = 128.0 * P + D_local * (64.0 + 24.0 * n_pass) + 24.0 * WHr + 8.0 * Tr
-        fwd_stages = ["preprocess", "emit", "split_hist", "split_colscan", "tile_scan_lpt", "split_scatter", "tile_sort_long", "tile_sort", "blend_forward"]
+        fwd_stages = ["preprocess", "emit", "split_hist", "split_colscan", "tile_scan_lpt", "split_scatter", "tile_sort", "blend_forward"]
         bwd_stages = ["blend_backward", "preprocess_backward"]
         us_r7 = per_launch_us.get("blend_backward", float("nan"))
         us_bwd = sum(per_launch_us.get(k, 0.0) for k in bwd_stages)
@@ -443,12 +443,12 @@ def main():
         traffic, traffic_src, note = None, None, ("working set (~60 MB) sits in the 256 MiB Infinity Cache: the HBM fraction is a formality; the kernel runs "
                                                   "~80 % VALU-busy and tracks the per-entry dependent chain (DESIGN 3.3)")
         if world == 1 and args.res == "replica" and P == 300_000:
-            for tag in ("r02", "r01"):   # PMC passes of this command, collected by tools/capture_profiles.sh (counters cannot be read in-process)
+            for tag in ("r03", "r02", "r01"):   # PMC passes of this command, collected by tools/capture_profiles.sh (counters cannot be read in-process)
                 tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
                 if os.path.exists(tp):
                     tj = json.load(open(tp)).get("blend_backward")
                     if tj:
-                        traffic, traffic_src = int(tj["fetch_bytes"] + tj["write_bytes"]), f"profiles/{tag}_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command; not re-measured in this run)"
+                        traffic, traffic_src = int(tj["fetch_bytes"] + tj["write_bytes"]), f"profiles/{tag}_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command by tools/capture_profiles.sh; PMC counters cannot be read in-process, so this is the LAST CAPTURE, not this run)"
                     sq = os.path.join(ROOT, "profiles", f"{tag}_rocprofv3_pmc_sq.csv")
                     if os.path.exists(sq):
                         import csv
@@ -460,7 +460,7 @@ def main():
                                 break
                     break
         roofline = {"bound": "hbm", "kernel": "blend_backward_tile_kernel (R7)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "kernel_us": round(us_r7, 2),
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "traffic_last_capture": traffic, "traffic_source": traffic_src, "kernel_us": round(us_r7, 2),
                     "algorithmic_bytes": int(b_r7), "byte_model": "SURVEY 8(d): 44 D + 40 W H + 44 P_vis",
                     "design_bytes": int(design_bytes), "design_frac": round(gbs(design_bytes, us_r7) / HBM_PEAK_GBS, 5),
                     "whole_backward": {"algorithmic_bytes": int(b_bwd), "us": round(us_bwd, 2), "frac": round(gbs(b_bwd, us_bwd) / HBM_PEAK_GBS, 5),
@@ -682,6 +682,12 @@ def main():
             "render_bwd_ms_per_iter": round(sum(v for k, v in per_launch_us.items() if not k.startswith(("gicp", "loss_", "adam"))) / 1e3, 4),
             "loss_adam_ms_per_iter": round(sum(v for k, v in per_launch_us.items() if k.startswith(("loss_", "adam"))) / 1e3, 4),
             "tracker_align_kernel_us": stage_us.get("gicp_align"),
+            # the headline tracker workload is a THROUGHPUT workload: SURVEY 8(d)'s pair sits outside GICP's basin at Replica's 2 cm gate, the
+            # optimiser (HIP and oracle alike) converges to a wrong pose; the in-basin pair is legs.tracker_only_basin
+            "pose_error_deg_mm": [round(ang_mm[0], 4), round(ang_mm[1], 3)] if "T" in last else None,
+            "tracker_pose_is_the_true_motion": (bool(ang_mm[0] < 0.05 and ang_mm[1] < 1.0) if "T" in last else None),
+            # what the UNMODIFIED mp_Mapper.py:219-248 statements cost on the drop-in rasteriser (the headline needs the fused, captured iteration)
+            "dropin_reference_loop_ms_per_iteration": (legs or {}).get("dropin_reference_loop", {}).get("ms_per_iteration"),
             "stage_us_per_step": stage_us,
             "legs": legs, "roofline": roofline, "cpu_baseline": cpu,
         }

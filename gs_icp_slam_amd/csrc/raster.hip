@@ -48,11 +48,11 @@ std::vector<hipEvent_t> g_prof_pool;
 hipEvent_t g_prof_open[ST_COUNT];
 std::atomic<int> g_prof_enabled{0};
 // stage -> kernel: preprocess = preprocess_kernel; tile_scan_lpt = tile_scan_lpt_kernel; emit = emit_kernel; split_hist / split_colscan /
-// split_scatter = the three multi-split kernels; tile_sort = tile_sort_kernel (tile_sort_long: a second size class that no longer exists, never timed);
+// split_scatter = the three multi-split kernels; tile_sort = tile_sort_kernel;
 // blend_forward = blend_forward_strip_kernel; blend_backward = blend_backward_tile_kernel; preprocess_backward = preprocess_backward_kernel;
 // gicp_* = the tracker's call-level stages (several launches each); loss_pass1 / loss_pass2 = the two loss kernels (pass 1 includes the
 // one-workgroup reduce); adam = adam_tensor_kernel (+ the one-thread step bump)
-const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "emit", "split_hist", "split_colscan", "split_scatter", "tile_sort_long",
+const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "emit", "split_hist", "split_colscan", "split_scatter",
                                              "tile_sort", "blend_forward", "blend_backward", "preprocess_backward", "gicp_knn_cov",
                                              "gicp_grid_build", "gicp_align", "gicp_exact_nn", "loss_pass1", "loss_pass2", "adam"};
 hipEvent_t prof_event() {

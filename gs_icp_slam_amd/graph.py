@@ -43,7 +43,7 @@ def torch_activations(p, live_rows=None):
 class MapperIterationGraph:
     """params: dict of raw leaf tensors (means3D, shs, opacities, scales, rotations) with requires_grad;
     optimizer: FusedAdam(capturable=True) over them;  capacity: upper bound for the number of (Gaussian, tile) duplicates
-    (e.g. 1.5x the count of an eager forward; `overflowed()` tells when it was too small)."""
+    (e.g. 1.5x the count of an eager forward; `overflowed()` tells when it was too small, `ensure_capacity()` enlarges it and re-captures)."""
 
     def __init__(self, params, optimizer, image_height, image_width, tanfovx, tanfovy, sh_degree, capacity, bg=None, lambda_dssim=0.2,
                  depth_weight=0.1, d_max=10.0, activations=None, rasterizer_factory=None, warmup=2, live_count=None,
@@ -74,6 +74,9 @@ class MapperIterationGraph:
             viewmatrix=self.viewmatrix, projmatrix=self.projmatrix, sh_degree=int(sh_degree), campos=self.campos, prefiltered=False,
             debug=False, capacity=self.capacity, live_count=live_count, depth_mode=int(depth_mode), raw_params=fused)
         self._fused_activations = fused
+        self._rs, self._rasterizer_factory = rs, rasterizer_factory
+        self._skipped_seen = 0
+        self.regrowths = 0          # times ensure_capacity() had to enlarge the lists and re-capture
         # live_count (int32[1] device tensor): `params` are the FULL-CAPACITY buffers of a GaussianStore(stable=True) and only the first
         # live_count[0] rows are Gaussians.  Growth and pruning then change that number and rows in place — no pointer, shape or launch grid
         # of the captured iteration changes, so ONE capture serves the whole run [REF mp_Mapper.py:161-195, 244-245 append / prune].
@@ -212,6 +215,34 @@ class MapperIterationGraph:
         if self._guard_count is not self.num_rendered and int(self._guard_count.item()) > self._guard_limit:   # sharded: some rank overflowed
             return True
         return self.num_rendered is not None and int(self.num_rendered.item()) > self.capacity
+
+    def ensure_capacity(self, growth=1.5):
+        """Capacity auto-grow.  Call between replays whenever a host synchronisation is acceptable (e.g. once per
+        keyframe): if replays since the last call overflowed the duplicate lists — they rendered nothing and their optimiser steps were skipped
+        on the device, nothing drifted — the lists are enlarged to max(growth x capacity, 1.25 x the count that overflowed) and the iteration
+        is captured again over the same parameters and optimiser state.  Returns the number of optimiser steps lost since the last call, so
+        that the caller can repeat them.  With a tile-sharded rasteriser every rank sees the same all-reduced flag and grows alike."""
+        now = self.skipped_steps()
+        lost = now - self._skipped_seen
+        self._skipped_seen = now
+        if lost <= 0 and not self.overflowed():
+            return 0
+        need = int(self.num_rendered.item()) if self.num_rendered is not None else 0
+        self.capacity = max(int(self.capacity * growth) + 1, int(1.25 * need) + 4096)
+        self._rs = self._rs._replace(capacity=self.capacity)
+        dev = self.params["means3D"].device
+        self.rasterizer = self._rasterizer_factory(self._rs) if self._rasterizer_factory is not None else GaussianRasterizer(self._rs)
+        inner = self.rasterizer.inner if hasattr(self.rasterizer, "inner") else self.rasterizer
+        if getattr(inner, "num_rendered", None) is None:
+            inner.num_rendered = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._guard_count, self._guard_limit = inner.num_rendered, self.capacity
+        shared_guard = self.rasterizer.overflow_guard() if hasattr(self.rasterizer, "overflow_guard") else None
+        if shared_guard is not None:
+            self._guard_count, self._guard_limit = shared_guard
+        self.graph = None
+        self.capture()
+        self.regrowths += 1
+        return max(lost, 1)
 
     def skipped_steps(self):
         """Number of replays whose optimiser step the device-side overflow guard skipped so far (sticky counter; synchronises)."""

@@ -201,6 +201,59 @@ def test_overflowing_replay_skips_the_optimiser_step_on_the_device():
     for k, v in params.items():
         assert torch.equal(v, snap[k]), f"{k} moved on an overflowed replay"
         assert torch.equal(opt.state[v]["exp_avg"], snap_m[k]) and torch.equal(opt.state[v]["exp_avg_sq"], snap_v[k])
+    # capacity auto-grow: the host notices the skipped steps, the lists are enlarged, the iteration is re-captured over the same parameters
+    # and optimiser state (capturing applies no update), and the lost steps can be repeated
+    lost = small.ensure_capacity()
+    assert lost == 3 and small.regrowths == 1 and small.capacity >= R
+    for k, v in params.items():
+        assert torch.equal(v, snap[k]), f"{k} moved while re-capturing"
+    for _ in range(lost):
+        small.step()
+    assert not small.overflowed() and small.skipped_steps() == 3 and small.ensure_capacity() == 0 and small.regrowths == 1
+    assert int(opt.state[params["means3D"]]["step"].item()) == steps0 + 3
+    assert not torch.equal(params["means3D"], snap["means3D"])
+
+
+def test_eager_steps_after_a_capture_keep_lr_arrays_and_are_not_gated_by_the_graphs_guard():
+    """ADVICE r2: (i) an eager capturable step() that sees fewer gradients must not free device lr arrays a captured graph still reads;
+    (ii) the overflow guard / live-row count a graph binds are scoped to ITS launches — an eager step on the same optimiser afterwards is
+    not skipped because the graph's last replay overflowed."""
+    from gs_icp_slam_amd.graph import MapperIterationGraph
+    P, W, H = 6000, 160, 96
+    g, cam, params, opt = _mapper_setup(P, W, H, capturable=True)
+    rs = make_settings(cam, [0.0, 0.0, 0.0])
+    gt_c = torch.rand((3, H, W), device="cuda")
+    gt_d = torch.rand((1, H, W), device="cuda") + 1.0
+    mg = MapperIterationGraph(params, opt, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=2_000_000, warmup=1)
+    mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_c, gt_d)
+    mg.capture()
+    assert opt._guard is None and opt._live_rows is None        # nothing stays bound after capture()
+    lr_ptrs = {k: v[0].data_ptr() for k, v in opt._lr_dev.items()}
+    assert lr_ptrs
+    # an eager step where only ONE parameter has a gradient (different bucket) ...
+    for p_ in params.values():
+        p_.grad = None
+    params["opacities"].grad = torch.zeros_like(params["opacities"])
+    opt.step()
+    # ... must leave the graph's lr arrays alive and in place
+    assert all(k in opt._lr_dev and opt._lr_dev[k][0].data_ptr() == ptr for k, ptr in lr_ptrs.items())
+    before = params["means3D"].detach().clone()
+    mg.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(params["means3D"], before) and torch.isfinite(params["means3D"]).all()
+    # (ii) a tiny-capacity graph overflows on replay; an eager step afterwards still updates
+    tiny = MapperIterationGraph(params, opt, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=16, warmup=1)
+    tiny.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_c, gt_d)
+    tiny.capture()
+    tiny.step()
+    assert tiny.overflowed() and tiny.skipped_steps() >= 1
+    before = params["opacities"].detach().clone()
+    for p_ in params.values():
+        p_.grad = None
+    params["opacities"].grad = torch.ones_like(params["opacities"])
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(params["opacities"], before), "an eager step was gated by a graph's stale overflow count"
 
 
 def test_one_graph_per_training_stage_resolution_shares_parameters_and_optimiser():

@@ -271,6 +271,10 @@ def main():
             else:
                 n_map_kf += 1
         map_some(args.iters)
+        lost = mg.ensure_capacity()        # duplicate lists outgrown (steps were skipped on the device): enlarge, re-capture, repeat the lost steps
+        if lost:
+            line += f" | list capacity grown to {mg.capacity}, {lost} skipped iteration(s) repeated"
+            map_some(lost)
         print(line)
     torch.cuda.synchronize()
     t_loop = time.perf_counter() - t_loop
