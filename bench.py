@@ -98,6 +98,11 @@ def main():
                     "letting the two halves run their --steps steps at their own pace inside the timed block")
     ap.add_argument("--no-graph", action="store_true", help="drive the mapper iteration eagerly from Python instead of replaying the captured HIP graph")
     ap.add_argument("--only", choices=["tracker", "mapper"], default=None, help="diagnostics: run only one half (the JSON line is then NOT the contract metric)")
+    ap.add_argument("--mp-mode", choices=["tiles", "keyframes"], default="tiles",
+                    help="N > 1 GPUs: `tiles` (default) = ONE view per step, its screen tiles sharded over the ranks (same optimiser trajectory as 1 GPU: "
+                         "strong scaling); `keyframes` = every rank renders its OWN view, one dense gradient all-reduce, N views per optimiser step "
+                         "(SURVEY 8e's throughput alternative: NOT result-parity with the reference's one-view-per-step loop; weak scaling).  With "
+                         "`tiles` the keyframes mode is also timed, as legs.keyframe_parallel")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with N > 1 and no launcher around it (the contract's plain form): start the N ranks ourselves — one process per
@@ -128,7 +133,7 @@ def main():
     from gs_icp_slam_amd.activations import activate
     from gs_icp_slam_amd.loss import mapper_loss_and_grads
     from gs_icp_slam_amd.optim import FusedAdam
-    from gs_icp_slam_amd.sharded import ShardedGaussianRasterizer
+    from gs_icp_slam_amd.sharded import KeyframeParallelRasterizer, ShardedGaussianRasterizer
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     import pygicp
 
@@ -387,6 +392,92 @@ def main():
     if mg is None and int(rast.inner.num_rendered.item()) > capacity:
         raise RuntimeError("duplicate-list capacity overflowed during the timed region")
     align_stats = trk.reg.last_align_stats() if args.only != "mapper" else {}
+
+    # ---------------- N > 1: the throughput mode, data-parallel over keyframes (SURVEY 8e alternative), timed on ALL ranks ----------------
+    # Every rank renders ITS OWN view of the same map (full image, plain single-GPU rasteriser), one dense all-reduce sums the parameter
+    # gradients, the replicated optimiser takes one step per N views.  NOT result-parity with the reference's one-view-per-step loop.
+    kf_leg = None
+    if (world > 1 or force_coll) and (not args.no_legs or args.mp_mode == "keyframes") and args.only != "tracker":
+        from gs_icp_slam_amd.graph import MapperIterationGraph as _KMG
+        pose_r = synth.DEFAULT_POSE_A @ synth.se3((0.0, 3.0 * rank, 0.0), (0.03 * rank, 0.0, 0.0))
+        cam_r = synth.make_camera(W, H, cfg["fx"], cfg["fy"], pose_r)
+        rs_r = rs._replace(viewmatrix=torch.from_numpy(cam_r["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(cam_r["projmatrix"]).to(dev),
+                           campos=torch.from_numpy(cam_r["campos"]).to(dev))
+        with torch.no_grad():
+            g2 = synth.s_map(P, seed=2, perturb_seed=3)
+            t2 = {k: torch.from_numpy(g2[k]).to(dev) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+            gtd_r, gtc_r, _, _ = GaussianRasterizer(rs_r)(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"],
+                                                          opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
+            gtd_r, gtc_r = gtd_r.clone(), gtc_r.clone()
+            del t2
+            cap_k = max(8 * P, 1 << 20)
+            while True:
+                pr = GaussianRasterizer(rs_r._replace(capacity=cap_k))
+                a0 = activated()
+                pr(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"], scales=a0["scales"],
+                   rotations=a0["rotations"])
+                r_full = int(pr.num_rendered.item())
+                if r_full <= cap_k:
+                    break
+                cap_k *= 2
+            cap_k = int(1.5 * r_full) + 4096
+        opt_k = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in LRS.items()], lr=0.0, eps=1e-15, capturable=use_graph)
+        if use_graph:
+            mgk = _KMG(params, opt_k, H, W, cam_r["tanfovx"], cam_r["tanfovy"], sh_degree=0, capacity=cap_k, lambda_dssim=0.2, warmup=2,
+                       rasterizer_factory=lambda rs_: KeyframeParallelRasterizer(rs_, force_collectives=force_coll))
+            mgk.set_view(rs_r.viewmatrix, rs_r.projmatrix, rs_r.campos, gtc_r, gtd_r)
+            mgk.capture()
+            kf_holder = mgk.rasterizer.holder
+
+            def kf_iteration():
+                mgk.set_view(rs_r.viewmatrix, rs_r.projmatrix, rs_r.campos, gtc_r, gtd_r)
+                return mgk.step(), mgk.radii
+        else:
+            kf_rast = KeyframeParallelRasterizer(rs_r._replace(capacity=cap_k), force_collectives=force_coll)
+            kf_holder = kf_rast.holder
+
+            def kf_iteration():
+                a = activated()
+                means2D = torch.zeros_like(a["means3D"], requires_grad=True)
+                depth, color, radii, used = kf_rast(means3D=a["means3D"], means2D=means2D, shs=a["shs"], opacities=a["opacities"],
+                                                    scales=a["scales"], rotations=a["rotations"])
+                parts, g_color, g_depth = mapper_loss_and_grads(color, depth, gtc_r, gtd_r, lambda_dssim=0.2)
+                torch.autograd.backward((color, depth), (g_color, g_depth))
+                opt_k.step()
+                opt_k.zero_grad(set_to_none=True)
+                return parts[0], radii
+
+        def kf_step():
+            if worker is not None and args.only is None:
+                jobs.put(1)
+                kf_iteration()
+                done.get()
+            else:
+                if args.only is None:
+                    trk.step()
+                kf_iteration()
+
+        def kf_free_block(steps):
+            jobs.put(steps)
+            for _ in range(steps):
+                kf_iteration()
+            done.get()
+        for _ in range(max(3, args.warmup // 2)):
+            kf_step()
+        kf_blocks = timed_blocks(kf_step, args.steps, max(1, args.repeats), whole=kf_free_block if (free_running and args.only is None) else None)
+        dtk = statistics.median(kf_blocks)
+        if use_graph and (mgk.overflowed() or mgk.skipped_steps() > 0):
+            raise RuntimeError("keyframe-parallel leg: capacity overflowed during the timed region")
+        kf_leg = {"mode": "keyframes", "value": round(world * args.steps / dtk, 3), "unit": "frames/s (N tracker-frame replicas + N mapper views per step)",
+                  "views_per_step": world, "ms_per_step": round(1e3 * dtk / args.steps, 4), "scaling": "weak",
+                  "block_ms_per_step": [round(1e3 * b / args.steps, 4) for b in kf_blocks],
+                  "gradient_all_reduce_bytes_per_rank": kf_holder.last_volume_bytes, "duplicates_per_rank": r_full,
+                  "mapper_iteration": "one hipGraph replay per iteration (dense gradient all-reduce captured inside)" if use_graph else "eager launches from Python",
+                  "what": "data-parallel over keyframes: every rank renders its own view of the replicated map, one dense all-reduce(sum) of the 14 parameter-"
+                          "gradient floats per Gaussian + a flag word, replicated Adam step on the N views' summed loss; tracker replicas on every rank; "
+                          "NOT result-parity with the reference's one-view-per-step loop [REF mp_Mapper.py:200-206]"}
+        if use_graph:
+            del mgk
 
     # ---------------- per-kernel hipEvent times ----------------
     # kernels inside a replayed graph carry no HIP events: the SAME kernels on the same inputs are timed (one hipEvent bracket per kernel) in eager iterations right after the
@@ -652,16 +743,26 @@ def main():
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
+        headline_value, headline_scaling, headline_blocks = args.steps / dt, "strong", blocks
+        if kf_leg is not None:
+            legs = dict(legs or {})
+            if args.mp_mode == "keyframes":       # the throughput mode is the headline; the tile-sharded (parity) mode becomes the leg
+                legs["tile_sharded"] = {"mode": "tiles", "value": round(args.steps / dt, 3), "ms_per_step": round(ms, 4), "scaling": "strong",
+                                        "block_ms_per_step": [round(1e3 * b / args.steps, 4) for b in blocks]}
+                headline_value, headline_scaling, ms = kf_leg["value"], "weak", kf_leg["ms_per_step"]
+                headline_blocks = [1e-3 * b * args.steps for b in kf_leg["block_ms_per_step"]]
+            else:
+                legs["keyframe_parallel"] = kf_leg
         stage_us = {k: round(v, 2) for k, v in per_launch_us.items()}
         it = align_stats.get("iterations")
         ang_mm = trk.pose_error(last["T"]) if "T" in last else (None, None)
         out = {
             "metric": ("SLAM hot-path FPS (GICP tracker frame + one full mapper iteration: render, loss, backward, Adam), Replica room0-shaped synthetic"
                        if args.only is None else f"DIAGNOSTIC: {args.only} half only"),
-            "value": round(args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "value": round(headline_value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": headline_scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "repeats": len(blocks), "block_ms_per_step": [round(1e3 * b / args.steps, 4) for b in blocks], "statistic": "median block",
+            "repeats": len(headline_blocks), "block_ms_per_step": [round(1e3 * b / args.steps, 4) for b in headline_blocks], "statistic": "median block",
             "config": {"workload": f"BASELINE configs[2] shape: tracker frame on the {args.pair} S-pair {args.res} [{motions[args.pair]}; {len(trk.sp['points_b'])} pts, "
                                    f"gate {cfg['max_corr']} m, {it} LM iterations, lands {ang_mm[0]:.3f} deg / {ang_mm[1]:.1f} mm from the true motion] concurrent with one "
                                    f"S-map mapper iteration (P={P}, {W}x{H}, sh_degree 0, depth = sum z alpha T, fromqs scale^2)" if "T" in last else f"{args.only} only",
@@ -677,7 +778,11 @@ def main():
                                                     "gradient_all_reduce_block": mg.rasterizer.holder.last_volume_bytes}
                                                    if (mg is not None and (world > 1 or force_coll)) else None),
                        "variants": {"depth_mode": "sum z alpha T (un-normalised)", "fromqs_scale_mode": "s^2", "regularization": "PLANE"},
-                       "parallelism": "single GPU" if world == 1 else f"mapper tiles sharded x{world} (RCCL all-gather of own tiles + all-reduce of visible gradient rows), tracker replicated",
+                       "mp_mode": (args.mp_mode if (world > 1 or force_coll) else None),
+                       "parallelism": ("single GPU" if world == 1 else
+                                       (f"mapper tiles sharded x{world} (RCCL all-gather of own tiles + all-reduce of visible gradient rows), tracker replicated"
+                                        if args.mp_mode == "tiles" else
+                                        f"data-parallel over keyframes x{world} (every rank its own view, one dense RCCL gradient all-reduce per step), tracker replicated")),
                        "world_size": world, "backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen},
             "render_bwd_ms_per_iter": round(sum(v for k, v in per_launch_us.items() if not k.startswith(("gicp", "loss_", "adam"))) / 1e3, 4),
             "loss_adam_ms_per_iter": round(sum(v for k, v in per_launch_us.items() if k.startswith(("loss_", "adam"))) / 1e3, 4),

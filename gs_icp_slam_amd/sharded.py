@@ -24,7 +24,11 @@ Three ways to run the gradient exchange:
                                   overflowed, raises the flag; after the all-reduce every rank sees it in `overflow_guard()` and the
                                   capturable Adam skips that step on all ranks alike.
 
-The result equals the single-GPU rasteriser up to fp32 summation order in the gradient all-reduce.  `is_used` is not read by the
+A SECOND, throughput mode is `KeyframeParallelRasterizer` (SURVEY 8e "alternative"): every rank renders a DIFFERENT keyframe in full and one
+dense all-reduce sums the per-Gaussian gradients — N views per optimiser step.  It changes the optimiser trajectory (the reference trains on
+one view per step [REF mp_Mapper.py:200-206]), so it is NOT result-parity with the reference; it is what scales at today's sizes.
+
+The tile-sharded result equals the single-GPU rasteriser up to fp32 summation order in the gradient all-reduce.  `is_used` is not read by the
 reference [REF mp_Mapper.py:219-222]; it stays per-rank unless `sync_is_used=True`.
 
 CPU tensors (the gloo tests, whose per-rank rasteriser is an oracle-backed stand-in) take torch index operations with the same layout
@@ -300,3 +304,91 @@ class ShardedGaussianRasterizer(nn.Module):
             is_used = is_used.clone()
             dist.all_reduce(is_used, op=dist.ReduceOp.MAX, group=self.group)
         return depth, color, radii, is_used
+
+
+class _SumGradsDense(torch.autograd.Function):
+    """Identity in forward; in backward ONE all-reduce(sum) over the concatenation of the listed gradients plus a flag word (this rank's
+    duplicate lists overflowed).  Static size, torch ops + one collective only: capturable in a hipGraph."""
+
+    @staticmethod
+    def forward(ctx, group, holder, *tensors):
+        ctx.group, ctx.holder = group, holder
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        holder = ctx.holder
+        present = [g for g in grads if g is not None]
+        if not present:
+            return (None, None, *grads)
+        dev = present[0].device
+        guard, limit = holder.guard if holder.guard is not None else (None, 0)
+        flag = (guard.reshape(1) > limit).to(present[0].dtype) if guard is not None else torch.zeros(1, dtype=present[0].dtype, device=dev)
+        packed = torch.cat([g.reshape(-1) for g in present] + [flag])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
+        if holder.overflow is None:
+            holder.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        holder.overflow.copy_((packed[-1:] > 0).to(torch.int32))
+        holder.last_volume_bytes = packed.numel() * packed.element_size()
+        out, off = [], 0
+        for g in grads:
+            if g is None:
+                out.append(None)
+            else:
+                n = g.numel()
+                out.append(packed[off:off + n].view(g.shape))
+                off += n
+        return (None, None, *out)
+
+
+class KeyframeParallelRasterizer(nn.Module):
+    """Throughput mode for N GPUs ("alternative"): data-parallel over keyframes.  Every rank renders ITS OWN view with the plain
+    single-GPU rasteriser (whole image, no tile sharding, no image exchange) and computes its own loss; in the backward ONE dense
+    all-reduce sums the gradients of the map parameters (xyz 3, opacity 1, DC / SH, scale 3, quaternion 4 — 14 floats per Gaussian at
+    sh_degree 0: 16.8 MB at P = 300 k) over the ranks, so that the replicated optimiser takes ONE step on the gradient of the N views'
+    summed losses.  The screen-space gradient (densification statistics only) stays per-rank.  NOT result-parity with the reference, which
+    trains on one view per step [REF mp_Mapper.py:200-206]: N views per step is a different (larger-batch) trajectory.  Same call
+    signature and return tuple as GaussianRasterizer; `overflow_guard()` as in ShardedGaussianRasterizer (a rank whose duplicate lists
+    overflowed raises a flag word that travels with the gradients, every rank skips that step alike)."""
+
+    def __init__(self, raster_settings, group=None, rasterizer_cls=None, force_collectives=False):
+        super().__init__()
+        if rasterizer_cls is None:
+            from .rasterizer import GaussianRasterizer as rasterizer_cls
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.force_collectives = bool(force_collectives) and dist.is_initialized()
+        self.raster_settings = raster_settings._replace(tile_mod=1, tile_rem=0)
+        self.inner = rasterizer_cls(raster_settings=self.raster_settings)
+        self.holder = _Holder()
+
+    @property
+    def collective(self):
+        return self.world > 1 or self.force_collectives
+
+    def overflow_guard(self):
+        if not self.collective:
+            return None
+        self.holder.guard_requested = True
+        if self.holder.overflow is None:
+            self.holder.overflow = torch.zeros(1, dtype=torch.int32, device=self.raster_settings.viewmatrix.device)
+        return self.holder.overflow, 0
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        if self.collective:
+            names = ["means3D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp"]
+            vals = [means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp]
+            idx = [i for i, v in enumerate(vals) if v is not None]
+            synced = _SumGradsDense.apply(self.group, self.holder, *[vals[i] for i in idx])
+            kw = {n: None for n in names}
+            for i, t in zip(idx, synced):
+                kw[names[i]] = t
+            means3D, opacities, shs, colors_precomp = kw["means3D"], kw["opacities"], kw["shs"], kw["colors_precomp"]
+            scales, rotations, cov3D_precomp = kw["scales"], kw["rotations"], kw["cov3D_precomp"]
+        out = self.inner(means3D=means3D, means2D=means2D, opacities=opacities, shs=shs, colors_precomp=colors_precomp, scales=scales,
+                         rotations=rotations, cov3D_precomp=cov3D_precomp)
+        cap = int(getattr(self.raster_settings, "capacity", 0) or 0)
+        count = getattr(self.inner, "num_rendered", None)
+        self.holder.guard = (count, cap) if (cap > 0 and count is not None) else None
+        return out

@@ -1,0 +1,40 @@
+"""GPU: the contract command `python bench.py --gpus 2 ...` on a ONE-GPU box, with the gloo override (two ranks share cuda:0): the launcher starts
+two ranks by itself, the tile-sharded mapper iteration (HIP movers + both collectives, eager) and the keyframe-parallel leg (dense gradient
+all-reduce) both run, and rank 0 prints one JSON line saying so.  With 8 real GPUs the same command needs nothing else (backend nccl = RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra, env_extra):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--repeats", "2", "--gaussians", "60000",
+                          "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, f"stdout: {out.stdout[-2000:]}\nstderr: {out.stderr[-4000:]}"
+    return json.loads(lines[0])
+
+
+def test_gpus_2_starts_two_ranks_and_runs_both_multi_gpu_modes_over_gloo():
+    res = _bench(["--gpus", "2"], {"GSICP_BENCH_BACKEND": "gloo"})
+    assert res["n_gpus"] == 2 and res["config"]["world_size"] == 2 and len(res["config"]["rccl_ranks_seen"]) == 2
+    assert res["config"]["mp_mode"] == "tiles" and res["scaling"] == "strong" and res["value"] > 0
+    kf = res["legs"]["keyframe_parallel"]
+    assert kf["views_per_step"] == 2 and kf["scaling"] == "weak" and kf["value"] > 0
+    assert kf["gradient_all_reduce_bytes_per_rank"] == (60000 * 14 + 1) * 4
+    assert res["pose_error_deg_mm"] is not None and res["roofline"]["traffic"] is None
+
+
+def test_keyframes_mode_as_the_headline_on_a_one_rank_rccl_group_captured_in_the_graph():
+    """world size 1 with the collectives forced (RCCL self all-reduce inside the captured iteration): the machinery of `--mp-mode keyframes`."""
+    res = _bench(["--mp-mode", "keyframes", "--only", "mapper"], {"GSICP_BENCH_FORCE_COLLECTIVES": "1"})
+    assert res["config"]["mp_mode"] == "keyframes" and res["legs"]["tile_sharded"]["value"] > 0 and res["value"] > 0
+    assert "hipGraph" in res["config"]["mapper_iteration"]

@@ -151,3 +151,64 @@ def test_two_rank_sharding_matches_single_process():
     for k in grads:   # both ranks hold identical (all-reduced) gradients
         assert np.array_equal(outs[0][3][k], outs[1][3][k])
     assert np.array_equal(np.maximum(outs[0][4], outs[1][4]), used.numpy())   # per-rank is_used flags OR to the full ones
+
+
+def _kf_cam(rank):
+    return synth.make_camera(80, 48, 64.0, 64.0, synth.se3((0.0, 4.0 * rank, 0.0), (0.05 * rank, 0.0, 0.0)))
+
+
+def _kf_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gs_icp_slam_amd.sharded import KeyframeParallelRasterizer
+    g = _scene()
+    target = torch.from_numpy(np.random.default_rng(10 + rank).random((4, 48, 80)).astype(np.float32))
+    kp = KeyframeParallelRasterizer(_settings(_kf_cam(rank)), rasterizer_cls=_OracleRasterizer)
+    guard = kp.overflow_guard()
+    color, depth, grads, used = _run(kp, g, target)
+    vol = kp.holder.last_volume_bytes
+    flag0 = int(guard[0].item())
+    # a rank whose duplicate lists overflowed: the flag word travels with the gradients and both ranks see it
+    kp2 = KeyframeParallelRasterizer(_settings(_kf_cam(rank)), rasterizer_cls=_OracleRasterizer)
+    guard2 = kp2.overflow_guard()
+    t = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in g.items()}
+    d2, c2, _, _ = kp2(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"], requires_grad=True), shs=t["shs"], opacities=t["opacities"],
+                       scales=t["scales"], rotations=t["rotations"])
+    kp2.holder.guard = (torch.tensor([11 if rank == 1 else 9], dtype=torch.int32), 10)
+    (c2.mean() + d2.mean()).backward()
+    q.put((rank, color.numpy(), {k: v.numpy() for k, v in grads.items()}, vol, flag0, int(guard2[0].item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_keyframe_parallel_sums_the_views_gradients():
+    """Throughput mode (SURVEY 8e alternative): each rank renders its own keyframe; the parameters' gradients on every rank equal the SUM of
+    the two views' single-process gradients; each rank keeps its own image; one dense all-reduce of 14 floats per Gaussian + a flag word."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_kf_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = _scene()
+    single = []
+    for rank in range(2):
+        target = torch.from_numpy(np.random.default_rng(10 + rank).random((4, 48, 80)).astype(np.float32))
+        single.append(_run(_OracleRasterizer(_settings(_kf_cam(rank))), g, target))
+    P = g["means3D"].shape[0]
+    for rank, color, grads, vol, flag0, flag_tripped in outs:
+        assert np.array_equal(color, single[rank][0].numpy()), f"rank {rank} must render ITS OWN view"
+        assert vol == (P * 14 + 1) * 4 and flag0 == 0 and flag_tripped == 1
+        for k in grads:
+            want = single[0][2][k].numpy() + single[1][2][k].numpy()
+            np.testing.assert_allclose(grads[k], want, rtol=1e-6, atol=1e-7 * (np.abs(want).max() + 1e-30))
+    for k in outs[0][2]:
+        assert np.array_equal(outs[0][2][k], outs[1][2][k])
+    assert not np.array_equal(outs[0][1], outs[1][1])
