@@ -66,9 +66,15 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
                                                          Win win, float d_max, float dS_scale /* = -lambda / (3HW) */,
                                                          float* __restrict__ abc /* (3, 3, H, W): A, B, C per channel */,
                                                          float* __restrict__ partial) {
+    // LDS overlay: the horizontal pass runs in two sub-phases — the three maps that need x (mu_x, E[xx], E[xy]) first; then x is dead and
+    // mu_y is written over it — so four map buffers instead of five: 39 KB instead of 45 KB per workgroup, four workgroups per CU instead
+    // of three (the kernel is bound by how many workgroups a CU holds).  Same arithmetic in the same order: bit-identical results.
     __shared__ __attribute__((aligned(16))) float s_x[LW][LWS];
     __shared__ __attribute__((aligned(16))) float s_y[LW][LWS];
-    __shared__ __attribute__((aligned(16))) float s_h[5][LW][LHS];
+    __shared__ __attribute__((aligned(16))) float s_hb[4][LW][LHS];
+    static_assert(LW * LHS <= LW * LWS, "a filtered map must fit in a staged map's space");
+    // moment order of the vertical pass: 0 mu_x, 1 mu_y, 2 E[xx], 3 E[yy], 4 E[xy]
+    float (*const s_h[5])[LHS] = {s_hb[0], (float (*)[LHS])&s_x[0][0], s_hb[1], s_hb[3], s_hb[2]};
     __shared__ float s_red[4][2];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
@@ -117,22 +123,32 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
         // separable form differs from it only by the rounding of the 121 products (relative 6e-8, zero-mean) PROVIDED the 1-D
         // weights are bit-identical to the reference's (an early version normalised them with a sequentially rounded sum, one ulp
         // off, and that 6e-8 scale error alone moved the SSIM mean by 1e-5 through sigma = E[xx] - mu^2).
+        // the L1 term needs this thread's own x, y after x has been overwritten: fetch them now
+        float xc[4], yc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xc[j] = s_x[4 * ry + j + HALO][lx + HALO]; yc[j] = s_y[4 * ry + j + HALO][lx + HALO]; }
         for (int it = tid; it < LW * HSEG; it += 256) {
             const int r = it / HSEG, c0 = 4 * (it % HSEG);
             float xv[16], yv[16], pr[16];
             lds_load16(&s_x[r][c0], xv);
             lds_load16(&s_y[r][c0], yv);
             *(float4*)&s_h[0][r][c0] = conv4(xv, win);
-            *(float4*)&s_h[1][r][c0] = conv4(yv, win);
 #pragma unroll
             for (int i = 0; i < 14; ++i) pr[i] = xv[i] * xv[i];
             *(float4*)&s_h[2][r][c0] = conv4(pr, win);
 #pragma unroll
-            for (int i = 0; i < 14; ++i) pr[i] = yv[i] * yv[i];
-            *(float4*)&s_h[3][r][c0] = conv4(pr, win);
-#pragma unroll
             for (int i = 0; i < 14; ++i) pr[i] = xv[i] * yv[i];
             *(float4*)&s_h[4][r][c0] = conv4(pr, win);
+        }
+        __syncthreads();   // x is consumed: mu_y may land on it
+        for (int it = tid; it < LW * HSEG; it += 256) {
+            const int r = it / HSEG, c0 = 4 * (it % HSEG);
+            float yv[16], pr[16];
+            lds_load16(&s_y[r][c0], yv);
+            *(float4*)&s_h[1][r][c0] = conv4(yv, win);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) pr[i] = yv[i] * yv[i];
+            *(float4*)&s_h[3][r][c0] = conv4(pr, win);
         }
         __syncthreads();
         float mom[5][4];
@@ -167,8 +183,7 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
                 abc[(ch * 3 + 0) * HW + pix] = dS_scale * dS_dmu1;
                 abc[(ch * 3 + 1) * HW + pix] = dS_scale * dS_de11;
                 abc[(ch * 3 + 2) * HW + pix] = dS_scale * dS_de12;
-                const float xc = s_x[4 * ry + j + HALO][lx + HALO], yc = s_y[4 * ry + j + HALO][lx + HALO];
-                if (yc != 0.f) l1 += fabsf(xc - yc);
+                if (yc[j] != 0.f) l1 += fabsf(xc[j] - yc[j]);
             }
         }
     }
@@ -224,8 +239,13 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
                                                          Win win, float d_max, float l1_scale /* (1 - lambda) / (3HW) */,
                                                          float depth_scale /* w_d / (HW d_max) */, const float* __restrict__ abc,
                                                          float* __restrict__ dL_dimage, float* __restrict__ dL_ddepth, LossReduceArgs red) {
+    // LDS overlay: the horizontally filtered map m is written where the INPUT map m - 1 lay (already consumed; map 0 gets a buffer of its
+    // own) — 28 KB instead of 40 KB per workgroup, five workgroups per CU instead of four (these kernels are bound by how many
+    // workgroups a CU can hold, not by bandwidth or arithmetic), at the price of a barrier per map instead of one for all three.
     __shared__ __attribute__((aligned(16))) float s_in[3][LW][LWS];
-    __shared__ __attribute__((aligned(16))) float s_h[3][LW][LHS];
+    __shared__ __attribute__((aligned(16))) float s_h0[LW][LHS];
+    static_assert(LW * LHS <= LW * LWS, "a filtered map must fit in an input map's space");
+    float (*const s_hm[3])[LHS] = {s_h0, (float (*)[LHS])&s_in[0][0][0], (float (*)[LHS])&s_in[1][0][0]};
     const int tid = threadIdx.x, lx = tid & 31, ry = tid >> 5;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
     const size_t HW = (size_t)W * H;
@@ -268,22 +288,22 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    for (int it = tid; it < LW * HSEG; it += 256) {
-        const int r = it / HSEG, c0 = 4 * (it % HSEG);
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < 3; ++m) {
+        for (int it = tid; it < LW * HSEG; it += 256) {
+            const int r = it / HSEG, c0 = 4 * (it % HSEG);
             float v[16];
             lds_load16(&s_in[m][r][c0], v);
-            *(float4*)&s_h[m][r][c0] = conv4(v, win);
+            *(float4*)&s_hm[m][r][c0] = conv4(v, win);
         }
+        __syncthreads();   // input map m is consumed: the next map's output may land on it
     }
-    __syncthreads();
     float acc[3][4];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {   // symmetric window: correlation == convolution
         float v[16];
 #pragma unroll
-        for (int i = 0; i < 14; ++i) v[i] = s_h[m][4 * ry + i][lx];
+        for (int i = 0; i < 14; ++i) v[i] = s_hm[m][4 * ry + i][lx];
         const float4 o = conv4(v, win);
         acc[m][0] = o.x; acc[m][1] = o.y; acc[m][2] = o.z; acc[m][3] = o.w;
     }
