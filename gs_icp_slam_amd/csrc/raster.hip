@@ -183,14 +183,17 @@ __device__ inline void emit_one(int x, int y, int gx, int tile_mod, int tile_rem
                                 uint32_t id, uint32_t u, uint32_t* __restrict__ emit_tile, uint32_t* __restrict__ emit_depth,
                                 uint32_t* __restrict__ entry_gauss, uint32_t* __restrict__ entry_bits) {
     const int t = y * gx + x;
+    // bit b: the footprint box can touch the 8x8 pixel BLOCK b of the tile (b & 1 = right half, b >> 1 = lower half).  Square blocks are cut
+    // by fewer footprints than 16x4 strips of the same area: 1.60 instead of 1.71 kept (block, entry) pairs per list entry on the benchmark
+    // scene, 1.54 instead of 1.67 at 640x480 (round 3, counted on the CPU from the oracle's lists).
     uint32_t bits = 0;
-    if (fx1 >= (float)(x * TILE) && fx0 <= (float)(x * TILE + TILE - 1)) {
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const float ylo = (float)(y * TILE + 4 * sidx);
-            if (fy1 >= ylo && fy0 <= ylo + 3.f) bits |= 1u << sidx;
-        }
-    }
+    const float xl = (float)(x * TILE), yl = (float)(y * TILE);
+    const bool x0_ = fx1 >= xl && fx0 <= xl + 7.f, x1_ = fx1 >= xl + 8.f && fx0 <= xl + 15.f;
+    const bool y0_ = fy1 >= yl && fy0 <= yl + 7.f, y1_ = fy1 >= yl + 8.f && fy0 <= yl + 15.f;
+    if (x0_ && y0_) bits |= 1u;
+    if (x1_ && y0_) bits |= 2u;
+    if (x0_ && y1_) bits |= 4u;
+    if (x1_ && y1_) bits |= 8u;
     emit_tile[u] = (uint32_t)t;
     emit_depth[u] = dbits;
     entry_gauss[u] = id;
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(64) void blend_forward_strip_kernel(BlendArgs a) {
     const int tile = (int)a.order[tl];
     const int tx = tile % a.gx, ty = tile / a.gx;
     const int lane = threadIdx.x;
-    const int px = tx * TILE + (lane & 15), py = ty * TILE + wave * 4 + (lane >> 4);
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);   // wave = 8x8 block of the tile
     const bool inside = px < a.W && py < a.H;
     const float pfx = (float)px, pfy = (float)py;
     const uint2 range = a.ranges[tile];
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     const int tile = (int)a.order[tl];
     const int tx = tile % a.gx, ty = tile / a.gx;
-    const int px = tx * TILE + (lane & 15), py = ty * TILE + wave * 4 + (lane >> 4);
+    const int px = tx * TILE + (wave & 1) * 8 + (lane & 7), py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);   // wave = 8x8 block of the tile
     const bool inside = px < a.W && py < a.H;
     const float pfx = (float)px, pfy = (float)py;
     const uint2 range = a.ranges[tile];

@@ -18,8 +18,9 @@ struct __attribute__((aligned(16))) SplatRec {
 };
 
 // point_list entries: EMISSION SLOT u (index into entry_gauss) in the low 28 bits, 4 "strip" bits on top.  Bit 28+s is set iff the Gaussian's
-// alpha >= 1/255 footprint (a conservative bounding box of it) can touch rows 4s..4s+3 of the tile, i.e. the 16x4
-// pixel strip that wave s of the blend workgroup owns.  The blend kernels skip entries whose bit is clear.
+// alpha >= 1/255 footprint (a conservative bounding box of it) can touch the 8x8-pixel BLOCK s of the tile (s & 1: right half, s >> 1: lower
+// half) — the block that wave s of the blend workgroup owns (rounds 1-2: 16x4 strips; square blocks are cut by 6-8 % fewer footprints).
+// The blend kernels skip entries whose bit is clear.
 constexpr uint32_t ID_MASK = 0x0FFFFFFFu;
 constexpr int STRIP_SHIFT = 28;
 constexpr int NGRAD = 10;    // mean2D x,y | conic a,b,c | opacity | colour r,g,b | depth
