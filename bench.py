@@ -66,6 +66,50 @@ def _torch_ssim(img, gt, window):
     return (((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
 
 
+def _measure_pmc_traffic(kernel_substr, timeout=240.0):
+    """HBM-side traffic of one kernel, MEASURED IN THIS RUN: two child runs of this script (mapper half only, a few steps) under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` — separate passes, never combined with other trace
+    domains (MI355X_MICROARCH.md) — and the mean counter value per launch of the kernel x 1024 (the counters are KiB).  Returns
+    (dict, None) or (None, reason).  Raw counters: the calibration of profiles/r03_pmc_calibration.json applies (FETCH_SIZE counts a wide
+    coalesced stream at 0.5x and a gather of 48-byte records at 1.55x of the bytes requested; WRITE_SIZE 1.0x / 1.28x)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="gsicp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", GSICP_BENCH_CHILD="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--only", "mapper", "--steps", "8", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--no-legs"]
+            pr = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            if pr.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited with {pr.returncode}: {pr.stderr[-300:]}"
+            tot, n = 0.0, 0
+            for root, _dirs, files in os.walk(d):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        for row in csv.DictReader(open(os.path.join(root, f))):
+                            if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                                tot += float(row["Counter_Value"]); n += 1
+            if n == 0:
+                return None, f"no {counter} rows for {kernel_substr}"
+            out[counter] = tot / n * 1024.0
+            out[counter + "_launches"] = n
+    except Exception as e:   # noqa: BLE001 — a profiler hiccup must not take the benchmark line with it
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, None
+
+
 def _spawn_ranks(n):
     import socket
     import subprocess
@@ -550,8 +594,21 @@ def main():
                                          f"{valu * 4.0 / 1024.0 / 2.4e3:.0f} us issue floor ({os.path.basename(sq)})")
                                 break
                     break
+        traffic_run, traffic_why = None, "not measured: diagnostic / multi-GPU / child run"
+        if rank == 0 and world == 1 and args.only is None and not args.no_legs and os.environ.get("GSICP_BENCH_CHILD") != "1" \
+                and os.environ.get("GSICP_BENCH_PMC", "1") != "0":
+            pmc, traffic_why = _measure_pmc_traffic("blend_backward_tile_kernel")
+            if pmc is not None:
+                traffic_run = int(pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"])
+                traffic_why = (f"measured in THIS run: two child passes `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --only mapper "
+                               f"--steps 8` (mean over {pmc['FETCH_SIZE_launches']} launches): FETCH_SIZE {int(pmc['FETCH_SIZE'])} B + WRITE_SIZE {int(pmc['WRITE_SIZE'])} B, raw counters; "
+                               "calibration on this box's access patterns (profiles/r03_pmc_calibration.json): FETCH_SIZE reads a coalesced 16 B/lane stream at 0.50x and a "
+                               "gather of 48-byte records at 1.55x of the bytes requested, WRITE_SIZE 1.00x / 1.28x — this kernel's fetches are ~2/3 record gathers, so "
+                               "the true figure lies between 1x and 1.3x of the raw sum")
         roofline = {"bound": "hbm", "kernel": "blend_backward_tile_kernel (R7)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "traffic_last_capture": traffic, "traffic_source": traffic_src, "kernel_us": round(us_r7, 2),
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic_run, "traffic_how": traffic_why,
+                    "traffic_over_algorithmic": (round(traffic_run / b_r7, 3) if traffic_run else None),
+                    "traffic_last_capture": traffic, "traffic_source": traffic_src, "kernel_us": round(us_r7, 2),
                     "algorithmic_bytes": int(b_r7), "byte_model": "SURVEY 8(d): 44 D + 40 W H + 44 P_vis",
                     "design_bytes": int(design_bytes), "design_frac": round(gbs(design_bytes, us_r7) / HBM_PEAK_GBS, 5),
                     "whole_backward": {"algorithmic_bytes": int(b_bwd), "us": round(us_bwd, 2), "frac": round(gbs(b_bwd, us_bwd) / HBM_PEAK_GBS, 5),

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): captures the evidence that tools/collect_profiles.py turns into profiles/rNN_*.
-# usage: bash tools/capture_profiles.sh r02      (outputs under gpurun_out/<tag>/)
+# usage: bash tools/capture_profiles.sh r03      (outputs under gpurun_out/<tag>/)
 # Counter passes are separate from the kernel-trace pass and never combined with other trace domains.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -30,14 +30,28 @@ GSICP_BENCH_FORCE_COLLECTIVES=1 python $ROOT/bench.py --only mapper --no-cpu-bas
 python $ROOT/tools/rccl_graph_probe.py > $OUT/rccl_graph_probe.json 2>> $OUT/bench.err
 # tracker: phase trace of the persistent LM kernel and the k-NN ring statistics on SURVEY 8(d)'s pair
 (cd $ROOT && GSICP_ALIGN_TRACE=1 GSICP_KNN_STATS=1 timeout 120 python tools/tracker_latency.py --survey > $OUT/tracker_latency_survey.txt 2>&1)
-# the UNTOUCHED reference system on the drop-ins (synthetic sequences in Replica's on-disk layout), with the drop-in call trace
+# the UNTOUCHED reference system on the drop-ins (synthetic sequences; one ray-cast sequence is shared through --cache): the 30-FPS-capped entry point
+# (the map has to converge through the reference's own optimiser), the unlimited one with the drop-in call trace, and the TUM branch (TUM on-disk
+# layout, tum.sh flags).  The 1500-frame unlimited run of round 3 is captured by tools/capture_reference_runs.sh.
 cd $ROOT
-timeout 600 python tools/run_reference_slam.py --synthetic 400 --timeout 500 --trace $OUT/trace_ref --log $OUT/reference_run_replica.log > $OUT/reference_run_replica.json 2> $OUT/reference_run.err
+C=/tmp/gsicp_cache
+timeout 600 python tools/run_reference_slam.py --cache $C --synthetic 400 --timeout 500 --trace $OUT/trace_ref --log $OUT/reference_run_unlimit400.log > $OUT/reference_run_unlimit400.json 2> $OUT/reference_run.err
 python tools/analyze_call_trace.py $OUT/trace_ref > $OUT/reference_call_trace.json 2>> $OUT/reference_run.err
-timeout 400 python tools/run_reference_slam.py --synthetic 200 --shape tum --noise --timeout 300 > $OUT/reference_run_tum_shaped.json 2>> $OUT/reference_run.err
+timeout 600 python tools/run_reference_slam.py --cache $C --synthetic 300 --limit30 --timeout 500 > $OUT/reference_run_limit30_300.json 2>> $OUT/reference_run.err
+timeout 400 python tools/run_reference_slam.py --synthetic 60 --shape tum --noise --limit30 --timeout 300 > $OUT/reference_run_tum_layout60.json 2>> $OUT/reference_run.err
+# map quality: PSNR / SSIM / depth-L1 against mapper iterations (device-resident loop, ONE captured graph), and the scale-semantics coverage experiment
 timeout 300 python tools/slam_demo.py 52 --iters 5 --prune-every 120 > $OUT/slam_demo.txt 2>&1
-timeout 200 python tools/mfma_cov_experiment.py > $OUT/mfma_cov_experiment.json 2> /dev/null
+timeout 400 python tools/slam_demo.py 240 --iters 8 --eval-every 250 --post-iters 1500 --capacity 800000 --list-capacity 8388608 --no-asserts --json $OUT/map_quality_curve.json > $OUT/map_quality_curve.log 2>&1
+timeout 120 python tools/scale_coverage.py --json $OUT/scale_coverage.json > /dev/null 2>&1
+# counter calibration on kernels of known traffic
+cd /tmp
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -o p -- python $ROOT/tools/pmc_calibration.py run > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/calib_write -o p -- python $ROOT/tools/pmc_calibration.py run > /dev/null 2>&1
+cd $ROOT
+python tools/pmc_calibration.py report $OUT/calib_fetch $OUT/calib_write > $OUT/pmc_calibration.json 2>/dev/null
+# the contract command with N = 2 on this ONE GPU over gloo (launcher + both multi-GPU modes; functional rehearsal, not a scaling number)
+GSICP_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline > $OUT/bench_gpus2_gloo_one_gpu.json 2>> $OUT/bench.err
 # keep only the small files (the merge-back limit is 64 MiB)
 find $OUT -name '*.csv' -size +20M -delete
-rm -rf $OUT/trace_ref
-ls -la $OUT | head -40
+rm -rf $OUT/trace_ref $OUT/calib_fetch $OUT/calib_write
+ls -la $OUT | head -60

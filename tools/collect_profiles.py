@@ -78,13 +78,15 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     for name in ("bench", "bench_tum", "bench_basin", "bench_eager", "bench_under_rocprof", "reference_run_replica", "reference_run_tum_shaped",
+                 "reference_run_unlimit400", "reference_run_limit30_300", "reference_run_tum_layout60", "bench_gpus2_gloo_one_gpu",
                  "mfma_cov_experiment", "bench_mapper_only", "bench_tracker_only", "bench_force_collectives", "rccl_graph_probe"):
         j = last_json_line(os.path.join(src, name + ".json"))
         if j is not None:
             json.dump(j, open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
             if "value" in j:
                 print(name, j["value"], j["unit"], j["ms_per_step"], "ms/step")
-    for name in ("slam_demo.txt", "reference_call_trace.json", "tracker_latency_survey.txt"):
+    for name in ("slam_demo.txt", "reference_call_trace.json", "tracker_latency_survey.txt", "map_quality_curve.json", "scale_coverage.json",
+                 "pmc_calibration.json"):
         if os.path.exists(os.path.join(src, name)):
             import shutil
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
@@ -134,9 +136,9 @@ def refresh_bench_lines(tag):
             continue
         j = json.load(open(path))
         rf = j.get("roofline") or {}
-        if "blend_backward" in traffic:
-            rf["traffic"] = int(traffic["blend_backward"]["fetch_bytes"] + traffic["blend_backward"]["write_bytes"])
-            rf["traffic_source"] = f"profiles/{tag}_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this command in the same capture)"
+        if "blend_backward" in traffic:     # `traffic` itself stays what the run measured (bench.py's own child passes); this is the capture's figure
+            rf["traffic_last_capture"] = int(traffic["blend_backward"]["fetch_bytes"] + traffic["blend_backward"]["write_bytes"])
+            rf["traffic_source"] = f"profiles/{tag}_pmc_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE passes of the bench step in the same capture)"
         row = sq.get("blend_backward_tile_kernel")
         if row and float(row.get("SQ_INSTS_VALU", 0) or 0) > 0:
             valu = float(row["SQ_INSTS_VALU"])
