@@ -41,6 +41,8 @@ SIGNATURES = {
     "gsicp_mapper_loss_scratch_bytes": (c_size_t, [c_int, c_int]),
     "gsicp_mapper_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
+    "gsicp_mapper_loss_sharded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_store_compact_scratch_bytes": (c_size_t, [c_int]),
     "gsicp_store_compact": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_tiles_chunk_floats": (c_size_t, [c_int, c_int, c_int]),

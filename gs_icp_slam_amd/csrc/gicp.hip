@@ -1418,7 +1418,7 @@ __device__ inline void linearize_points(const AlignArgs& a, const double* __rest
                 // MJ = M J, columns 0..2 (M skew(t)); columns 3..5 are -M.  Row r of M: (Mr0, Mr1, Mr2).
                 //   MJ[r][0] = Mr1 tz - Mr2 ty,  MJ[r][1] = Mr2 tx - Mr0 tz,  MJ[r][2] = Mr0 ty - Mr1 tx
                 const double M00 = m[0], M01 = m[1], M02 = m[2], M11 = m[3], M12 = m[4], M22 = m[5];
-                const double q00 = M01 * tz - M02 * ty, q01 = M02 * tx - M00 * tz, q02 = M00 * ty - M01 * tx;
+                const double q01 = M02 * tx - M00 * tz, q02 = M00 * ty - M01 * tx;      // (MJ[0][0] only feeds the lower triangle)
                 const double q10 = M11 * tz - M12 * ty, q11 = M12 * tx - M01 * tz, q12 = M01 * ty - M11 * tx;
                 const double q20 = M12 * tz - M22 * ty, q21 = M22 * tx - M02 * tz, q22 = M02 * ty - M12 * tx;
                 // H = J^T (M J), upper triangle row by row (acc[0..20]); column r of J: (0, tz, -ty) (-tz, 0, tx) (ty, -tx, 0) then -I

@@ -12,6 +12,7 @@
 // results are bit-reproducible) by one workgroup of pass 2 — or by a one-workgroup kernel when only the loss value is asked for.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #include <hip/hip_runtime.h>
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
 // Finish the sums in a fixed order and form the loss.  out = {loss, L1, SSIM mean, depth L1}.  256 threads; called either by the
 // one-workgroup kernel below (loss value only) or by ONE workgroup of pass 2 (value + gradients: the reduction then costs no launch of its
 // own — 4.6 us of a 0.36 ms iteration) — same thread count and order, so both give the same bits.
-struct LossReduceArgs { const float2* partial; int n_tiles; float inv_n_img, inv_n_depth, lambda_dssim, depth_weight; float* out; };
+struct LossReduceArgs { const float2* partial; int n_tiles; float inv_n_img, inv_n_depth, lambda_dssim, depth_weight; float* out;
+                        float lambda_const; };   // the loss's constant term lambda * 1: lambda on one GPU; lambda / N per rank when N ranks each sum their own blocks
 __device__ inline void loss_reduce_body(const LossReduceArgs& q, const int tid) {
     __shared__ double s_acc[3][4];
     const int lane = tid & 63, wave = tid >> 6;
@@ -227,7 +229,8 @@ __device__ inline void loss_reduce_body(const LossReduceArgs& q, const int tid) 
         double a = 0, b = 0, c = 0;
         for (int w = 0; w < 4; ++w) { a += s_acc[0][w]; b += s_acc[1][w]; c += s_acc[2][w]; }
         const float L1 = (float)(a * q.inv_n_img), SS = (float)(b * q.inv_n_img), LD = (float)(c * q.inv_n_depth);
-        q.out[0] = (1.f - q.lambda_dssim) * L1 + q.lambda_dssim * (1.f - SS) + q.depth_weight * LD;
+        q.out[0] = q.lambda_const == q.lambda_dssim ? (1.f - q.lambda_dssim) * L1 + q.lambda_dssim * (1.f - SS) + q.depth_weight * LD
+                                                    : ((1.f - q.lambda_dssim) * L1 + (q.lambda_const - q.lambda_dssim * SS)) + q.depth_weight * LD;
         q.out[1] = L1; q.out[2] = SS; q.out[3] = LD;
     }
 }
@@ -321,6 +324,209 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
             }
             dL_dimage[ch * HW + pix] = gr;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fused loss (value parts + gradient)
+// ONE kernel instead of pass 1 + pass 2: a workgroup stages its 32x32 tile with a TEN-pixel halo (52x52), builds the five window moments on
+// the 42x42 region its outputs' windows reach, forms the SSIM map and the three derivative maps there, and applies the window to them for
+// its own 32x32 pixels — the derivative maps never travel through memory.  Against the two-pass form: no (3,3,H,W) map buffer (36 B / pixel
+// written, 65 B / pixel re-read with the halo), no second read of the images; the price is the window moments on 1.7x the pixels.
+// Same per-pixel arithmetic in the same order as the two passes: gradients are bit-identical to theirs.
+constexpr int FH = 2 * HALO;           // staged halo
+constexpr int FIN = LT + 2 * FH;       // 52 staged rows / columns
+constexpr int FMID = LT + 2 * HALO;    // 42 rows / columns of moments and derivative maps
+constexpr int FXS = 56;                // staged row stride (floats)
+constexpr int FMS = 44;                // row stride of the horizontally filtered moment maps and of the derivative maps
+constexpr int FSEG = FMS / 4;          // 11 four-column segments across the region
+constexpr int FVG = (FMID + 3) / 4;    // 11 four-row groups down the region
+
+__global__ __launch_bounds__(256) void loss_fused_kernel(const float* __restrict__ image, const float* __restrict__ depth,
+                                                         const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
+                                                         Win win, float d_max, float dS_scale /* -lambda / (3HW) */, float l1_scale /* (1 - lambda) / (3HW) */,
+                                                         float depth_scale /* w_d / (HW d_max) */, float* __restrict__ dL_dimage,
+                                                         float* __restrict__ dL_ddepth, float* __restrict__ partial, int tile_mod, int tile_rem) {
+    __shared__ __attribute__((aligned(16))) float s_x[FIN][FXS];        // later: the three derivative maps (FMID x FMS each)
+    __shared__ __attribute__((aligned(16))) float s_y[FIN][FXS];
+    __shared__ __attribute__((aligned(16))) float s_b[3][FIN][FMS];     // three horizontally filtered moment maps at a time; later the filtered derivative maps
+    __shared__ float s_red[4][2];
+    static_assert(3 * FMID * FMS <= 2 * FIN * FXS, "derivative maps must fit in the staging buffers");
+    static_assert(3 * FMID * LHS <= 3 * FIN * FMS, "filtered derivative maps must fit in the moment buffers");
+    float (*const s_a)[FMID][FMS] = (float (*)[FMID][FMS])&s_x[0][0];
+    float (*const s_h2)[FMID][LHS] = (float (*)[FMID][LHS])&s_b[0][0][0];
+    const int tid = threadIdx.x, lx = tid & 31, ry = tid >> 5;
+    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
+    const size_t HW = (size_t)W * H;
+    const int n_tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    const int px = x0 + lx;
+    float l1 = 0.f, ssum = 0.f;
+    // multi-GPU: a 32x32 block is one 2x2 super-tile of the rasteriser (raster_common.hpp tile_xy_is_mine); only its owner works on it, the
+    // others contribute zero partial sums and leave its pixels of dL_dimage / dL_ddepth alone (nobody reads them on this rank)
+    if (tile_mod > 1 && (tile % tile_mod) != tile_rem) {
+        if (tid == 0) { partial[((size_t)ch * n_tiles + tile) * 2 + 0] = 0.f; partial[((size_t)ch * n_tiles + tile) * 2 + 1] = 0.f; }
+        return;
+    }
+    if (ch == 3) {   // depth term: value and gradient
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int py = y0 + 4 * ry + j;
+            if (px < W && py < H) {
+                const size_t pix = (size_t)py * W + px;
+                const float g = gt_depth[pix] / d_max, d = depth[pix] / d_max;
+                float gr = 0.f;
+                if (g != 0.f) { l1 += fabsf(d - g); gr = d > g ? depth_scale : (d < g ? -depth_scale : 0.f); }
+                if (dL_ddepth) dL_ddepth[pix] = gr;
+            }
+        }
+    } else {
+        {   // stage: y = gt * (gt_depth > 0), x = where(y != 0, image, 0); zero outside the image.  Loads unconditional on clamped addresses.
+            constexpr int NST = (FIN * FXS + 255) / 256;   // 12
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float gd[NST / 2], gi[NST / 2], im[NST / 2];
+#pragma unroll
+                for (int u = 0; u < NST / 2; ++u) {
+                    const int i = tid + (half * (NST / 2) + u) * 256, r = i / FXS, c = i % FXS;
+                    int qx = x0 + c - FH, qy = y0 + r - FH;
+                    qx = qx < 0 ? 0 : (qx >= W ? W - 1 : qx);
+                    qy = qy < 0 ? 0 : (qy >= H ? H - 1 : qy);
+                    const size_t q = (size_t)qy * W + qx;
+                    gd[u] = gt_depth[q]; gi[u] = gt_image[ch * HW + q]; im[u] = image[ch * HW + q];
+                }
+#pragma unroll
+                for (int u = 0; u < NST / 2; ++u) {
+                    const int i = tid + (half * (NST / 2) + u) * 256, r = i / FXS, c = i % FXS;
+                    const int qx = x0 + c - FH, qy = y0 + r - FH;
+                    if (i < FIN * FXS) {
+                        const bool in = c < FIN && qx >= 0 && qx < W && qy >= 0 && qy < H;
+                        const float yv = (in && gd[u] > 0.f) ? gi[u] : 0.f;
+                        s_x[r][c] = yv != 0.f ? im[u] : 0.f;
+                        s_y[r][c] = yv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        float xc[4], yc[4];     // this thread's own four pixels (the staging buffers are overwritten below)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xc[j] = s_x[4 * ry + j + FH][lx + FH]; yc[j] = s_y[4 * ry + j + FH][lx + FH]; }
+        // this thread's vertical-pass items: four stacked rows (4 vg .. 4 vg + 3) of one column of the 42x42 region
+        const int itA = tid, itB = tid + 256;
+        const bool hasB = itB < FMID * FVG;
+        const int colA = itA % FMID, vgA = itA / FMID, colB = hasB ? itB % FMID : 0, vgB = hasB ? itB / FMID : 0;
+        float mom[2][5][4];
+        auto vpass = [&](const int m_buf, const int m_out) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k == 1 && !hasB) break;
+                const int col = k ? colB : colA, vg = k ? vgB : vgA;
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 14; ++i) { const int r = 4 * vg + i; v[i] = s_b[m_buf][r < FIN ? r : FIN - 1][col]; }
+                const float4 o = conv4(v, win);
+                mom[k][m_out][0] = o.x; mom[k][m_out][1] = o.y; mom[k][m_out][2] = o.z; mom[k][m_out][3] = o.w;
+            }
+        };
+        // horizontal pass A: the maps that need x — mu_x, E[xx], E[xy]
+        for (int it = tid; it < FIN * FSEG; it += 256) {
+            const int r = it / FSEG, c0 = 4 * (it % FSEG);
+            float xv[16], yv[16], pr[16];
+            lds_load16(&s_x[r][c0], xv);
+            lds_load16(&s_y[r][c0], yv);
+            *(float4*)&s_b[0][r][c0] = conv4(xv, win);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) pr[i] = xv[i] * xv[i];
+            *(float4*)&s_b[1][r][c0] = conv4(pr, win);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) pr[i] = xv[i] * yv[i];
+            *(float4*)&s_b[2][r][c0] = conv4(pr, win);
+        }
+        __syncthreads();
+        vpass(0, 0); vpass(1, 2); vpass(2, 4);
+        __syncthreads();
+        // horizontal pass B: mu_y, E[yy]
+        for (int it = tid; it < FIN * FSEG; it += 256) {
+            const int r = it / FSEG, c0 = 4 * (it % FSEG);
+            float yv[16], pr[16];
+            lds_load16(&s_y[r][c0], yv);
+            *(float4*)&s_b[0][r][c0] = conv4(yv, win);
+#pragma unroll
+            for (int i = 0; i < 14; ++i) pr[i] = yv[i] * yv[i];
+            *(float4*)&s_b[1][r][c0] = conv4(pr, win);
+        }
+        __syncthreads();
+        vpass(0, 1); vpass(1, 3);
+        // SSIM map + derivative maps on the 42x42 region (x and y staging is dead: the maps land there)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k == 1 && !hasB) break;
+            const int col = k ? colB : colA, vg = k ? vgB : vgA;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * vg + j;
+                if (r >= FMID) continue;
+                const int qx = x0 + col - HALO, qy = y0 + r - HALO;
+                const bool in = qx >= 0 && qx < W && qy >= 0 && qy < H;
+                const float mu1 = mom[k][0][j], mu2 = mom[k][1][j], e11 = mom[k][2][j], e22 = mom[k][3][j], e12 = mom[k][4][j];
+                const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+                const float a = 2.f * mu12 + C1, b = 2.f * (e12 - mu12) + C2;
+                const float c = mu1_sq + mu2_sq + C1, d = (e11 - mu1_sq) + (e22 - mu2_sq) + C2;
+                const float inv_d = __builtin_amdgcn_rcpf(d);
+                const float inv_cd = __builtin_amdgcn_rcpf(c) * inv_d;
+                const float S = a * b * inv_cd;
+                const float dS_dmu1 = 2.f * mu2 * (b - a) * inv_cd - 2.f * mu1 * S * (d - c) * inv_cd;
+                const float dS_de11 = -S * inv_d;
+                const float dS_de12 = 2.f * a * inv_cd;
+                s_a[0][r][col] = in ? dS_scale * dS_dmu1 : 0.f;
+                s_a[1][r][col] = in ? dS_scale * dS_de11 : 0.f;
+                s_a[2][r][col] = in ? dS_scale * dS_de12 : 0.f;
+                // the SSIM mean counts every image pixel once: by the workgroup whose OUTPUT tile holds it
+                if (in && r >= HALO && r < HALO + LT && col >= HALO && col < HALO + LT) ssum += S;
+            }
+        }
+        __syncthreads();
+        // window applied to the derivative maps: horizontal ...
+        for (int it = tid; it < FMID * HSEG; it += 256) {
+            const int r = it / HSEG, c0 = 4 * (it % HSEG);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                float v[16];
+                lds_load16(&s_a[m][r][c0], v);
+                *(float4*)&s_h2[m][r][c0] = conv4(v, win);
+            }
+        }
+        __syncthreads();
+        // ... and vertical, for this thread's own four pixels
+        float acc[3][4];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 14; ++i) v[i] = s_h2[m][4 * ry + i][lx];
+            const float4 o = conv4(v, win);
+            acc[m][0] = o.x; acc[m][1] = o.y; acc[m][2] = o.z; acc[m][3] = o.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int py = y0 + 4 * ry + j;
+            if (px < W && py < H) {
+                float gr = 0.f;
+                if (yc[j] != 0.f) {
+                    l1 += fabsf(xc[j] - yc[j]);
+                    gr = acc[0][j] + 2.f * xc[j] * acc[1][j] + yc[j] * acc[2][j];
+                    gr += xc[j] > yc[j] ? l1_scale : (xc[j] < yc[j] ? -l1_scale : 0.f);
+                }
+                if (dL_dimage) dL_dimage[ch * HW + (size_t)py * W + px] = gr;
+            }
+        }
+    }
+    l1 = wave_sum_f(l1); ssum = wave_sum_f(ssum);
+    if ((tid & 63) == 0) { s_red[tid >> 6][0] = l1; s_red[tid >> 6][1] = ssum; }
+    __syncthreads();
+    if (tid == 0) {
+        partial[((size_t)ch * n_tiles + tile) * 2 + 0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+        partial[((size_t)ch * n_tiles + tile) * 2 + 1] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
     }
 }
 
@@ -600,17 +806,32 @@ __global__ __launch_bounds__(256) void rows_move_kernel(int P, const int* __rest
 }
 
 
-// ---- multi-GPU mapper: a rank's own 16x16 tiles (tile t belongs to rank t % tile_mod) as one contiguous all-gather chunk --------------------
-// chunk layout: [k = t / tile_mod][channel: r, g, b, depth][256 pixels of the tile, row-major]; pixels outside the image are zero.
+// ---- multi-GPU mapper: a rank's own 16x16 tiles (dealt in 2x2 super-tiles: raster_common.hpp tile_xy_is_mine) as one contiguous all-gather chunk
+// chunk layout: [slot k][channel: r, g, b, depth][256 pixels of the tile, row-major]; slot k of rank r = tile (k & 3) of its (k >> 2)-th
+// super-tile S = (k >> 2) * tile_mod + r; slots past the image edge and pixels outside the image are zero.
 template <bool PACK>
-__global__ __launch_bounds__(256) void tiles_move_kernel(int W, int H, int gx, int T, int tile_mod, int tile_rem, int chunk_tiles,
+__global__ __launch_bounds__(256) void tiles_move_kernel(int W, int H, int gx, int gy, int tile_mod, int tile_rem, int chunk_slots,
                                                          float* __restrict__ color, float* __restrict__ depth, float* __restrict__ buf) {
-    // PACK: blockIdx.x = k, own tile t = k * tile_mod + tile_rem.  UNPACK: blockIdx.x = t, source chunk of rank t % tile_mod.
-    const int t = PACK ? (int)blockIdx.x * tile_mod + tile_rem : (int)blockIdx.x;
-    const int k = PACK ? (int)blockIdx.x : t / tile_mod;
-    float* __restrict__ slab = buf + ((size_t)(PACK ? 0 : (t % tile_mod)) * chunk_tiles + k) * 1024 + threadIdx.x;
-    const int x = (t % gx) * 16 + (threadIdx.x & 15), y = (t / gx) * 16 + (threadIdx.x >> 4);
-    const bool inside = t < T && x < W && y < H;
+    // PACK: blockIdx.x = slot k of this rank.  UNPACK: blockIdx.x = tile t, read from the chunk of the rank that owns it.
+    const int sgx = (gx + 1) >> 1, sgy = (gy + 1) >> 1;
+    int tx, ty, k, src_rank;
+    bool valid;
+    if (PACK) {
+        k = (int)blockIdx.x; src_rank = 0;
+        const int S = (k >> 2) * tile_mod + tile_rem;
+        tx = 2 * (S % sgx) + (k & 1); ty = 2 * (S / sgx) + ((k >> 1) & 1);
+        valid = S < sgx * sgy && tx < gx && ty < gy;
+    } else {
+        const int t = (int)blockIdx.x;
+        tx = t % gx; ty = t / gx;
+        const int S = (ty >> 1) * sgx + (tx >> 1);
+        src_rank = S % tile_mod;
+        k = (S / tile_mod) * 4 + ((ty & 1) * 2 + (tx & 1));
+        valid = true;
+    }
+    float* __restrict__ slab = buf + ((size_t)src_rank * chunk_slots + k) * 1024 + threadIdx.x;
+    const int x = tx * 16 + (threadIdx.x & 15), y = ty * 16 + (threadIdx.x >> 4);
+    const bool inside = valid && x < W && y < H;
     const size_t HW = (size_t)W * H, pix = (size_t)y * W + x;
     if (PACK) {
         slab[0] = inside ? color[pix] : 0.f;
@@ -635,10 +856,11 @@ size_t gsicp_mapper_loss_scratch_bytes(int width, int height) {
     return align_up(9 * HW * sizeof(float)) + align_up(4 * tiles * 2 * sizeof(float));
 }
 
-int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
-                      float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
-                      char* scratch, void* stream_v) {
+static int mapper_loss_impl(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
+                            float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
+                            char* scratch, int tile_mod, int tile_rem, void* stream_v) {
     hipStream_t stream = (hipStream_t)stream_v;
+    if (tile_mod < 1 || tile_rem < 0 || tile_rem >= tile_mod) { g_last_error = "gsicp_mapper_loss_sharded: bad tile_mod / tile_rem"; return -2; }
     if (width <= 0 || height <= 0 || !image || !depth || !gt_image || !gt_depth || !loss_out || !scratch) {
         g_last_error = "gsicp_mapper_loss: bad arguments"; return -2;
     }
@@ -660,8 +882,24 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
     float* abc = (float*)scratch;
     float* partial = (float*)(scratch + align_up(9 * HW * sizeof(float)));
     const float n_img = 3.f * (float)HW;
-    const LossReduceArgs red{(const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim, depth_weight, loss_out};
+    const LossReduceArgs red{(const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim, depth_weight, loss_out, lambda_dssim};
     const bool with_grads = dL_dimage && dL_ddepth;
+    if (tile_mod > 1) {
+        // Multi-GPU (tile_mod ranks): THIS rank's 32x32 blocks only, in ONE kernel — the fused form needs no derivative maps of blocks other
+        // ranks own (the two-pass form would: its second pass reads them with a 5-pixel halo), so its work divides by the rank count:
+        // 70 us / N against 33 + 33 us replicated (on one GPU the two passes are faster: csrc/experiments/README.md).  loss_out receives this
+        // rank's SHARE {loss, L1, SSIM mean, depth L1}: the sum over the ranks is the loss (the constant lambda is split N ways).
+        const LossReduceArgs red_n{(const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim, depth_weight, loss_out,
+                                   lambda_dssim / (float)tile_mod};
+        { ProfileScope ps(ST_LOSS_PASS1, stream);
+          hipLaunchKernelGGL(loss_fused_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
+                             -lambda_dssim / n_img, (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), dL_dimage, dL_ddepth, partial,
+                             tile_mod, tile_rem); }
+        { ProfileScope ps(ST_LOSS_PASS2, stream);
+          hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, red_n); }
+        if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss_sharded: kernel launch failed"; return -1; }
+        return 0;
+    }
     { ProfileScope ps(ST_LOSS_PASS1, stream);
       hipLaunchKernelGGL(loss_pass1_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                          -lambda_dssim / n_img, abc, partial);
@@ -673,6 +911,19 @@ int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_im
     }
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss: kernel launch failed"; return -1; }
     return 0;
+}
+
+int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
+                      float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
+                      char* scratch, void* stream) {
+    return mapper_loss_impl(image, depth, gt_image, gt_depth, width, height, lambda_dssim, depth_weight, d_max, loss_out, dL_dimage, dL_ddepth,
+                            scratch, 1, 0, stream);
+}
+int gsicp_mapper_loss_sharded(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
+                              float lambda_dssim, float depth_weight, float d_max, int tile_mod, int tile_rem, float* loss_out,
+                              float* dL_dimage, float* dL_ddepth, char* scratch, void* stream) {
+    return mapper_loss_impl(image, depth, gt_image, gt_depth, width, height, lambda_dssim, depth_weight, d_max, loss_out, dL_dimage, dL_ddepth,
+                            scratch, tile_mod, tile_rem, stream);
 }
 
 size_t gsicp_store_compact_scratch_bytes(int n) { return ((size_t)(n > 0 ? (n + 255) / 256 : 1) + 1) * sizeof(unsigned); }
@@ -752,25 +1003,24 @@ int gsicp_rows_unpack(int P, const int* radii, int n_arrays, float* const* dst, 
 
 size_t gsicp_tiles_chunk_floats(int width, int height, int tile_mod) {
     if (width <= 0 || height <= 0 || tile_mod <= 0) return 0;
-    const size_t T = (size_t)((width + 15) / 16) * ((height + 15) / 16);
-    return ((T + tile_mod - 1) / tile_mod) * 1024;
+    return (size_t)tile_chunk_slots((width + 15) / 16, (height + 15) / 16, tile_mod) * 1024;
 }
 
 int gsicp_tiles_pack(int width, int height, int tile_mod, int tile_rem, const float* color, const float* depth, float* chunk, void* stream) {
     if (width <= 0 || height <= 0 || tile_mod <= 0 || tile_rem < 0 || tile_rem >= tile_mod || !color || !depth || !chunk) {
         g_last_error = "gsicp_tiles_pack: bad arguments"; return -2;
     }
-    const int gx = (width + 15) / 16, T = gx * ((height + 15) / 16), chunk_tiles = (T + tile_mod - 1) / tile_mod;
-    hipLaunchKernelGGL(tiles_move_kernel<true>, dim3(chunk_tiles), dim3(256), 0, (hipStream_t)stream, width, height, gx, T, tile_mod, tile_rem,
-                       chunk_tiles, (float*)color, (float*)depth, chunk);
+    const int gx = (width + 15) / 16, gy = (height + 15) / 16, chunk_slots = tile_chunk_slots(gx, gy, tile_mod);
+    hipLaunchKernelGGL(tiles_move_kernel<true>, dim3(chunk_slots), dim3(256), 0, (hipStream_t)stream, width, height, gx, gy, tile_mod, tile_rem,
+                       chunk_slots, (float*)color, (float*)depth, chunk);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_tiles_pack: kernel launch failed"; return -1; }
     return 0;
 }
 
 int gsicp_tiles_unpack(int width, int height, int tile_mod, const float* gathered, float* color, float* depth, void* stream) {
     if (width <= 0 || height <= 0 || tile_mod <= 0 || !gathered || !color || !depth) { g_last_error = "gsicp_tiles_unpack: bad arguments"; return -2; }
-    const int gx = (width + 15) / 16, T = gx * ((height + 15) / 16), chunk_tiles = (T + tile_mod - 1) / tile_mod;
-    hipLaunchKernelGGL(tiles_move_kernel<false>, dim3(T), dim3(256), 0, (hipStream_t)stream, width, height, gx, T, tile_mod, 0, chunk_tiles, color,
+    const int gx = (width + 15) / 16, gy = (height + 15) / 16, chunk_slots = tile_chunk_slots(gx, gy, tile_mod);
+    hipLaunchKernelGGL(tiles_move_kernel<false>, dim3(gx * gy), dim3(256), 0, (hipStream_t)stream, width, height, gx, gy, tile_mod, 0, chunk_slots, color,
                        depth, (float*)gathered);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_tiles_unpack: kernel launch failed"; return -1; }
     return 0;

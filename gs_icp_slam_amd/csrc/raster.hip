@@ -111,7 +111,7 @@ __global__ void publish_count_kernel(const uint32_t* __restrict__ total, uint32_
 // Single workgroup: exclusive scan of the per-tile duplicate counts -> list ranges, and an LPT dispatch order by a
 // counting sort over 64 length buckets (exact ordering is not needed for load balance).  Any T; one launch.
 constexpr int LPT_BUCKETS = 64;   // = the wave size (the bucket scan below runs on one wave)
-__global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int tile_mod, int tile_rem, const uint32_t* __restrict__ tile_count,
+__global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int gx, int tile_mod, int tile_rem, const uint32_t* __restrict__ tile_count,
                                                              uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_hist[LPT_BUCKETS];
@@ -149,9 +149,9 @@ __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int tile_mod
     // LPT order over this rank's tiles
     const uint32_t maxlen = s_maxlen;
     const uint32_t div = maxlen / LPT_BUCKETS + 1;
-    const int n_local = (T - tile_rem + tile_mod - 1) / tile_mod;
-    for (int i = tid; i < n_local; i += 1024) {
-        const uint32_t c = tile_count[i * tile_mod + tile_rem];
+    for (int t = tid; t < T; t += 1024) {
+        if (!tile_is_mine(t, gx, tile_mod, tile_rem)) continue;
+        const uint32_t c = tile_count[t];
         atomicAdd(&s_hist[LPT_BUCKETS - 1 - (c / div)], 1u);     // bucket 0 = longest lists
     }
     __syncthreads();
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int tile_mod
         s_hist[tid] = incl - h;
     }
     __syncthreads();
-    for (int i = tid; i < n_local; i += 1024) {
-        const int t = i * tile_mod + tile_rem;
+    for (int t = tid; t < T; t += 1024) {
+        if (!tile_is_mine(t, gx, tile_mod, tile_rem)) continue;
         const uint32_t c = tile_count[t];
         const uint32_t pos = atomicAdd(&s_hist[LPT_BUCKETS - 1 - (c / div)], 1u);
         order[pos] = (uint32_t)t;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __rest
     if (active && !wide) {
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
-                if (tile_mod > 1 && ((y * gx + x) % tile_mod) != tile_rem) continue;
+                if (!tile_xy_is_mine(x, y, gx, tile_mod, tile_rem)) continue;
                 emit_one(x, y, gx, tile_mod, tile_rem, fx0, fx1, fy0, fy1, dbits, (uint32_t)id, u, emit_tile, emit_depth, entry_gauss, entry_bits);
                 ++u;
             }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __rest
             uint32_t kept = 0;
             for (int k0 = 0; k0 < n; k0 += 64) {
                 const int k = k0 + lane;
-                const bool mine = k < n && (((by0 + k / w) * gx + bx0 + k % w) % tile_mod) == tile_rem;
+                const bool mine = k < n && tile_xy_is_mine(bx0 + k % w, by0 + k / w, gx, tile_mod, tile_rem);
                 const unsigned long long mm = __ballot(mine);
                 if (mine)
                     emit_one(bx0 + k % w, by0 + k / w, gx, tile_mod, tile_rem, gfx0, gfx1, gfy0, gfy1, gdb, gid,
@@ -909,7 +909,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     }
     {
         ProfileScope ps(ST_RANGES, stream);
-        hipLaunchKernelGGL(tile_scan_lpt_kernel, dim3(1), dim3(1024), 0, stream, T, tile_mod, tile_rem, tile_count, ranges, order);
+        hipLaunchKernelGGL(tile_scan_lpt_kernel, dim3(1), dim3(1024), 0, stream, T, gx, tile_mod, tile_rem, tile_count, ranges, order);
     }
     if (num_rendered > 0) {
         {
@@ -917,7 +917,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
             hipLaunchKernelGGL(split_scatter_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, emit_depth,
                                entry_bits, block_hist, ranges, (uint32_t*)(bin + BL.scatter_keys), (uint32_t*)(bin + BL.scatter_vals));
         }
-        const int n_local = (T - tile_rem + tile_mod - 1) / tile_mod;
+        const int n_local = count_local_tiles(gx, gy, tile_mod, tile_rem);
         // ONE class: lists up to SORT_SMALL entries (everything the BASELINE scenes produce: their longest lists are ~500 entries) are sorted
         // in LDS, longer ones in SORT_SMALL-entry chunks merged by rank.  A second, persistent 512-thread kernel for the long lists cost a
         // 4.5 us launch in EVERY iteration to find nothing to do (kernels in a replayed graph cost ~4 us each whatever they compute).
@@ -930,7 +930,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     BlendArgs ba;
     std::memset(&ba, 0, sizeof(ba));
     ba.W = width; ba.H = height; ba.gx = gx; ba.tile_mod = tile_mod; ba.tile_rem = tile_rem; ba.depth_mode = depth_mode;
-    ba.n_tiles_local = (T - tile_rem + tile_mod - 1) / tile_mod;
+    ba.n_tiles_local = count_local_tiles(gx, gy, tile_mod, tile_rem);
     ba.ranges = ranges; ba.point_list = point_list; ba.rec = rec; ba.list_gauss = (const uint32_t*)(bin + BL.list_gauss);
     ba.order = order;
     ba.bg = background;
@@ -1005,7 +1005,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     BlendArgs ba;
     std::memset(&ba, 0, sizeof(ba));
     ba.W = width; ba.H = height; ba.gx = gx; ba.tile_mod = tile_mod; ba.tile_rem = tile_rem;
-    ba.n_tiles_local = (T - tile_rem + tile_mod - 1) / tile_mod;
+    ba.n_tiles_local = count_local_tiles(gx, gy, tile_mod, tile_rem);
     ba.ranges = (const uint2*)(img_buffer + IL.ranges);
     ba.order = (const uint32_t*)(img_buffer + IL.order);
     ba.point_list = (const uint32_t*)(binning_buffer + BL.point_list);

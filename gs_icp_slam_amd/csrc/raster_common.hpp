@@ -33,6 +33,29 @@ constexpr int CK_F = 5;      // floats per pixel and checkpoint
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// Multi-GPU tile ownership (tile_mod = number of ranks, tile_rem = this rank): tiles are dealt round-robin in 2x2 GROUPS — super-tile
+// S = (ty / 2) * ceil(gx / 2) + tx / 2 belongs to rank S % tile_mod.  A super-tile is exactly one 32x32-pixel block of the loss kernels, so
+// the rank that blends a block also owns its loss gradient (round 3; rounds 1-2 dealt single tiles, t % tile_mod, and every rank computed the
+// whole loss).  Interleaving keeps the load balanced; tile_mod <= 1 means "all tiles".
+__host__ __device__ inline bool tile_xy_is_mine(int tx, int ty, int gx, int tile_mod, int tile_rem) {
+    return tile_mod <= 1 || ((((ty >> 1) * ((gx + 1) >> 1)) + (tx >> 1)) % tile_mod) == tile_rem;
+}
+__host__ __device__ inline bool tile_is_mine(int t, int gx, int tile_mod, int tile_rem) {
+    return tile_mod <= 1 || tile_xy_is_mine(t % gx, t / gx, gx, tile_mod, tile_rem);
+}
+inline int count_local_tiles(int gx, int gy, int tile_mod, int tile_rem) {
+    if (tile_mod <= 1) return gx * gy;
+    int n = 0;
+    for (int ty = 0; ty < gy; ++ty)
+        for (int tx = 0; tx < gx; ++tx) n += tile_xy_is_mine(tx, ty, gx, tile_mod, tile_rem) ? 1 : 0;
+    return n;
+}
+// all-gather chunk of the tile movers: slot k of rank r holds tile (sub = k & 3) of its (k >> 2)-th super-tile; slots past the image are padding
+__host__ __device__ inline int tile_chunk_slots(int gx, int gy, int tile_mod) {
+    const int n_super = ((gx + 1) >> 1) * ((gy + 1) >> 1);
+    return 4 * ((n_super + tile_mod - 1) / tile_mod);
+}
+
 // Section offsets inside the three torch-owned scratch buffers.
 struct GeomLayout { size_t records, clamped, slot_base, tiles_touched, total; };
 struct BinLayout { size_t point_list, tile_keys, list_gauss, entry_gauss, entry_bits, emit_tile, emit_depth, scatter_keys, scatter_vals, block_hist, seg_work, ckpt, total; };

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
                 if (a.tile_mod > 1) {  // multi-GPU tile sharding: only this rank's tiles get emission slots
                     mine = 0;
                     for (int y = y0; y < y1; ++y)
-                        for (int x = x0; x < x1; ++x) mine += ((y * gx + x) % a.tile_mod) == a.tile_rem;
+                        for (int x = x0; x < x1; ++x) mine += tile_xy_is_mine(x, y, gx, a.tile_mod, a.tile_rem) ? 1u : 0u;
                 }
                 a.radii[idx] = rad;
                 a.clamped[idx] = (unsigned char)cm;

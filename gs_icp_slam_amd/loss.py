@@ -61,10 +61,12 @@ def mapper_loss_parts(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_
     return _MapperLoss.apply(image, depth, gt_image, gt_depth, lambda_dssim, depth_weight, d_max)
 
 
-def mapper_loss_and_grads(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_weight=0.1, d_max=10.0):
+def mapper_loss_and_grads(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_weight=0.1, d_max=10.0, tile_mod=1, tile_rem=0):
     """No-autograd form for callers that drive the backward themselves (gs_icp_slam_amd/graph.py):
     -> (tensor([loss, L1, SSIM mean, depth L1]), dL/dimage (3,H,W), dL/ddepth (1,H,W)), the gradients being those of `loss`
-    itself, so no ones_like / multiply launches are needed before `torch.autograd.backward((image, depth), (g_image, g_depth))`."""
+    itself, so no ones_like / multiply launches are needed before `torch.autograd.backward((image, depth), (g_image, g_depth))`.
+    tile_mod > 1 (multi-GPU mapper): this rank's 32x32 blocks only (gsicp_mapper_loss_sharded) — the four values are this rank's SHARE
+    (their sum over the ranks is the loss) and the gradients are defined on the rank's own blocks (zero elsewhere)."""
     lib = _lib.load()
     if not image.is_cuda:
         raise RuntimeError("mapper_loss (gfx950): tensors must live on the HIP device; there is no CPU path")
@@ -76,9 +78,15 @@ def mapper_loss_and_grads(image, depth, gt_image, gt_depth, lambda_dssim=0.2, de
         raise RuntimeError("mapper_loss: expected image/gt_image (3,H,W) and depth/gt_depth (1,H,W)")
     with torch.cuda.device(dev):
         out = torch.empty(4, dtype=torch.float32, device=dev)
-        g_img, g_dep = torch.empty_like(image_c), torch.empty_like(depth_c)
+        sharded = int(tile_mod) > 1
+        g_img, g_dep = (torch.zeros_like(image_c), torch.zeros_like(depth_c)) if sharded else (torch.empty_like(image_c), torch.empty_like(depth_c))
         scratch = torch.empty(int(lib.gsicp_mapper_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.gsicp_mapper_loss(_p(image_c), _p(depth_c), _p(gt_c), _p(gtd_c), W, H, float(lambda_dssim), float(depth_weight),
-                                         float(d_max), _p(out), _p(g_img), _p(g_dep), _p(scratch), stream), "gsicp_mapper_loss")
+        if sharded:
+            _lib.check(lib.gsicp_mapper_loss_sharded(_p(image_c), _p(depth_c), _p(gt_c), _p(gtd_c), W, H, float(lambda_dssim), float(depth_weight),
+                                                     float(d_max), int(tile_mod), int(tile_rem), _p(out), _p(g_img), _p(g_dep), _p(scratch), stream),
+                       "gsicp_mapper_loss_sharded")
+        else:
+            _lib.check(lib.gsicp_mapper_loss(_p(image_c), _p(depth_c), _p(gt_c), _p(gtd_c), W, H, float(lambda_dssim), float(depth_weight),
+                                             float(d_max), _p(out), _p(g_img), _p(g_dep), _p(scratch), stream), "gsicp_mapper_loss")
     return out, g_img.view(image.shape), g_dep.view(depth.shape)

@@ -2,8 +2,9 @@
 which is single-GPU with no collectives).
 
 Every rank holds the full Gaussian set (replicated parameters + optimiser state).  Rank r bins and blends only the
-16x16 tiles with ``tile_id % world == r`` (interleaved for load balance), so the expensive per-(tile, Gaussian) work
-is divided by the world size.  Two collectives per iteration, both RCCL over xGMI when the backend is "nccl":
+16x16 tiles of the 2x2 super-tiles (32x32-pixel blocks) with ``super_tile_id % world == r`` (interleaved for load balance), so the expensive
+per-(tile, Gaussian) work is divided by the world size — and so is the loss: a super-tile is exactly one block of the loss kernels, and the
+rank that blends a block computes the loss gradient of that block (gs_icp_slam_amd/loss.py, `tile_mod / tile_rem`).  Two collectives per iteration, both RCCL over xGMI when the backend is "nccl":
 
   forward : ALL-GATHER of each rank's own tiles — `gsicp_tiles_pack` writes the rank's tiles (r, g, b, depth) as one contiguous chunk
             (13/N MB at 1200x680), one all_gather_into_tensor moves the N chunks, `gsicp_tiles_unpack` writes the full image.  Every
@@ -42,11 +43,11 @@ import torch.nn as nn
 
 
 def _own_pixel_table(W, H, world, device):
-    """(world, n_max) int64: flat pixel indices of each rank's tiles (tile t belongs to rank t % world), padded with H*W (a dummy slot).
+    """(world, n_max) int64: flat pixel indices of each rank's tiles (32x32-pixel super-tile S belongs to rank S % world), padded with H*W (a dummy slot).
     CPU path only."""
-    gx = (W + 15) // 16
+    sgx = ((W + 15) // 16 + 1) // 2        # tiles are dealt in 2x2 super-tiles = 32x32-pixel blocks (csrc/raster_common.hpp tile_xy_is_mine)
     ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
-    owner = (((ys // 16) * gx + (xs // 16)) % world).reshape(-1)
+    owner = (((ys // 32) * sgx + (xs // 32)) % world).reshape(-1)
     per = [torch.nonzero(owner == r).squeeze(1) for r in range(world)]
     n_max = max(int(p.numel()) for p in per)
     table = torch.full((world, n_max), H * W, dtype=torch.int64)

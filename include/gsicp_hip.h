@@ -247,6 +247,17 @@ size_t gsicp_mapper_loss_scratch_bytes(int width, int height);
 int gsicp_mapper_loss(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
                       float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
                       char* scratch, void* stream);
+/* The same loss SHARDED over tile_mod ranks (multi-GPU mapper, section 4b): rank tile_rem works on the 32x32-pixel blocks it owns — block
+ * (bx, by) belongs to rank (by * ceil(W / 32) + bx) % tile_mod, which is exactly the 2x2 super-tile rule by which the rasteriser deals its
+ * tiles (tile_mod / tile_rem of gsicp_raster_forward), so the rank that blends a block also owns its loss gradient.  `image` / `depth` must
+ * hold the WHOLE rendered image (a block's SSIM windows and their gradient reach 10 pixels into the neighbouring blocks: after
+ * gsicp_tiles_unpack).  dL_dimage / dL_ddepth are written on the rank's own blocks only (the other pixels are left untouched and are not read
+ * by that rank's backward).  loss_out[4] receives this rank's SHARE of {loss, L1, SSIM mean, depth L1}: the sums over the ranks are the values
+ * gsicp_mapper_loss returns (the loss's constant lambda is split tile_mod ways).  One fused kernel + a one-workgroup sum.  tile_mod = 1 is
+ * gsicp_mapper_loss. */
+int gsicp_mapper_loss_sharded(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
+                              float lambda_dssim, float depth_weight, float d_max, int tile_mod, int tile_rem, float* loss_out,
+                              float* dL_dimage, float* dL_ddepth, char* scratch, void* stream);
 
 /* Keyframe selection for a captured (hipGraph) mapper iteration: copies the camera (viewmatrix 16, projmatrix 16, campos 3 floats)
  * and the two target images (gt_image (3,H,W), gt_depth (1,H,W)) of the chosen keyframe [REF mp_Mapper.py:205-217] into the fixed

@@ -16,9 +16,9 @@ from tests import util
 
 
 def _tile_mask(W, H, mod, rem):
-    ty, tx = np.meshgrid(np.arange(H) // 16, np.arange(W) // 16, indexing="ij")
-    tid = ty * ((W + 15) // 16) + tx
-    return torch.from_numpy((tid % mod) == rem)
+    sy, sx = np.meshgrid(np.arange(H) // 32, np.arange(W) // 32, indexing="ij")      # tiles are dealt in 2x2 super-tiles (32x32-pixel blocks)
+    sid = sy * (((W + 15) // 16 + 1) // 2) + sx
+    return torch.from_numpy((sid % mod) == rem)
 
 
 class _OracleRasterFn(torch.autograd.Function):
