@@ -220,7 +220,11 @@ def main():
     force_coll = world == 1 and os.environ.get("GSICP_BENCH_FORCE_COLLECTIVES") == "1"
     if force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -332,7 +336,10 @@ def main():
         means2D = torch.zeros_like(a["means3D"], requires_grad=True)
         depth, color, radii, used = rast(means3D=a["means3D"], means2D=means2D, shs=a["shs"], opacities=a["opacities"],
                                          scales=a["scales"], rotations=a["rotations"])
-        parts, g_color, g_depth = mapper_loss_and_grads(color, depth, gt_color, gt_depth, lambda_dssim=0.2)
+        shard = rast.loss_shard()        # N > 1: the loss is sharded with the tiles (this rank's 32x32 blocks)
+        parts, g_color, g_depth = mapper_loss_and_grads(color, depth, gt_color, gt_depth, lambda_dssim=0.2, tile_mod=shard[0], tile_rem=shard[1])
+        if shard[0] > 1:
+            rast.attach_loss_share(parts)
         torch.autograd.backward((color, depth), (g_color, g_depth))
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)

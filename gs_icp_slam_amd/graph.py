@@ -139,10 +139,16 @@ class MapperIterationGraph:
             a = self.activations(self.params, self.live_count) if self.live_count is not None else self.activations(self.params)
         depth, color, radii, used = self.rasterizer(means3D=a["means3D"], means2D=self._means2D, shs=a["shs"], opacities=a["opacities"],
                                                     scales=a["scales"], rotations=a["rotations"])
-        # the loss kernels produce dL/dimage and dL/ddepth directly: no autograd node, no ones_like / multiply launches
+        # the loss kernels produce dL/dimage and dL/ddepth directly: no autograd node, no ones_like / multiply launches.  Tile-sharded over several
+        # GPUs the loss is sharded with the tiles: this rank's 32x32 blocks only; its share of the four values travels inside the gradient exchange
+        shard = self.rasterizer.loss_shard() if hasattr(self.rasterizer, "loss_shard") else (1, 0)
         parts, g_color, g_depth = mapper_loss_and_grads(color, depth, self.gt_image, self.gt_depth, lambda_dssim=self.lambda_dssim,
-                                                        depth_weight=self.depth_weight, d_max=self.d_max)
+                                                        depth_weight=self.depth_weight, d_max=self.d_max, tile_mod=shard[0], tile_rem=shard[1])
+        if shard[0] > 1:
+            self.rasterizer.attach_loss_share(parts)
         torch.autograd.backward((color, depth), (g_color, g_depth))
+        if shard[0] > 1:
+            parts = self.rasterizer.summed_loss()
         self.screenspace_grad = self._means2D.grad     # (P,3) viewspace gradient of this iteration (densification statistics)
         self._means2D.grad = None
         self.optimizer.step()

@@ -125,7 +125,7 @@ def _static_exchange_cuda(grads, radii, holder, group):
     key = (P, tuple(widths), R, dev)
     if holder.static_key != key:
         holder.static_key = key
-        holder.packed = torch.zeros(R * Wt + 1, dtype=torch.float32, device=dev)
+        holder.packed = torch.zeros(R * Wt + 1 + 4, dtype=torch.float32, device=dev)   # rows | overflow flag | this rank's share of {loss, L1, SSIM, depth L1}
         holder.scratch = torch.zeros(int(lib.gsicp_rows_pack_scratch_bytes(P)), dtype=torch.uint8, device=dev)
         if holder.overflow is None:          # may already be bound to the optimiser (overflow_guard)
             holder.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -135,7 +135,11 @@ def _static_exchange_cuda(grads, radii, holder, group):
     with torch.cuda.device(dev):
         _lib.check(lib.gsicp_rows_pack(P, _p(radii), len(grads), ptrs, holder.c_widths, _p(holder.packed), R,
                                        _p(guard) if guard is not None else None, int(limit), _p(holder.scratch), _stream(dev)), "gsicp_rows_pack")
+        tail = holder.packed[R * Wt + 1:]
+        if holder.loss_share is not None:      # the sharded loss's four partial values ride along: their sums come back in the same words
+            tail.copy_(holder.loss_share)
         dist.all_reduce(holder.packed, op=dist.ReduceOp.SUM, group=group)
+        holder.loss_sum = tail
         _lib.check(lib.gsicp_rows_unpack(P, _p(radii), len(grads), ptrs, holder.c_widths, _p(holder.packed), R, _p(holder.scratch),
                                          _p(holder.overflow), _stream(dev)), "gsicp_rows_unpack")
     holder.last_volume_bytes = holder.packed.numel() * 4
@@ -159,14 +163,17 @@ def _static_exchange_torch(grads, radii, holder, group):
     n_vis = int(mask.sum())
     keep = mask & (pos < R)
     rows = torch.cat([g.reshape(P, -1) for g in grads], dim=1)
-    packed = torch.zeros(R * Wt + 1, dtype=rows.dtype, device=rows.device)
+    packed = torch.zeros(R * Wt + 1 + 4, dtype=rows.dtype, device=rows.device)
     packed[: R * Wt].view(R, Wt).index_copy_(0, pos[keep], rows[keep])
     guard, limit = holder.guard if holder.guard is not None else (None, 0)
-    packed[-1] = 1.0 if (n_vis > R or (guard is not None and int(guard.item()) > limit)) else 0.0
+    packed[R * Wt] = 1.0 if (n_vis > R or (guard is not None and int(guard.item()) > limit)) else 0.0
+    if holder.loss_share is not None:
+        packed[R * Wt + 1:] = holder.loss_share
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    holder.loss_sum = packed[R * Wt + 1:]
     if holder.overflow is None:
         holder.overflow = torch.zeros(1, dtype=torch.int32, device=rows.device)
-    holder.overflow.fill_(1 if float(packed[-1]) > 0 else 0)
+    holder.overflow.fill_(1 if float(packed[R * Wt]) > 0 else 0)
     out_rows = rows.clone()
     out_rows[keep] = packed[: R * Wt].view(R, Wt).index_select(0, pos[keep])
     holder.last_volume_bytes = packed.numel() * 4
@@ -243,6 +250,8 @@ class _Holder:
     vis_capacity = 0
     guard = None          # (int32[1] device tensor: this rank's duplicate count, its capacity) or None
     guard_requested = False   # overflow_guard() was handed out: the caller's optimiser skips overflowing steps on all ranks alike
+    loss_share = None     # this rank's share of {loss, L1, SSIM mean, depth L1} (sharded loss): summed over the ranks inside the gradient exchange
+    loss_sum = None       # ... and the sums, valid after the backward
     static_key = None
     packed = scratch = overflow = c_widths = None
 
@@ -269,6 +278,28 @@ class ShardedGaussianRasterizer(nn.Module):
     @property
     def collective(self):
         return self.world > 1 or self.force_collectives
+
+    def loss_shard(self):
+        """(tile_mod, tile_rem) for `mapper_loss_and_grads`: this rank computes the loss on the 32x32 blocks (= 2x2 super-tiles) it blends."""
+        return (self.world, self.rank) if self.world > 1 else (1, 0)
+
+    def attach_loss_share(self, parts):
+        """Hand over this rank's share of the four loss values (output of the sharded loss); they are summed over the ranks inside the next
+        backward's gradient exchange — no collective of their own — and `summed_loss()` returns the totals afterwards."""
+        self.holder.loss_share = parts
+        self.holder.loss_sum = None
+
+    def summed_loss(self):
+        """tensor([loss, L1, SSIM mean, depth L1]) of the whole image after the backward (static exchange: a view of the exchange block's tail;
+        the other exchange modes: a small all-reduce of their own, issued here)."""
+        h = self.holder
+        if h.loss_sum is None and h.loss_share is not None:
+            if self.collective:
+                h.loss_sum = h.loss_share.clone()
+                dist.all_reduce(h.loss_sum, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                h.loss_sum = h.loss_share
+        return h.loss_sum
 
     def overflow_guard(self):
         """(int32[1] device tensor, limit) for FusedAdam.set_overflow_guard when the static gradient exchange is on: the tensor is 1 after

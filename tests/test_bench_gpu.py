@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _bench(extra, env_extra):
     env = dict(os.environ, **env_extra)
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):     # other tests of this pytest process set rendezvous variables
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--repeats", "2", "--gaussians", "60000",
                           "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)

@@ -111,7 +111,7 @@ def _worker(rank, world, port, q):
     assert torch.equal(color, color_s) and torch.equal(depth, depth_s)
     for k in grads:
         assert torch.equal(grads_s[k], grads_d[k]), k
-    assert static.holder.last_volume_bytes == ((n_vis + 5) * 17 + 1) * 4 and int(static.holder.overflow.item()) == 0
+    assert static.holder.last_volume_bytes == ((n_vis + 5) * 17 + 1 + 4) * 4 and int(static.holder.overflow.item()) == 0   # rows | flag | 4 loss words
     flagged = ShardedGaussianRasterizer(_settings(cam), rasterizer_cls=_OracleRasterizer, vis_capacity=n_vis + 5)
     _run_flagged(flagged, g, target, trip=(rank == 1))      # only rank 1's duplicate lists "overflow"
     assert int(flagged.holder.overflow.item()) == 1, "an overflow on rank 1 must reach rank 0 through the flag word"

@@ -25,8 +25,8 @@ def _stream():
 
 @pytest.mark.parametrize("W,H,mod", [(176, 100, 3), (320, 200, 8), (64, 48, 1)])
 def test_tile_movers_compose_the_image_of_emulated_ranks(hip_lib, W, H, mod):
-    """Each emulated rank renders its tiles (tile % mod == rank) and packs them; the concatenation of the chunks (what all_gather_into_tensor
-    delivers) unpacks to exactly the single-GPU image, partial edge tiles included."""
+    """Each emulated rank renders its tiles (2x2 super-tile S % mod == rank) and packs them; the concatenation of the chunks (what
+    all_gather_into_tensor delivers) unpacks to exactly the single-GPU image, partial edge tiles and odd tile counts included."""
     from diff_gaussian_rasterization import GaussianRasterizer
     from gs_icp_slam_amd import _lib
     lib = _lib.load()
@@ -41,8 +41,8 @@ def test_tile_movers_compose_the_image_of_emulated_ranks(hip_lib, W, H, mod):
         return d.contiguous(), c.contiguous()
     d_full, c_full = render(util.make_settings(cam, [0.1, 0.2, 0.3]))
     n = int(lib.gsicp_tiles_chunk_floats(W, H, mod))
-    T = ((W + 15) // 16) * ((H + 15) // 16)
-    assert n == ((T + mod - 1) // mod) * 1024
+    n_super = (((W + 15) // 16 + 1) // 2) * (((H + 15) // 16 + 1) // 2)
+    assert n == 4 * ((n_super + mod - 1) // mod) * 1024
     gathered = torch.full((mod, n), float("nan"), device="cuda")
     for r in range(mod):
         d, c = render(util.make_settings(cam, [0.1, 0.2, 0.3], tile_mod=mod, tile_rem=r))
@@ -165,8 +165,8 @@ def test_captured_sharded_iteration_with_rccl_inside_equals_the_plain_graph(hip_
         assert not mg_b.overflowed() and mg_b.skipped_steps() == 0
         assert int(opt_b.state[params_b["means3D"]]["step"].item()) == len(schedule)
         sh_b = holders[0]
-        assert sh_b.holder.last_volume_bytes == (int(1.5 * n_vis) * 17 + 1) * 4        # xyz 3 + means2D 3 + opacity 1 + sh 3 + scale 3 + quat 4
-        assert sh_b.holder.last_image_bytes == ((W + 15) // 16) * ((H + 15) // 16) * 1024 * 4
+        assert sh_b.holder.last_volume_bytes == (int(1.5 * n_vis) * 17 + 1 + 4) * 4    # xyz 3 + means2D 3 + opacity 1 + sh 3 + scale 3 + quat 4 | flag | 4 loss words
+        assert sh_b.holder.last_image_bytes == 4 * (((W + 15) // 16 + 1) // 2) * (((H + 15) // 16 + 1) // 2) * 1024 * 4
         # too few rows: the all-reduced flag makes Adam skip every step; nothing moved, nothing counted
         assert mg_c.overflowed() and mg_c.skipped_steps() == len(schedule)
         assert int(opt_c.state[params_c["means3D"]]["step"].item()) == 0
@@ -174,3 +174,42 @@ def test_captured_sharded_iteration_with_rccl_inside_equals_the_plain_graph(hip_
             assert torch.equal(params_c[k], start[k]), k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,H,mod", [(176, 100, 3), (320, 200, 8), (1200, 680, 8)])
+def test_sharded_loss_of_emulated_ranks_sums_to_the_loss_and_owns_its_blocks_gradient(hip_lib, W, H, mod):
+    """gsicp_mapper_loss_sharded (one fused kernel on the rank's own 32x32 blocks): the ranks' shares of {loss, L1, SSIM mean, depth L1} sum to
+    what gsicp_mapper_loss returns, every rank's dL/dimage and dL/ddepth equal the full gradient BIT FOR BIT on the blocks it owns and are
+    zero elsewhere, and the owned blocks are exactly the rasteriser's own tiles (the same rank blends a block and owns its loss gradient)."""
+    from gs_icp_slam_amd.loss import mapper_loss_and_grads
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.rand((3, H, W), device="cuda", generator=gen)
+    gt = torch.rand((3, H, W), device="cuda", generator=gen)
+    dep = torch.rand((1, H, W), device="cuda", generator=gen) * 3
+    gtd = torch.rand((1, H, W), device="cuda", generator=gen) * 3
+    gtd[:, 10:30, 20:70] = 0.0          # a hole in the sensor depth: masked everywhere
+    parts, g_img, g_dep = mapper_loss_and_grads(img, dep, gt, gtd, lambda_dssim=0.2)
+    sgx = ((W + 15) // 16 + 1) // 2
+    ys, xs = torch.meshgrid(torch.arange(H, device="cuda"), torch.arange(W, device="cuda"), indexing="ij")
+    owner = ((ys // 32) * sgx + (xs // 32)) % mod
+    total = torch.zeros(4, device="cuda", dtype=torch.float64)
+    covered = torch.zeros((H, W), dtype=torch.bool, device="cuda")
+    for r in range(mod):
+        share, gi, gd = mapper_loss_and_grads(img, dep, gt, gtd, lambda_dssim=0.2, tile_mod=mod, tile_rem=r)
+        mine = owner == r
+        assert torch.equal(gi[:, mine], g_img[:, mine]) and torch.equal(gd[:, mine], g_dep[:, mine]), f"rank {r}: own-block gradient differs"
+        assert not bool(gi[:, ~mine].any()) and not bool(gd[:, ~mine].any()), f"rank {r} wrote outside its blocks"
+        total += share.double()
+        covered |= mine
+    assert bool(covered.all())
+    torch.testing.assert_close(total.float(), parts, rtol=2e-6, atol=1e-7)
+    # the rasteriser deals its tiles by the same rule: a tile-sharded render of rank r is non-zero only inside r's blocks
+    from diff_gaussian_rasterization import GaussianRasterizer
+    cam = synth.make_camera(W, H, 140.0, 140.0)
+    t = util.torch_inputs(synth.random_gaussians(400, seed=3))
+    for r in (0, mod - 1):
+        with torch.no_grad():
+            _d, c, _, _ = GaussianRasterizer(util.make_settings(cam, [0.3, 0.3, 0.3], tile_mod=mod, tile_rem=r))(
+                means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), shs=t["shs"], opacities=t["opacities"], scales=t["scales"],
+                rotations=t["rotations"])
+        assert bool((c[:, owner == r] > 0).all()) and not bool(c[:, owner != r].any())
