@@ -125,7 +125,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.gsicp_abi_version() != 3:
+        if lib.gsicp_abi_version() != 4:
             raise ImportError("libgsicp_hip.so ABI version mismatch")
         if os.environ.get("GSICP_ANNOUNCE"):   # tools/run_reference_slam.py: show which processes of the reference run loaded the library
             print(f"GSICP_LOADED {LIB_PATH} pid={os.getpid()}", flush=True)

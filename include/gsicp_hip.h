@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GSICP_ABI_VERSION 3
+#define GSICP_ABI_VERSION 4
 
 int gsicp_abi_version(void);
 const char* gsicp_last_error(void);
@@ -58,8 +58,10 @@ typedef char* (*gsicp_resize_fn)(void* user, size_t bytes);
  *   depth_mode selects the depth compositing rule — one of the three fork semantics the reference tree cannot settle (its rasteriser
  *   fork is an empty submodule): 0 = sum_i z_i alpha_i T_i (default; no normalisation, no background term),
  *   1 = alpha-normalised, sum_i z_i alpha_i T_i / (1 - T_final) (0 where nothing was blended).  Every reported number names the variant.
- *   tile_mod / tile_rem: this call blends only tiles with (tile_id % tile_mod) == tile_rem and leaves the other
- *   tiles' pixels untouched (multi-GPU tile sharding; pass 1, 0 for the whole image).
+ *   tile_mod / tile_rem: multi-GPU tile sharding (pass 1, 0 for the whole image).  Tiles are dealt round-robin in 2x2 SUPER-TILES: with
+ *   gx = ceil(W / 16), super-tile S = (ty / 2) * ceil(gx / 2) + tx / 2 of tile (tx, ty) belongs to rank S % tile_mod; this call blends only the
+ *   tiles of rank tile_rem and leaves the other tiles' pixels untouched.  (ABI version 4; versions <= 3 dealt single tiles, tile_id %
+ *   tile_mod.)  A super-tile is one 32x32-pixel block of gsicp_mapper_loss_sharded: the rank that blends a block owns its loss gradient.
  * Returns the number of (Gaussian, tile) duplicates binned for this call (the reference's `num_rendered`).
  * Synchronises `stream` once (to size the binning buffer), like the reference implementation. */
 int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
@@ -317,12 +319,13 @@ int gsicp_store_compact(int n, const unsigned char* keep, int n_arrays, const vo
                         void* scratch, int* n_out_dev, void* stream);
 
 /* --------------------------------------------------------------------------------------------------------
- * 4b. Multi-GPU mapper (not in the reference, which is single-GPU).  Rank r rasterises the tiles t with
- *     t % tile_mod == r (section 2's tile_mod / tile_rem); these four calls move what the two collectives carry, with static
+ * 4b. Multi-GPU mapper (not in the reference, which is single-GPU).  Rank r rasterises the tiles of the 2x2 super-tiles S
+ *     with S % tile_mod == r (section 2's tile_mod / tile_rem); these four calls move what the two collectives carry, with static
  *     sizes so that the whole iteration — RCCL calls included — can be captured in a hipGraph.  All pointers are DEVICE pointers.
  *
  *  image all-gather: gsicp_tiles_pack writes this rank's tiles as one chunk of gsicp_tiles_chunk_floats() floats, laid out
- *     [k = t / tile_mod][r, g, b, depth][256 pixels of the tile]; after an all-gather of the tile_mod chunks (rank order),
+ *     [slot k][r, g, b, depth][256 pixels of the tile], slot k = tile (k & 3) of the rank's (k >> 2)-th super-tile (slots past the image edge
+ *     are zero padding: 4 * ceil(n_super_tiles / tile_mod) slots); after an all-gather of the tile_mod chunks (rank order),
  *     gsicp_tiles_unpack writes every tile of the (3,H,W) colour and (1,H,W) depth images from the chunk of its owner.
  *  gradient all-reduce: radii (int[P], identical on every rank because every rank preprocesses all Gaussians) selects the rows
  *     with radii > 0; gsicp_rows_pack copies those rows of n_arrays (<= 8) row-major (P, row_width[a]) float arrays, in ascending
