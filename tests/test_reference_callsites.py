@@ -69,6 +69,72 @@ def test_reference_render_3_drives_the_drop_in_rasterizer(monkeypatch):
     assert (seen["rs"].image_height, seen["rs"].image_width) == (H // 2, W // 2)
 
 
+def _lift(name, eval_sh=None):
+    import diff_gaussian_rasterization as dgr
+    tree = ast.parse(open(REF).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    assert len(fn) == 1
+    ns = {"torch": torch, "math": math, "GaussianModel": object, "GaussianRasterizationSettings": dgr.GaussianRasterizationSettings,
+          "GaussianRasterizer": dgr.GaussianRasterizer, "eval_sh": eval_sh}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), REF, "exec"), ns)
+    return ns[name]
+
+
+@pytest.mark.parametrize("name", ["render", "render_2"])
+def test_reference_render_and_render_2_drive_the_drop_in_rasterizer(monkeypatch, name):
+    """The viewer / metric-pass entry points [REF gaussian_renderer/__init__.py:18-131 `render`, 133-216 `render_2`] — plain-number cameras,
+    `scaling_modifier`, and the optional Python-side paths (`pipe.compute_cov3D_python` -> cov3D_precomp, `pipe.convert_SHs_python` ->
+    colors_precomp through the reference's own eval_sh, `override_color`) — lifted unmodified and run against the drop-in package with a
+    recorder behind it.  (`render` also runs on the GPU in every reference run: the end-of-run metric pass [REF mp_Mapper.py:378] calls it.)"""
+    import sys
+    from gs_icp_slam_amd import rasterizer as R
+    sys.path.insert(0, "/root/reference")
+    try:
+        from utils.sh_utils import eval_sh
+    finally:
+        sys.path.remove("/root/reference")
+    fn = _lift(name, eval_sh=eval_sh)
+    P, H, W = 6, 40, 56
+    seen = {}
+
+    def recorder(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, count_out=None):
+        seen.update(means3D=means3D, means2D=means2D, sh=sh, colors_precomp=colors_precomp, opacities=opacities, scales=scales,
+                    rotations=rotations, cov3Ds_precomp=cov3Ds_precomp, rs=raster_settings)
+        return (torch.full((1, H, W), 3.0), torch.full((3, H, W), 0.25), torch.ones(P, dtype=torch.int32), torch.ones(P, dtype=torch.int32))
+
+    monkeypatch.setattr(R, "rasterize_gaussians", recorder)
+    zl = torch.zeros_like
+    monkeypatch.setattr(torch, "zeros_like", lambda t, **k: zl(t, **{kk: v for kk, v in k.items() if kk != "device"}))
+    cam = SimpleNamespace(FoVx=1.1, FoVy=0.8, image_width=W, image_height=H, world_view_transform=torch.eye(4),
+                          full_proj_transform=torch.eye(4) * 3, camera_center=torch.tensor([0.5, 1.0, 1.5]))
+    cov = torch.rand(P, 6)
+    pc = SimpleNamespace(get_xyz=torch.randn(P, 3), get_opacity=torch.rand(P, 1), get_scaling=torch.rand(P, 3), get_rotation=torch.randn(P, 4),
+                         get_features=torch.randn(P, 4, 3), active_sh_degree=1, max_sh_degree=1, get_covariance=lambda m: cov * m)
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    # 1. the default path: SHs and (scales, rotations) go to the rasteriser, scaling_modifier into the settings
+    out = fn(cam, pc, SimpleNamespace(debug=True, compute_cov3D_python=False, convert_SHs_python=False), bg, 0.7)
+    rs = seen["rs"]
+    assert (rs.image_height, rs.image_width, rs.sh_degree, rs.scale_modifier, rs.debug) == (H, W, 1, 0.7, True)
+    assert rs.tanfovx == math.tan(0.55) and rs.tanfovy == math.tan(0.4)
+    assert seen["sh"] is pc.get_features and seen["scales"] is pc.get_scaling and seen["rotations"] is pc.get_rotation
+    assert seen["colors_precomp"] is None and seen["cov3Ds_precomp"] is None
+    assert float(out["render"][0, 0, 0]) == 0.25 and float(out["render_depth"][0, 0, 0]) == 3.0 and out["is_used"].shape == (P,)
+    # 2. Python-side covariance and SH evaluation: the precomputed forms reach the drop-in, the others are None
+    fn(cam, pc, SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True), bg, 2.0)
+    assert torch.equal(seen["cov3Ds_precomp"], cov * 2.0) and seen["scales"] is None and seen["rotations"] is None
+    assert seen["sh"] is None and seen["colors_precomp"].shape == (P, 3) and float(seen["colors_precomp"].min()) >= 0.0
+    d = pc.get_xyz - cam.camera_center
+    want = torch.clamp_min(eval_sh(1, pc.get_features.transpose(1, 2).view(-1, 3, 4), d / d.norm(dim=1, keepdim=True)) + 0.5, 0.0)
+    assert torch.equal(seen["colors_precomp"], want)
+    # 3. override_color
+    oc = torch.rand(P, 3)
+    fn(cam, pc, SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False), bg, 1.0, oc)
+    assert seen["colors_precomp"] is oc and seen["sh"] is None
+    if name == "render_2":      # the coarse-to-fine stage sizes
+        fn(cam, pc, SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False), bg, 1.0, None, 2)
+        assert (seen["rs"].image_height, seen["rs"].image_width) == (H // 4, W // 4)
+
+
 def test_reference_argument_errors_are_the_upstream_ones():
     import diff_gaussian_rasterization as dgr
     rs = dgr.GaussianRasterizationSettings(image_height=4, image_width=4, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3), scale_modifier=1.0,
