@@ -341,12 +341,56 @@ __device__ inline void bitonic_pairs(unsigned long long* __restrict__ s_key, uin
 constexpr int SORT_SMALL = 1024;   // LDS capacity of the sort kernel: 256 threads (one wave does all the work of a <= 128-entry list; the others only meet
                                    // it at three barriers), 12 KB LDS -> many workgroups per CU.  With the pair-per-thread network a 1024-entry list costs
                                    // ~6 us; longer lists (none in the BASELINE scenes) take the chunk-sort + rank-merge path below
+// Exact block bits (round 3).  emit_one sets a block's bit when the BOUNDING BOX of the splat's alpha >= 1/255 footprint touches the block;
+// here, one thread per list entry, every set bit is re-tested against the footprint itself: the ellipse q(d) = ca dx^2 + 2 cb dx dy + cc dy^2
+// <= 2 tau (tau = ln(255 opacity) + 0.01: the 1 % pad in alpha that the box uses, far above any fp32 / exp rounding) meets the block iff the
+// minimum of q over the rectangle of the block's pixel centres is <= 2 tau — the centre lies inside, or the minimum sits on one of the four
+// edges (a clamped 1-D parabola each).  Conservative by construction (a continuous rectangle contains its 64 pixel centres), so the per-pixel
+// tests still decide everything; it only removes (block, entry) pairs no pixel would accept: 1.25 instead of 1.60 per list entry on the
+// benchmark scene (the pixel-exact count is 1.250) — a fifth of the blend kernels' evaluations.
+__device__ inline uint32_t refine_block_bits(const uint32_t word, const SplatRec& r, const float tile_x0, const float tile_y0) {
+    uint32_t bits = word >> STRIP_SHIFT;
+    if (bits == 0u) return word;
+    const float two_tau = 2.f * (__logf(255.f * r.opacity) + 0.01f);
+    const float inv_ca = __builtin_amdgcn_rcpf(r.ca), inv_cc = __builtin_amdgcn_rcpf(r.cc);
+    uint32_t out = 0u;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (!((bits >> b) & 1u)) continue;
+        const float x0 = tile_x0 + (float)((b & 1) * 8), y0 = tile_y0 + (float)((b >> 1) * 8);
+        // d = splat centre - pixel; over the block dx in [dx_lo, dx_hi], dy in [dy_lo, dy_hi]
+        const float dx_hi = r.px - x0, dx_lo = dx_hi - 7.f, dy_hi = r.py - y0, dy_lo = dy_hi - 7.f;
+        bool hit = dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f;     // the centre is inside the block: q = 0 there
+        if (!hit) {
+            float qmin = 3.4e38f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {        // vertical edges dx = const: the parabola in dy has its vertex at -cb dx / cc
+                const float dx = e ? dx_hi : dx_lo;
+                float dy = -r.cb * dx * inv_cc;
+                dy = fminf(fmaxf(dy, dy_lo), dy_hi);
+                qmin = fminf(qmin, r.ca * dx * dx + 2.f * r.cb * dx * dy + r.cc * dy * dy);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {        // horizontal edges dy = const
+                const float dy = e ? dy_hi : dy_lo;
+                float dx = -r.cb * dy * inv_ca;
+                dx = fminf(fmaxf(dx, dx_lo), dx_hi);
+                qmin = fminf(qmin, r.ca * dx * dx + 2.f * r.cb * dx * dy + r.cc * dy * dy);
+            }
+            hit = qmin <= two_tau;
+        }
+        if (hit) out |= 1u << b;
+    }
+    return (word & ID_MASK) | (out << STRIP_SHIFT);
+}
+
 template <int CAP, int THREADS, int MIN_N>
 __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uint32_t* __restrict__ s_val, const uint32_t tile,
                                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ sc_keys, const uint32_t* __restrict__ sc_vals,
                                      const uint32_t* __restrict__ entry_gauss, uint32_t* __restrict__ point_list,
-                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ list_gauss) {
+                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ list_gauss, const SplatRec* __restrict__ rec, const int gx) {
     const uint2 range = ranges[tile];
+    const float tile_x0 = (float)((int)(tile % (uint32_t)gx) * TILE), tile_y0 = (float)((int)(tile / (uint32_t)gx) * TILE);
     const int n = (int)(range.y - range.x);
     if (n <= MIN_N) return;   // (MIN_N > 0: a size class that leaves the short lists to another launch; not used by the shipped path)
     const int tid = threadIdx.x;
@@ -396,7 +440,7 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
                 }
                 rank += lo;
             }
-            point_list[range.x + rank] = v;
+            point_list[range.x + rank] = refine_block_bits(v, rec[gid], tile_x0, tile_y0);
             tile_keys[range.x + rank] = tile;
             list_gauss[range.x + rank] = gid;
         }
@@ -419,9 +463,10 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
     bitonic_pairs<THREADS>(s_key, s_val, npad, tid);
     __syncthreads();
     for (int i = tid; i < n; i += THREADS) {
-        point_list[range.x + i] = s_val[i];
+        const uint32_t gid = (uint32_t)s_key[i];        // low word of the sort key = Gaussian id
+        point_list[range.x + i] = refine_block_bits(s_val[i], rec[gid], tile_x0, tile_y0);
         tile_keys[range.x + i] = tile;
-        list_gauss[range.x + i] = (uint32_t)s_key[i];   // low word of the sort key = Gaussian id
+        list_gauss[range.x + i] = gid;
     }
 }
 // One workgroup per tile of the LPT order (grid-stride, so a smaller persistent grid also works; `limit_dev`, optional, bounds the
@@ -431,13 +476,13 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int n_tiles, const u
                                                             const uint2* __restrict__ ranges, const uint32_t* __restrict__ sc_keys,
                                                             const uint32_t* __restrict__ sc_vals, const uint32_t* __restrict__ entry_gauss,
                                                             uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
-                                                            uint32_t* __restrict__ list_gauss) {
+                                                            uint32_t* __restrict__ list_gauss, const SplatRec* __restrict__ rec, int gx) {
     __shared__ unsigned long long s_key[CAP];
     __shared__ uint32_t s_val[CAP];
     int limit = n_tiles;
     if (limit_dev) { const int l = (int)*limit_dev; limit = l < limit ? l : limit; }
     for (int bi = blockIdx.x; bi < limit; bi += gridDim.x) {
-        tile_sort_one<CAP, THREADS, MIN_N>(s_key, s_val, order[bi], ranges, sc_keys, sc_vals, entry_gauss, point_list, tile_keys, list_gauss);
+        tile_sort_one<CAP, THREADS, MIN_N>(s_key, s_val, order[bi], ranges, sc_keys, sc_vals, entry_gauss, point_list, tile_keys, list_gauss, rec, gx);
         __syncthreads();   // the LDS arrays are reused by the next list
     }
 }
@@ -924,7 +969,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
         { ProfileScope ps(ST_TILE_SORT, stream);
           hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 256, 0>), dim3(n_local), dim3(256), 0, stream, n_local, (const uint32_t*)nullptr, order, ranges,
                              (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
-                             (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss)); }
+                             (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss), (const SplatRec*)rec, gx); }
     }
 
     BlendArgs ba;
