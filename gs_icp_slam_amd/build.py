@@ -78,7 +78,31 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     build_experiments(force=force, verbose=verbose)
+    build_pybind_module(force=force, verbose=verbose)
     return OUT
+
+
+def build_pybind_module(force=False, verbose=True):
+    """integration/pygicp_pybind.cpp -> integration/pygicp.<abi>.so: a COMPILED `pygicp` module (PyInit_pygicp) over the C ABI
+    (INTEGRATION.md 3.2); it opens libgsicp_hip.so at import (after torch, like the ctypes mirror) instead of linking it.
+    Plain g++ + pybind11: no HIP code in the binding."""
+    import sysconfig
+    try:
+        import pybind11
+    except ImportError:
+        return None
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "integration", "pygicp_pybind.cpp")
+    if not os.path.exists(src):
+        return None
+    out = os.path.join(root, "integration", "pygicp" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if force or _newer(out, [src, os.path.join(root, "include", "gsicp_hip.h"), OUT]):
+        cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}",
+               src, "-o", out, "-ldl"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
 
 
 def build_experiments(force=False, verbose=True):

@@ -57,3 +57,13 @@ def test_untouched_reference_two_process_run_tum_layout_and_flags():
     assert 24.0 < res["system_fps"] <= 30.5, res["system_fps"]
     assert res["ate_rmse_cm"] < 0.30, res["ate_rmse_cm"]     # the real fr1_desk figure of the paper is 2.7 cm; this is the analytic room + the noise model
     assert res["psnr"] > 17.0 and res["ssim"] > 0.76, (res["psnr"], res["ssim"])
+
+
+def test_untouched_reference_runs_on_the_compiled_pygicp_module():
+    """`import pygicp` [REF mp_Tracker.py:10] resolving to the COMPILED pybind11 module (PyInit_pygicp, integration/pygicp_pybind.cpp) instead of
+    the ctypes mirror: the tracker process of the unmodified reference drives it through the numpy API, it pickles into the spawned process
+    [REF gs_icp_slam.py:121-127], and the trajectory is tracked as with the mirror."""
+    res = _run(["--synthetic", "40", "--compiled-pygicp"])
+    assert res["pygicp_binding"].startswith("compiled"), res
+    assert res["processes_that_loaded_it"] >= 3
+    assert res["ate_rmse_cm"] <= 0.03, res["ate_rmse_cm"]

@@ -54,7 +54,7 @@ def flags_for(config, shape=None):
     return dict(TUM_FLAGS if (dataset_type(config) == "tum" or shape == "tum") else REPLICA_FLAGS)
 
 
-def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_flags=(), flags=None, trace_dir=None, omp_threads=1):
+def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_flags=(), flags=None, trace_dir=None, omp_threads=1, compiled_pygicp=False):
     name = "gs_icp_slam_unlimit" if unlimit else "gs_icp_slam"
     script = os.path.join(reference, name + ".py")
     if not os.path.exists(script):
@@ -66,7 +66,10 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
         cmd += [f"--{k}", str(v)]
     cmd += list(extra_flags)
     env = dict(os.environ)
-    env["PYTHONPATH"] = os.pathsep.join([ROOT] + [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p] +
+    # --compiled-pygicp: `import pygicp` resolves to integration/pygicp.<abi>.so (PyInit_pygicp, the pybind11 binding over the C ABI) instead of the
+    # ctypes mirror package at the repo root
+    front = [os.path.join(ROOT, "integration")] if compiled_pygicp else []
+    env["PYTHONPATH"] = os.pathsep.join(front + [ROOT] + [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p] +
                                         [os.path.join(ROOT, "tests", "refstubs")])
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MPLBACKEND", "Agg")
@@ -95,6 +98,7 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
         timed_out = True
     res = dict(returncode=p.returncode, timed_out=timed_out, wall_s=round(time.time() - t0, 2), script=os.path.basename(script),
                reference=reference, loaded_so=sorted(set(re.findall(r"GSICP_LOADED (\S+)", out))),
+               pygicp_binding=("compiled pybind11 module (integration/pygicp.*.so)" if re.search(r"via=compiled-pygicp", out) else "ctypes mirror (pygicp/)"),
                processes_that_loaded_it=len(set(re.findall(r"GSICP_LOADED \S+ pid=(\d+)", out))))
     for key, pat in (("system_fps", r"System FPS:\s*([-\d.eE+naninf]+)"), ("ate_rmse_cm", r"ATE RMSE:\s*([-\d.eE+naninf]+)"),
                      ("psnr", r"PSNR:\s*([-\d.eE+naninf]+)"), ("ssim", r"SSIM:\s*([-\d.eE+naninf]+)")):
@@ -121,6 +125,8 @@ def main():
     ap.add_argument("--trace", default=None, help="directory for the drop-in call trace (GSICP_CALL_TRACE): one file per process")
     ap.add_argument("--omp-threads", type=int, default=1, help="OMP_NUM_THREADS for the reference's processes (0 = leave the environment alone)")
     ap.add_argument("--log", default=None, help="write the reference's full stdout here")
+    ap.add_argument("--compiled-pygicp", action="store_true", help="let the reference's `import pygicp` resolve to the compiled pybind11 module "
+                    "integration/pygicp.<abi>.so instead of the ctypes mirror package")
     a = ap.parse_args()
     ref = find_reference(a.reference)
     if ref is None:
@@ -156,7 +162,8 @@ def main():
     if not a.config:
         a.config = os.path.join(ref, "configs", "Replica", "caminfo.txt")
     out_dir = a.output or tempfile.mkdtemp(prefix="gsicp_out_")
-    res, log = run(ref, a.dataset, a.config, out_dir, unlimit=not a.limit30, timeout=a.timeout, flags=flags, trace_dir=a.trace, omp_threads=a.omp_threads)
+    res, log = run(ref, a.dataset, a.config, out_dir, unlimit=not a.limit30, timeout=a.timeout, flags=flags, trace_dir=a.trace, omp_threads=a.omp_threads,
+                   compiled_pygicp=a.compiled_pygicp)
     res.update(status="measured" if res["returncode"] == 0 and res["system_fps"] is not None else "failed", dataset=a.dataset,
                data="synthetic" if a.synthetic else "real", frames=a.synthetic or None, dataset_type=dataset_type(a.config),
                flags=flags or flags_for(a.config), entry="gs_icp_slam.py (30 FPS cap)" if a.limit30 else "gs_icp_slam_unlimit.py")
