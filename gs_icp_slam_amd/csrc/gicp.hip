@@ -1212,6 +1212,7 @@ __device__ inline bool is_converged_wave(const double* R, const double* t, doubl
 }
 struct AlignShared {
     double scratch[AL_T / 64][NRED + 1];
+    double chunk[8][32];   // partial sums of an eighth of the workgroups each (grid_sum)
     double red[NRED + 1];
     double x0[12];      // current pose R,t
     double xi[12];      // trial pose
@@ -1332,15 +1333,29 @@ __device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, un
     }
     __syncthreads();
     if (trace) trace_stamp(trace, *trace_n, 11);   // barrier passed
-    if (tid < NV) {
+    // All 256 threads fetch: thread (k = tid & 31, c = tid >> 5) adds the partials of value k over the c-th eighth of the workgroups, in
+    // workgroup order; then the eight chunk sums are added in chunk order.  ONE round of loads in flight instead of ceil(nwg / 8) dependent
+    // rounds on 29 threads (1.6 -> ~0.9 us of every phase); the order is fixed, so every workgroup still holds the same bits.
+    {
+        const int k = tid & 31, c = tid >> 5, per = (nwg + 7) >> 3;
         double s = 0;
-        for (int w0 = 0; w0 < nwg; w0 += 8) {   // eight loads in flight, added in workgroup order (same sum, an eighth of the latency)
-            double v[8];
+        if (k < NV) {
+            const int w_lo = c * per, w_hi = (w_lo + per) < nwg ? (w_lo + per) : nwg;
+            for (int w0 = w_lo; w0 < w_hi; w0 += 8) {     // one trip for up to 64 workgroups
+                double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (w0 + u < nwg) ? sy->partials[buf][w0 + u][tid] : 0.0;
+                for (int u = 0; u < 8; ++u) v[u] = (w0 + u < w_hi) ? sy->partials[buf][w0 + u][k] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (w0 + u < nwg) s += v[u];
+                for (int u = 0; u < 8; ++u) if (w0 + u < w_hi) s += v[u];
+            }
+            sh.chunk[c][k] = s;
         }
+    }
+    __syncthreads();
+    if (tid < NV) {
+        double s = sh.chunk[0][tid];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) s += sh.chunk[c][tid];
         sh.red[tid] = s;
     }
     __syncthreads();
