@@ -25,12 +25,6 @@ constexpr uint32_t ID_MASK = 0x0FFFFFFFu;
 constexpr int STRIP_SHIFT = 28;
 constexpr int NGRAD = 10;    // mean2D x,y | conic a,b,c | opacity | colour r,g,b | depth
 constexpr int SLOT_F = 12;   // floats per emission-slot gradient record: NGRAD + 2 pad = three float4
-// Segmented (checkpointed) backward: the forward saves every pixel's blend state (T, C_r, C_g, C_b, D) each SEG list entries, so that the
-// backward can treat every SEG-entry segment of a tile list as an independent work item (no dependent chain longer than SEG entries, no
-// straggler tiles).  A tile of L entries has ceil(L / SEG) segments and ceil(L / SEG) - 1 checkpoints.
-constexpr int SEG = 128;
-constexpr int CK_F = 5;      // floats per pixel and checkpoint
-
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // Multi-GPU tile ownership (tile_mod = number of ranks, tile_rem = this rank): tiles are dealt round-robin in 2x2 GROUPS — super-tile
@@ -58,9 +52,9 @@ __host__ __device__ inline int tile_chunk_slots(int gx, int gy, int tile_mod) {
 
 // Section offsets inside the three torch-owned scratch buffers.
 struct GeomLayout { size_t records, clamped, slot_base, tiles_touched, total; };
-struct BinLayout { size_t point_list, tile_keys, list_gauss, entry_gauss, entry_bits, emit_tile, emit_depth, scatter_keys, scatter_vals, block_hist, seg_work, ckpt, total; };
+struct BinLayout { size_t point_list, tile_keys, list_gauss, entry_gauss, entry_bits, emit_tile, emit_depth, scatter_keys, scatter_vals, block_hist, total; };
 constexpr int SPLIT_BLOCKS_MAX = 128;   // workgroups of the tile multi-split (each owns a contiguous chunk of emission slots)
-struct ImgLayout { size_t ranges, final_T, n_contrib, order, tile_count, ckpt_base, total; };
+struct ImgLayout { size_t ranges, final_T, n_contrib, order, tile_count, total; };
 
 inline GeomLayout geom_layout(int P) {
     GeomLayout L;
@@ -87,8 +81,6 @@ inline BinLayout bin_layout(size_t R, size_t T) {
     L.scatter_keys = o; o = align_up(o + Rp * 4);     // forward-only: depth bits in scatter order
     L.scatter_vals = o; o = align_up(o + Rp * 4);     // forward-only: list words in scatter order
     L.block_hist = o; o = align_up(o + (size_t)SPLIT_BLOCKS_MAX * (T > 0 ? T : 1) * 4);   // forward-only: per-(split block, tile) counts
-    L.seg_work = o; o = align_up(o + ((T > 0 ? T : 1) + Rp / SEG + 1) * 8);               // backward work items (tile, segment): <= T + R / SEG
-    L.ckpt = o; o = align_up(o + (Rp / SEG + 1) * (size_t)CK_F * TILE_PIX * 4);           // forward -> backward: per-pixel blend state at every SEG-th entry of a tile list
     L.total = o;
     return L;
 }
@@ -101,8 +93,7 @@ inline ImgLayout img_layout(int W, int H) {
     L.final_T = o; o = align_up(o + HW * 4);
     L.n_contrib = o; o = align_up(o + HW * 4);
     L.order = o; o = align_up(o + T * 4);             // this rank's tiles, longest list first (LPT dispatch order)
-    L.tile_count = o; o = align_up(o + (2 * T + 64) * 4);   // per-tile counts, cursors, 64 counters ([0] = R, [1] = number of backward work items)
-    L.ckpt_base = o; o = align_up(o + T * 4);         // first checkpoint of each tile in BinLayout::ckpt (its ceil(L / SEG) - 1 checkpoints are contiguous)
+    L.tile_count = o; o = align_up(o + (2 * T + 64) * 4);   // per-tile counts, cursors, 64 counters ([0] = R)
     L.total = o;
     return L;
 }
