@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -2466,29 +2467,49 @@ int gsicp_gicp_barrier_retries(gsicp_gicp* g) { return g->barrier_retries; }
 int gsicp_gicp_get_final_hessian(gsicp_gicp* g, double out[36]) { std::memcpy(out, g->host_result.H_final, sizeof(double) * 36); return 0; }
 
 
-// simple_knn._C.distCUDA2: out[i] = mean squared distance from point i to its 3 nearest other points (f32).  Asynchronous on `stream`
-// after the first call (scratch grows with hipMalloc); one scratch set per process, guarded by a mutex (the function is off the SLAM loop:
-// the reference calls it at most when a map is created from a point cloud [REF scene/gaussian_model.py:20]).
+// simple_knn._C.distCUDA2: out[i] = mean squared distance from point i to its 3 nearest other points (f32).  Asynchronous on `stream`.
+// Scratch is kept per DEVICE (a multi-device process must not run device 1's kernels on device 0's buffers) and guarded for use from several
+// streams: every call records an event behind its last kernel; a call on another stream waits for that event before it touches
+// the buffers, and a call that has to grow them first waits for the device (hipFree of memory a queued kernel still reads is only safe after
+// that).  The function is off the SLAM loop — the reference calls it at most when a map is created from a point cloud
+// [REF scene/gaussian_model.py:20] — so the mutex simply serialises the enqueue.
+namespace {
+struct Knn3Scratch {
+    DevBuf<float4> pts, sorted;
+    DevBuf<int> cell_of;
+    DevBuf<unsigned> count, start, fill;
+    DevBuf<KnnGrid> params;
+    hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+};
+}  // namespace
 int gsicp_knn_dist2(int P, const float* points, float* out, void* stream_v) {
     if (P < 0) { g_last_error = "gsicp_knn_dist2: negative size"; return -2; }
     if (P == 0) return 0;
     if (!points || !out) { g_last_error = "gsicp_knn_dist2: null pointer"; return -2; }
     static std::mutex mu;
-    static DevBuf<float4> pts, sorted;
-    static DevBuf<int> cell_of;
-    static DevBuf<unsigned> count, start, fill;
-    static DevBuf<KnnGrid> params;
+    static std::map<int, Knn3Scratch> per_device;
     std::lock_guard<std::mutex> lk(mu);
     hipStream_t stream = (hipStream_t)stream_v;
-    if (pts.ensure((size_t)P) || sorted.ensure((size_t)P) || cell_of.ensure((size_t)P) || count.ensure(KNN_MAX_CELLS + 1) ||
-        start.ensure(KNN_MAX_CELLS + 1) || fill.ensure(KNN_MAX_CELLS + 1) || params.ensure(1)) { g_last_error = "hipMalloc failed"; return -1; }
-    hipLaunchKernelGGL(knn3_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, pts.p);
-    hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, stream, P, pts.p, KNN_H_AREA, KNN_H_VOL, params.p, count.p);
-    hipLaunchKernelGGL(knn_count_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, pts.p, params.p, cell_of.p, count.p);
-    hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, stream, params.p, count.p, start.p, fill.p);
-    hipLaunchKernelGGL(knn_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, pts.p, cell_of.p, fill.p, sorted.p);
-    hipLaunchKernelGGL(knn3_grid_kernel, dim3((P + 3) / 4), dim3(256), 0, stream, P, pts.p, params.p, start.p, sorted.p, out);
+    int dev = 0;
+    GC(hipGetDevice(&dev));
+    Knn3Scratch& k = per_device[dev];
+    if (!k.done) GC(hipEventCreateWithFlags(&k.done, hipEventDisableTiming));
+    const bool grow = (size_t)P > k.pts.cap || (size_t)P > k.sorted.cap || (size_t)P > k.cell_of.cap || k.count.cap < (size_t)KNN_MAX_CELLS + 1 || k.params.cap < 1;
+    if (k.used && grow) GC(hipDeviceSynchronize());                                     // nothing queued may still read what is about to be freed
+    else if (k.used && k.last_stream != stream) GC(hipStreamWaitEvent(stream, k.done, 0));   // another stream's call owns the buffers until its kernels are done
+    if (k.pts.ensure((size_t)P) || k.sorted.ensure((size_t)P) || k.cell_of.ensure((size_t)P) || k.count.ensure(KNN_MAX_CELLS + 1) ||
+        k.start.ensure(KNN_MAX_CELLS + 1) || k.fill.ensure(KNN_MAX_CELLS + 1) || k.params.ensure(1)) { g_last_error = "hipMalloc failed"; return -1; }
+    hipLaunchKernelGGL(knn3_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, k.pts.p);
+    hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, stream, P, k.pts.p, KNN_H_AREA, KNN_H_VOL, k.params.p, k.count.p);
+    hipLaunchKernelGGL(knn_count_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, k.pts.p, k.params.p, k.cell_of.p, k.count.p);
+    hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, stream, k.params.p, k.count.p, k.start.p, k.fill.p);
+    hipLaunchKernelGGL(knn_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, k.pts.p, k.cell_of.p, k.fill.p, k.sorted.p);
+    hipLaunchKernelGGL(knn3_grid_kernel, dim3((P + 3) / 4), dim3(256), 0, stream, P, k.pts.p, k.params.p, k.start.p, k.sorted.p, out);
     GC(hipGetLastError());
+    GC(hipEventRecord(k.done, stream));
+    k.last_stream = stream; k.used = true;
     return 0;
 }
 

@@ -54,3 +54,22 @@ def test_dist2_duplicates_surfaces_and_full_size():
     d[np.arange(300), sample] = np.inf
     want = np.sort(d, axis=1)[:, :3].sum(1) / 3.0
     np.testing.assert_allclose(got_big.cpu().numpy()[sample], want, rtol=1e-5)
+
+
+def test_dist2_from_two_streams_back_to_back():
+    """the scratch of distCUDA2 is per device and guarded by an event, so calls on DIFFERENT streams (the first still queued, the second
+    growing the buffers) neither race on the buffers nor free memory a queued kernel reads."""
+    import oracle
+    import torch
+    from simple_knn._C import distCUDA2
+    rng = np.random.default_rng(5)
+    clouds = [rng.normal(size=(n, 3)).astype(np.float32) for n in (3000, 90000, 700, 40000)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for i, c in enumerate(clouds):
+        with torch.cuda.stream(streams[i % 2]):
+            t = torch.from_numpy(c).cuda(non_blocking=True)
+            outs.append((t, distCUDA2(t)))           # nothing synchronises between the calls
+    torch.cuda.synchronize()
+    for c, (_t, o) in zip(clouds, outs):
+        np.testing.assert_allclose(o.cpu().numpy(), oracle.knn_dist2(c), rtol=1e-5, atol=1e-9)
