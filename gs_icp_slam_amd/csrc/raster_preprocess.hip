@@ -406,10 +406,12 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
         gs[4] = -0.5f * hyy * r.opacity;
     }
     a.dL_dmean2D[3 * i] = gs[0]; a.dL_dmean2D[3 * i + 1] = gs[1]; a.dL_dmean2D[3 * i + 2] = 0.f;
-    a.dL_dconic[4 * i] = gs[2]; a.dL_dconic[4 * i + 1] = gs[3]; a.dL_dconic[4 * i + 2] = gs[4]; a.dL_dconic[4 * i + 3] = 0.f;
+    // dL_dconic, dL_ddepths, dL_dcolors (when SHs are used) and dL_dcov3D (when scales / rotations are used) are intermediate results the caller
+    // only needs for inspection: a NULL pointer skips their 56 B per Gaussian of writes (round 3)
+    if (a.dL_dconic) { a.dL_dconic[4 * i] = gs[2]; a.dL_dconic[4 * i + 1] = gs[3]; a.dL_dconic[4 * i + 2] = gs[4]; a.dL_dconic[4 * i + 3] = 0.f; }
     a.dL_dopacity[i] = (a.raw_params && visible) ? gs[5] * r_early.opacity * (1.f - r_early.opacity) : gs[5];   // sigmoid' = o (1 - o)
-    a.dL_dcolors[3 * i] = gs[6]; a.dL_dcolors[3 * i + 1] = gs[7]; a.dL_dcolors[3 * i + 2] = gs[8];
-    a.dL_ddepths[i] = gs[9];
+    if (a.dL_dcolors) { a.dL_dcolors[3 * i] = gs[6]; a.dL_dcolors[3 * i + 1] = gs[7]; a.dL_dcolors[3 * i + 2] = gs[8]; }
+    if (a.dL_ddepths) a.dL_ddepths[i] = gs[9];
     if (visible) {
         Cam cam;
         load_cam(a.view, a.proj, cam);
@@ -531,8 +533,10 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) a.dL_dmeans3D[3 * i + k] = dm[k];
+    if (a.dL_dcov3D) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = dcov[k];
+        for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * i + k] = dcov[k];
+    }
     if (a.raw_params && visible && !a.cov3D_precomp) {
         // chain rule of the activations (as activations_backward_kernel): exp' = s;  normalize: (g - y (y . g)) / n above the 1e-12 clamp
 #pragma unroll

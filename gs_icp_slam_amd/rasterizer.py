@@ -159,12 +159,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_depth = _f32c(grad_depth, dev) if grad_depth is not None else None
             f32 = dict(dtype=torch.float32, device=dev)
             dL_dmeans2D = torch.empty((P, 3), **f32)
-            dL_dconic = torch.empty((P, 4), **f32)
+            dL_dconic = None                                       # intermediate results nobody reads: NULL skips their writes (56 B per Gaussian)
             dL_dopacity = torch.empty((P, 1), **f32)
-            dL_dcolors = torch.empty((P, 3), **f32)
-            dL_ddepths = torch.empty((P,), **f32)
+            dL_dcolors = torch.empty((P, 3), **f32) if col_c is not None else None
+            dL_ddepths = None
             dL_dmeans3D = torch.empty((P, 3), **f32)
-            dL_dcov3D = torch.empty((P, 6), **f32)
+            dL_dcov3D = torch.empty((P, 6), **f32) if cov_c is not None else None
             dL_dsh = torch.empty((P, M, 3), **f32) if sh_c is not None else None
             dL_dscales = torch.empty((P, 3), **f32) if sc_c is not None else None
             dL_drots = torch.empty((P, 4), **f32) if rot_c is not None else None

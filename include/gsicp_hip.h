@@ -109,8 +109,9 @@ size_t gsicp_raster_backward_scratch_bytes(int num_rendered, int width, int heig
  * depth_mode 1 `out_depth` must be the depth image that forward produced (may be NULL otherwise).
  * No atomics are used: gradients are bit-reproducible from run to run.
  * Gradient outputs (all DEVICE, all fully overwritten): dL_dmeans2D (P,3) [x,y in NDC-scaled units, z = 0],
- * dL_dconic (P,4) scratch, dL_dopacity (P), dL_dcolors (P,3), dL_ddepths (P) scratch, dL_dmeans3D (P,3),
- * dL_dcov3D (P,6), dL_dsh (P,M,3; may be NULL when colors_precomp is used), dL_dscales (P,3), dL_drots (P,4).
+ * dL_dopacity (P), dL_dmeans3D (P,3), dL_dsh (P,M,3; may be NULL when colors_precomp is used), dL_dscales (P,3), dL_drots (P,4);
+ * intermediate results, each may be NULL (its writes are then skipped): dL_dconic (P,4), dL_ddepths (P), dL_dcolors (P,3) [needed when
+ * colors_precomp is the input], dL_dcov3D (P,6) [needed when cov3D_precomp is the input].
  * Asynchronous on `stream`. */
 int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* background, int width, int height,
                           const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
