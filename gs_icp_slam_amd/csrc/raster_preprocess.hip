@@ -239,8 +239,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
             }
         }
     }
-    if (!ok) rec = SplatRec{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    a.rec[idx] = rec;
+    if (ok) a.rec[idx] = rec;     // a culled Gaussian's record is never read (radii == 0, no emission slots): 48 B x ~3/4 of the map not written
     }  // in_range
     // Emission-slot allocation: each Gaussian gets a private contiguous run of `mine` slots.  The runs need no global
     // order (only contiguity), so one block-aggregated atomic per workgroup replaces a device-wide prefix scan.
