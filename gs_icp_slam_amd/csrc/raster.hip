@@ -13,10 +13,11 @@
 //    list ranges and an LPT dispatch order; one workgroup per tile then bitonic-sorts its list in LDS by (depth bits,
 //    Gaussian id).  The (depth, id) order is total, so the lists are exactly those of a stable (tile << 32 | depth)
 //    sort of duplicates emitted in id order — the parity tests compare them bit-for-bit.
-//  * Blend kernels: one wave64 per (tile, 16x4 strip).  Binning tags every list entry with 4 strip bits (which
-//    strips the splat's alpha >= 1/255 footprint can reach); a wave compacts its 64-entry batches by its bit and
-//    stages only the surviving 48-byte records in LDS — no workgroup barriers, and culled entries cost 1/64 of a
-//    vector instruction.  Work items are dispatched longest list first (LPT).
+//  * Blend kernels: one wave64 per (tile, 8x8 block) (rounds 1-2: 16x4 strips; the code keeps the word "strip").  Binning tags every
+//    list entry with 4 bits — which blocks the splat's alpha >= 1/255 footprint can reach: the footprint's bounding box at emit time,
+//    re-tested against the footprint ellipse itself when the tile sort writes the list (refine_block_bits) —; a wave compacts its
+//    64-entry batches by its bit and stages only the surviving 48-byte records in LDS — no workgroup barriers, and culled entries cost
+//    1/64 of a vector instruction.  Work items are dispatched longest list first (LPT).
 //  * Backward: every lane of a wave walks the same splat at the same step, so the 10 partial sums are reduced across the
 //    64 lanes with 16 permlane-swap folds + 7 bank-masked DPP adds; the four strip waves of a tile meet once per 64-entry
 //    batch and write ONE 48-byte record per (tile, entry); each Gaussian then sums its own contiguous run of records.
