@@ -858,6 +858,8 @@ def main():
             # what the UNMODIFIED mp_Mapper.py:219-248 statements cost on the drop-in rasteriser (the headline needs the fused, captured iteration)
             "dropin_reference_loop_ms_per_iteration": (legs or {}).get("dropin_reference_loop", {}).get("ms_per_iteration"),
             "stage_us_per_step": stage_us,
+            "stage_us_source": ("one hipEvent bracket per kernel in EAGER iterations run right after the timed region (kernels inside a replayed hipGraph carry no "
+                                "events): they read ~5-15 % above the same kernels inside the graph; the rocprofv3 kernel traces under profiles/ time the replayed kernels"),
             "legs": legs, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
