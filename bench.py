@@ -66,7 +66,7 @@ def _torch_ssim(img, gt, window):
     return (((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
 
 
-def _measure_pmc_traffic(kernel_substr, timeout=240.0):
+def _measure_pmc_traffic(kernel_substr, timeout=120.0):
     """HBM-side traffic of one kernel, MEASURED IN THIS RUN: two child runs of this script (mapper half only, a few steps) under
     `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` — separate passes, never combined with other trace
     domains (MI355X_MICROARCH.md) — and the mean counter value per launch of the kernel x 1024 (the counters are KiB).  Returns
