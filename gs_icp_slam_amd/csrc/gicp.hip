@@ -1307,14 +1307,21 @@ __device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, un
         double s = 0;
 #pragma unroll
         for (int w = 0; w < AL_T / 64; ++w) s += sh.scratch[w][tid];
-        sy->partials[buf][blockIdx.x][tid] = s;
+        // agent-scope atomic store: written through to where every XCD reads it (see the note at the barrier)
+        __hip_atomic_store(&sy->partials[buf][blockIdx.x][tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     ++epoch;
     if (trace) trace_stamp(trace, *trace_n, 10);   // wave + LDS reduction done, partial stored
     if (nwg > 1) {
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // NO agent-scope fences around this barrier (round 3).  The only data that crosses workgroups here are the partial sums, and they
+            // travel as agent-scope atomic stores / loads (write-through, read at the coherence point); everything else a thread reads after the
+            // barrier it wrote itself (its points' correspondences and Mahalanobis matrices) or was written before the launch (grid, clouds,
+            // covariances).  A release FENCE would write back every dirty line of this XCD's L2 — the co-tenant mapper's included — and an
+            // acquire FENCE would invalidate the L2, so that the hash-grid search after every barrier restarted from cold lines.
+            // All partial stores of this workgroup were issued by this wave (NV <= 64): waiting for its own memory operations orders them
+            // before the arrive.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(&sy->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned target = epoch * (unsigned)nwg;
@@ -1328,7 +1335,6 @@ __device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, un
                     break;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             sh.abort = ab;
         }
     }
@@ -1345,7 +1351,8 @@ __device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, un
             for (int w0 = w_lo; w0 < w_hi; w0 += 8) {     // one trip for up to 64 workgroups
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = (w0 + u < w_hi) ? sy->partials[buf][w0 + u][k] : 0.0;
+                for (int u = 0; u < 8; ++u)
+                    v[u] = (w0 + u < w_hi) ? __hip_atomic_load(&sy->partials[buf][w0 + u][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) if (w0 + u < w_hi) s += v[u];
             }
