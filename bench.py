@@ -448,6 +448,7 @@ def main():
     # Every rank renders ITS OWN view of the same map (full image, plain single-GPU rasteriser), one dense all-reduce sums the parameter
     # gradients, the replicated optimiser takes one step per N views.  NOT result-parity with the reference's one-view-per-step loop.
     kf_leg = None
+    mgk = None
     if (world > 1 or force_coll) and (not args.no_legs or args.mp_mode == "keyframes") and args.only != "tracker":
         from gs_icp_slam_amd.graph import MapperIterationGraph as _KMG
         pose_r = synth.DEFAULT_POSE_A @ synth.se3((0.0, 3.0 * rank, 0.0), (0.03 * rank, 0.0, 0.0))
@@ -528,7 +529,8 @@ def main():
                           "gradient floats per Gaussian + a flag word, replicated Adam step on the N views' summed loss; tracker replicas on every rank; "
                           "NOT result-parity with the reference's one-view-per-step loop [REF mp_Mapper.py:200-206]"}
         if use_graph:
-            del mgk
+            mgk.release()     # the graph replays RCCL kernels: gone before the communicator is, and its pools are free for the legs below
+            mgk = None
 
     # ---------------- per-kernel hipEvent times ----------------
     # kernels inside a replayed graph carry no HIP events: the SAME kernels on the same inputs are timed (one hipEvent bracket per kernel) in eager iterations right after the
@@ -866,6 +868,10 @@ def main():
     if worker is not None:
         jobs.put(None)
     if world > 1 or force_coll:
+        for g_ in (mg, mgk):
+            if g_ is not None:
+                g_.release()      # a hipGraph that replays RCCL kernels must not outlive the communicator
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

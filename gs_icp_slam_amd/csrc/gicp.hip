@@ -2496,7 +2496,7 @@ int gsicp_knn_dist2(int P, const float* points, float* out, void* stream_v) {
     if (P == 0) return 0;
     if (!points || !out) { g_last_error = "gsicp_knn_dist2: null pointer"; return -2; }
     static std::mutex mu;
-    static std::map<int, Knn3Scratch> per_device;
+    static std::map<int, Knn3Scratch>& per_device = *new std::map<int, Knn3Scratch>();   // never destroyed: no hipFree after the runtime's own teardown at exit
     std::lock_guard<std::mutex> lk(mu);
     hipStream_t stream = (hipStream_t)stream_v;
     int dev = 0;

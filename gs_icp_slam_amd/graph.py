@@ -215,6 +215,14 @@ class MapperIterationGraph:
         self.graph.replay()
         return self.loss_parts[0]
 
+    def release(self):
+        """Drop the captured hipGraph (a later step() captures again).  Call it BEFORE `torch.distributed.destroy_process_group()` when the
+        iteration holds RCCL collectives: a graph must not outlive the communicator whose kernels it replays."""
+        if self.graph is not None:
+            torch.cuda.synchronize(self.params["means3D"].device)
+            self.graph.reset()
+            self.graph = None
+
     def overflowed(self):
         """True when the last replay produced more duplicates than the capacity (it then rendered nothing and its optimiser step was
         skipped on the device).  Synchronises."""

@@ -172,7 +172,16 @@ def test_captured_sharded_iteration_with_rccl_inside_equals_the_plain_graph(hip_
         assert int(opt_c.state[params_c["means3D"]]["step"].item()) == 0
         for k in params_c:
             assert torch.equal(params_c[k], start[k]), k
+        # a released graph captures again on the next step and lands on the same bits
+        mg_b.release()
+        mg_a.set_view(rs0.viewmatrix, rs0.projmatrix, rs0.campos, c0, d0)
+        mg_b.set_view(rs0.viewmatrix, rs0.projmatrix, rs0.campos, c0, d0)
+        assert float(mg_a.step()) == float(mg_b.step())
     finally:
+        # graphs that replay RCCL kernels must be gone before their communicator is
+        for mg in [v for v in locals().values() if isinstance(v, MapperIterationGraph)]:
+            mg.release()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 
