@@ -79,6 +79,7 @@ def build(force=False, verbose=True):
         subprocess.check_call(cmd)
     build_experiments(force=force, verbose=verbose)
     build_pybind_module(force=force, verbose=verbose)
+    build_torch_ext_module(force=force, verbose=verbose)
     return OUT
 
 
@@ -103,6 +104,38 @@ def build_pybind_module(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
     return out
+
+
+def build_torch_ext_module(force=False, verbose=True):
+    """integration/torch_ext_pybind.cpp -> integration/torch_ext/{diff_gaussian_rasterization,simple_knn}/_C.<abi>.so: the COMPILED torch extension
+    `_C` (rasterize_gaussians, rasterize_gaussians_backward, mark_visible, distCUDA2) over the C ABI.  Plain g++ against
+    libtorch's headers (torch tensors and the current stream only; no HIP code in the binding); libgsicp_hip.so is opened at first use, not linked."""
+    import shutil
+    import sysconfig
+    try:
+        import pybind11  # noqa: F401
+        import torch
+        from torch.utils import cpp_extension
+    except ImportError:
+        return None
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "integration", "torch_ext_pybind.cpp")
+    if not os.path.exists(src):
+        return None
+    suffix = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    outs = [os.path.join(root, "integration", "torch_ext", pkg, "_C" + suffix) for pkg in ("diff_gaussian_rasterization", "simple_knn")]
+    if force or any(_newer(o, [src, os.path.join(root, "include", "gsicp_hip.h")]) for o in outs):
+        tl = _torch_lib_dir()
+        rocm_inc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")
+        cmd = (["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wno-deprecated-declarations", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+                "-DTORCH_API_INCLUDE_EXTENSION_H", "-DTORCH_EXTENSION_NAME=_C", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"] +
+               [f"-I{p}" for p in cpp_extension.include_paths()] + [f"-I{rocm_inc}", f"-I{sysconfig.get_paths()['include']}", src, "-o", outs[0],
+                f"-L{tl}", f"-Wl,-rpath,{tl}", "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-ldl"])
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        shutil.copyfile(outs[0], outs[1])
+    return outs
 
 
 def build_experiments(force=False, verbose=True):

@@ -59,11 +59,14 @@ def test_untouched_reference_two_process_run_tum_layout_and_flags():
     assert res["psnr"] > 17.0 and res["ssim"] > 0.76, (res["psnr"], res["ssim"])
 
 
-def test_untouched_reference_runs_on_the_compiled_pygicp_module():
-    """`import pygicp` [REF mp_Tracker.py:10] resolving to the COMPILED pybind11 module (PyInit_pygicp, integration/pygicp_pybind.cpp) instead of
-    the ctypes mirror: the tracker process of the unmodified reference drives it through the numpy API, it pickles into the spawned process
-    [REF gs_icp_slam.py:121-127], and the trajectory is tracked as with the mirror."""
-    res = _run(["--synthetic", "40", "--compiled-pygicp"])
+def test_untouched_reference_runs_on_compiled_extension_modules_at_all_three_boundaries():
+    """`import pygicp` [REF mp_Tracker.py:10] resolving to the COMPILED pybind11 module (PyInit_pygicp, integration/pygicp_pybind.cpp) and
+    `diff_gaussian_rasterization` / `simple_knn._C` [REF gaussian_renderer/__init__.py:14, scene/gaussian_model.py:20] to the packages around the
+    COMPILED torch extension `_C` (integration/torch_ext_pybind.cpp) instead of the ctypes mirrors: the unmodified reference's tracker drives the
+    first through the numpy API (it pickles into the spawned process [REF gs_icp_slam.py:121-127]), its mapper renders and back-propagates through
+    the second, and the trajectory is tracked as with the mirrors."""
+    res = _run(["--synthetic", "40", "--compiled-ext"])
     assert res["pygicp_binding"].startswith("compiled"), res
-    assert res["processes_that_loaded_it"] >= 3
+    assert res["raster_binding"].startswith("compiled"), res
+    assert res["processes_that_loaded_it"] >= 2          # tracker (pygicp at import) and mapper (_C at its first render)
     assert res["ate_rmse_cm"] <= 0.03, res["ate_rmse_cm"]

@@ -54,7 +54,7 @@ def flags_for(config, shape=None):
     return dict(TUM_FLAGS if (dataset_type(config) == "tum" or shape == "tum") else REPLICA_FLAGS)
 
 
-def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_flags=(), flags=None, trace_dir=None, omp_threads=1, compiled_pygicp=False):
+def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_flags=(), flags=None, trace_dir=None, omp_threads=1, compiled_pygicp=False, compiled_ext=False):
     name = "gs_icp_slam_unlimit" if unlimit else "gs_icp_slam"
     script = os.path.join(reference, name + ".py")
     if not os.path.exists(script):
@@ -68,7 +68,9 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
     env = dict(os.environ)
     # --compiled-pygicp: `import pygicp` resolves to integration/pygicp.<abi>.so (PyInit_pygicp, the pybind11 binding over the C ABI) instead of the
     # ctypes mirror package at the repo root
-    front = [os.path.join(ROOT, "integration")] if compiled_pygicp else []
+    # --compiled-ext: additionally `diff_gaussian_rasterization` and `simple_knn._C` resolve to the packages around the compiled torch-extension
+    # module `_C` (integration/torch_ext/, built from integration/torch_ext_pybind.cpp): all three native boundaries are then extension modules
+    front = ([os.path.join(ROOT, "integration", "torch_ext")] if compiled_ext else []) + ([os.path.join(ROOT, "integration")] if compiled_pygicp or compiled_ext else [])
     env["PYTHONPATH"] = os.pathsep.join(front + [ROOT] + [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p] +
                                         [os.path.join(ROOT, "tests", "refstubs")])
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -99,6 +101,8 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
     res = dict(returncode=p.returncode, timed_out=timed_out, wall_s=round(time.time() - t0, 2), script=os.path.basename(script),
                reference=reference, loaded_so=sorted(set(re.findall(r"GSICP_LOADED (\S+)", out))),
                pygicp_binding=("compiled pybind11 module (integration/pygicp.*.so)" if re.search(r"via=compiled-pygicp", out) else "ctypes mirror (pygicp/)"),
+               raster_binding=("compiled torch extension (integration/torch_ext/diff_gaussian_rasterization/_C.*.so)" if re.search(r"via=compiled-torch-ext", out)
+                               else "ctypes mirror (diff_gaussian_rasterization/)"),
                processes_that_loaded_it=len(set(re.findall(r"GSICP_LOADED \S+ pid=(\d+)", out))))
     for key, pat in (("system_fps", r"System FPS:\s*([-\d.eE+naninf]+)"), ("ate_rmse_cm", r"ATE RMSE:\s*([-\d.eE+naninf]+)"),
                      ("psnr", r"PSNR:\s*([-\d.eE+naninf]+)"), ("ssim", r"SSIM:\s*([-\d.eE+naninf]+)")):
@@ -127,6 +131,8 @@ def main():
     ap.add_argument("--log", default=None, help="write the reference's full stdout here")
     ap.add_argument("--compiled-pygicp", action="store_true", help="let the reference's `import pygicp` resolve to the compiled pybind11 module "
                     "integration/pygicp.<abi>.so instead of the ctypes mirror package")
+    ap.add_argument("--compiled-ext", action="store_true", help="all three native boundaries as compiled extension modules: --compiled-pygicp plus "
+                    "`diff_gaussian_rasterization` / `simple_knn._C` from integration/torch_ext/ (the pybind11 torch extension `_C` over the C ABI)")
     a = ap.parse_args()
     ref = find_reference(a.reference)
     if ref is None:
@@ -163,7 +169,7 @@ def main():
         a.config = os.path.join(ref, "configs", "Replica", "caminfo.txt")
     out_dir = a.output or tempfile.mkdtemp(prefix="gsicp_out_")
     res, log = run(ref, a.dataset, a.config, out_dir, unlimit=not a.limit30, timeout=a.timeout, flags=flags, trace_dir=a.trace, omp_threads=a.omp_threads,
-                   compiled_pygicp=a.compiled_pygicp)
+                   compiled_pygicp=a.compiled_pygicp, compiled_ext=a.compiled_ext)
     res.update(status="measured" if res["returncode"] == 0 and res["system_fps"] is not None else "failed", dataset=a.dataset,
                data="synthetic" if a.synthetic else "real", frames=a.synthetic or None, dataset_type=dataset_type(a.config),
                flags=flags or flags_for(a.config), entry="gs_icp_slam.py (30 FPS cap)" if a.limit30 else "gs_icp_slam_unlimit.py")
