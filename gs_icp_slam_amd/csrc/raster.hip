@@ -683,11 +683,14 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
     const size_t HW = (size_t)a.W * a.H;
     const size_t pix = (size_t)py * a.W + px;
 
-    __shared__ SplatRec s_rec[4][SLAB];
+    // A compacted entry's 48-byte Gaussian record and the 48-byte partial-gradient record the wave produces from it share ONE LDS slot: the
+    // record is in registers (read one pair ahead) before its entry is evaluated, and nothing reads it again.  12 KB less LDS per workgroup.
+    union BwdSlot { SplatRec rec; float part[SLOT_F]; };
+    static_assert(sizeof(SplatRec) == SLOT_F * sizeof(float), "record and partial record must alias exactly");
+    __shared__ BwdSlot s_slot[4][SLAB];
     __shared__ int s_pos[4][SLAB];
-    __shared__ __attribute__((aligned(16))) float s_part[4][SLAB][SLOT_F];
     __shared__ uint32_t s_e[SLAB];
-    __shared__ unsigned long long s_wrote[4];
+    __shared__ unsigned long long s_wrote[4], s_keep[4];
 
     const float T_final = inside ? a.final_T[pix] : 0.f;
     float T = T_final;
@@ -732,12 +735,12 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
         if (m != 0ull && top - 64 < top0) {
             const int n = __popcll(m);
             if (keep) {
-                const int slot = __popcll(m & ((1ull << lane) - 1ull));
+                const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // kept lanes below this one
                 s_pos[wave][slot] = posn;
-                s_rec[wave][slot] = a.rec[gid];
+                s_slot[wave][slot].rec = a.rec[gid];
             }
             __builtin_amdgcn_wave_barrier();
-            auto eval = [&](const SplatRec& r, const int position_v) {
+            auto eval = [&](const SplatRec& r, const int position_v, const int j) {
                 const int position = __builtin_amdgcn_readfirstlane(position_v);   // wave-uniform (LDS broadcast read): keep it scalar
                 const float dx = r.px - pfx, dy = r.py - pfy;
                 const float power = -0.5f * (r.ca * dx * dx + r.cc * dy * dy) - r.cb * dx * dy;
@@ -764,25 +767,25 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
                 const float hx = dx * h, hy = dy * h;
                 const float tsum = wave_sum10_banked(hx, hy, dx * hx, dx * hy, dy * hy, h, w * dp0, w * dp1, w * dp2, w * dpd);
                 const int bp = top - 1 - position;                         // position inside this batch = the lane that loaded the entry
-                if (st_lane) s_part[wave][bp][st_idx] = tsum;
+                if (st_lane) s_slot[wave][j].part[st_idx] = tsum;          // over the entry's own (already consumed) Gaussian record
                 wrote |= 1ull << bp;
             };
             // two entries per trip with two named register sets: the LDS reads of one are in flight while the other is evaluated,
             // and no record has to be copied from a "next" to a "current" register set
-            SplatRec ra = s_rec[wave][0];
+            SplatRec ra = s_slot[wave][0].rec;
             int pa = s_pos[wave][0];
             for (int j = 0; j < n; j += 2) {
                 const int j1 = j + 1 < n ? j + 1 : j;
-                const SplatRec rb = s_rec[wave][j1];
-                const int pb = j + 1 < n ? s_pos[wave][j1] : 0x7fffffff;   // odd tail: a position no pixel can blend
-                eval(ra, pa);
+                const SplatRec rb = s_slot[wave][j1].rec;                  // read BEFORE eval(ra) overwrites slot j (j1 == j on an odd tail)
+                const int pb = j + 1 < n ? s_pos[wave][j1] : 0x7fffffff;   // odd tail: a position no pixel can blend (nothing is written)
+                eval(ra, pa, j);
                 const int j2 = j + 2 < n ? j + 2 : j1;
-                ra = s_rec[wave][j2];
+                ra = s_slot[wave][j2].rec;                                 // j2 > j + 1 or the loop ends: never a slot that holds partials and is used
                 pa = s_pos[wave][j2];
-                eval(rb, pb);
+                eval(rb, pb, j + 1);
             }
         }
-        if (lane == 0) s_wrote[wave] = wrote;
+        if (lane == 0) { s_wrote[wave] = wrote; s_keep[wave] = m; }
         __syncthreads();
         {   // merge the strips of every batch position in strip order and write the entry record once
             const int p = (int)(threadIdx.x >> 2), q = (int)(threadIdx.x & 3);
@@ -791,7 +794,8 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     if ((s_wrote[w] >> p) & 1ull) {
-                        const float4 v = *(const float4*)&s_part[w][p][4 * q];
+                        const int slot = __popcll(s_keep[w] & ((1ull << p) - 1ull));   // compaction keeps the order: lane p's entry sits behind the kept lanes below it
+                        const float4 v = *(const float4*)&s_slot[w][slot].part[4 * q];
                         if (q == 2) { acc.x += v.x + v.z; acc.y += v.y + v.w; }      // words 10, 11 = the second row halves of values 8, 9
                         else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
                     }
