@@ -2372,6 +2372,8 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     if (nwg < 1) nwg = 1;
     if (nwg > AL_MAX_WG) nwg = AL_MAX_WG;
     if (nwg > g->max_resident_wg) nwg = g->max_resident_wg;   // e.g. a partitioned (CPX) device: fewer, fatter workgroups
+    static const int wg_cap = [] { const char* v = std::getenv("GSICP_ALIGN_WG"); return v ? std::atoi(v) : 0; }();   // A/B switch: fewer, fatter workgroups leave the co-tenant mapper more CUs
+    if (wg_cap > 0 && nwg > wg_cap) nwg = wg_cap;
     const float ms = 0.f;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (g->inject_abort && attempt == 0) {   // test hook: the first barrier of this launch sees the abort flag
