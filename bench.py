@@ -297,6 +297,18 @@ def main():
             idx, d2 = r.get_source_correspondence()
             return T, idx, d2
 
+        def step_timed(self, acc):
+            """step() with the host wall time of every call added into `acc` (legs.tracker_call_profile)."""
+            r, sp, pc = self.reg, self.sp, time.perf_counter
+            t0 = pc(); r.set_input_source(sp["points_b"])
+            t1 = pc(); r.set_source_filter(len(sp["trackable_b"]), self.f_src)
+            t2 = pc(); T = r.align(sp["pose_a"])
+            t3 = pc(); idx, d2 = r.get_source_correspondence()
+            t4 = pc()
+            for k, v in (("set_input_source", t1 - t0), ("set_source_filter", t2 - t1), ("align", t3 - t2), ("get_source_correspondence", t4 - t3), ("frames", 1.0)):
+                acc[k] = acc.get(k, 0.0) + v
+            return T, idx, d2
+
         def pose_error(self, T):
             gt = self.sp["pose_b"]
             dR = np.asarray(T, np.float64)[:3, :3] @ gt[:3, :3].T
@@ -318,6 +330,11 @@ def main():
             if n is None:
                 return
             r = None
+            if isinstance(n, tuple):         # (frames, accumulator): the timed variant of the frame (legs.tracker_call_profile)
+                for _ in range(n[0]):
+                    r = trk.step_timed(n[1])
+                done.put(r)
+                continue
             for _ in range(n):
                 r = trk.step()
             done.put(r)
@@ -644,6 +661,25 @@ def main():
             s_lock = rate(step, 100)
             legs["lockstep_step"] = {"frames_per_s": round(1.0 / s_lock, 1), "ms_per_step": round(1e3 * s_lock, 4),
                                      "what": "tracker frame and mapper iteration joined after every step (round-1 loop)"}
+        # -- where the tracker's frame goes on the HOST side, alone and next to the free-running mapper: wall time of each of the four calls of a frame
+        #    [REF mp_Tracker.py:191-199, 231] (the GPU work of a call is inside it only where the call has to wait: align, get_source_correspondence)
+        if worker is not None and free_running:
+            prof = {}
+            for mode in ("alone", "co_tenant"):
+                acc = {}
+                for _ in range(2):
+                    acc.clear()
+                    torch.cuda.synchronize()
+                    jobs.put((200, acc))
+                    if mode == "co_tenant":
+                        for _ in range(200):
+                            mapper_iteration()
+                    done.get()
+                    torch.cuda.synchronize()
+                n_f = acc.pop("frames")
+                prof[mode] = {k: round(1e6 * v / n_f, 1) for k, v in acc.items()}
+                prof[mode]["frame"] = round(sum(prof[mode].values()), 1)
+            legs["tracker_call_profile_us"] = prof
         # -- tracker alone, both pairs
         cases = {args.pair: trk}
         other = "basin" if args.pair == "survey" else "survey"

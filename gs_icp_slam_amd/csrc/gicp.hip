@@ -1755,6 +1755,13 @@ __global__ __launch_bounds__(256) void ingest_points_kernel(int n, const float4*
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) { pts[i] = h_pts[i]; track[i] = i; }   // every point trackable until a filter says otherwise
 }
+// set_input_* immediately followed by set_*_filter — the reference's order [REF mp_Tracker.py:157-158, 191-192] — as ONE launch: the points and,
+// for the first n_track rows, the filter's list instead of the identity
+__global__ __launch_bounds__(256) void ingest_points_track_kernel(int n, const float4* __restrict__ h_pts, float4* __restrict__ pts, int n_track,
+                                                                  const int* __restrict__ h_track, int* __restrict__ track) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { pts[i] = h_pts[i]; track[i] = i < n_track ? h_track[i] : i; }
+}
 __global__ __launch_bounds__(256) void ingest_track_kernel(int n, const int* __restrict__ h_track, int* __restrict__ track) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) track[i] = h_track[i];
@@ -1866,6 +1873,7 @@ struct Cloud {
     PinnedBuf<int> h_track;
     hipEvent_t staged[2] = {nullptr, nullptr};   // [0] h_pts copy, [1] h_track copy
     bool staged_pending[2] = {false, false};
+    bool pts_pending = false;     // h_pts holds a cloud whose ingest launch is deferred to the filter call (one fused launch) or to the first consumer
     ~Cloud() { for (hipEvent_t e : staged) if (e) (void)hipEventDestroy(e); }
     DevBuf<double> cov;
     DevBuf<float> rotq, scales;
@@ -1916,6 +1924,12 @@ struct gsicp_gicp {
     DevBuf<unsigned> sel_blocks;
     AlignResult host_result{};
     bool aligned = false, dist_exact = false;
+    // get_source_correspondence's kernels enqueued by align itself, right behind the LM kernel (see enqueue_correspondence_export): switched on
+    // by the first get_source_correspondence call of this object — the reference asks after every align [REF mp_Tracker.py:231] — so a caller
+    // that never asks never pays for them
+    bool spec_corr = false, spec_valid = false;
+    unsigned spec_seq = 0;
+    int spec_m = 0;
     std::vector<float> h_stage;
     double stats[6] = {0, 0, 0, 0, 0, 0};
 };
@@ -1974,10 +1988,17 @@ int upload_points(gsicp_gicp* g, Cloud& c, const void* pts, int n, int is_f64) {
         float4* h = c.h_pts.p;
         if (is_f64) { const double* p = (const double*)pts; for (int i = 0; i < n; ++i, p += 3) h[i] = make_float4((float)p[0], (float)p[1], (float)p[2], 0.f); }
         else { const float* p = (const float*)pts; for (int i = 0; i < n; ++i, p += 3) h[i] = make_float4(p[0], p[1], p[2], 0.f); }
-        hipLaunchKernelGGL(ingest_points_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, (const float4*)h, c.pts.p, c.track.p);
-        if (int rc = mark_staging(g, c, 0)) return rc;
-    }
+        c.pts_pending = true;      // launched by upload_filter (fused with the filter's list) or by flush_points
+    } else c.pts_pending = false;
     return 0;
+}
+
+// Every consumer of a cloud's device arrays calls this first: a cloud that was uploaded without a filter call behind it is ingested now.
+int flush_points(gsicp_gicp* g, Cloud& c) {
+    if (!c.pts_pending) return 0;
+    c.pts_pending = false;
+    hipLaunchKernelGGL(ingest_points_kernel, dim3((c.n + 255) / 256), dim3(256), 0, g->stream, c.n, (const float4*)c.h_pts.p, c.pts.p, c.track.p);
+    return mark_staging(g, c, 0);
 }
 
 int upload_filter(gsicp_gicp* g, Cloud& c, int n_track, const int32_t* f, int n) {
@@ -1994,7 +2015,13 @@ int upload_filter(gsicp_gicp* g, Cloud& c, int n_track, const int32_t* f, int n)
         if (tr[i] >= 0) tr[w++] = tr[i];
     c.n_track = (int)w;
     if (c.track.ensure(w ? w : 1)) { g_last_error = "hipMalloc failed"; return -1; }
-    if (w) {
+    if (c.pts_pending && n > 0) {
+        c.pts_pending = false;
+        hipLaunchKernelGGL(ingest_points_track_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, (const float4*)c.h_pts.p, c.pts.p, (int)w,
+                           (const int*)tr, c.track.p);
+        if (int rc = mark_staging(g, c, 0)) return rc;
+        if (int rc = mark_staging(g, c, 1)) return rc;
+    } else if (w) {
         hipLaunchKernelGGL(ingest_track_kernel, dim3(((int)w + 255) / 256), dim3(256), 0, g->stream, (int)w, (const int*)tr, c.track.p);
         if (int rc = mark_staging(g, c, 1)) return rc;
     }
@@ -2003,6 +2030,7 @@ int upload_filter(gsicp_gicp* g, Cloud& c, int n_track, const int32_t* f, int n)
 
 int calc_cov(gsicp_gicp* g, Cloud& c) {
     const int n = c.n;
+    if (int rc = flush_points(g, c)) return rc;
     if (c.cov.ensure((size_t)6 * (n ? n : 1)) || c.rotq.ensure((size_t)4 * (n ? n : 1)) || c.scales.ensure((size_t)3 * (n ? n : 1))) {
         g_last_error = "hipMalloc failed"; return -1;
     }
@@ -2040,6 +2068,7 @@ int calc_cov(gsicp_gicp* g, Cloud& c) {
 
 int build_grid(gsicp_gicp* g) {
     Cloud& t = g->tgt;
+    if (int rc = flush_points(g, t)) return rc;
     const int n = t.n_track;
     GridView& G = g->grid;
     std::memset(&G, 0, sizeof(G));
@@ -2146,7 +2175,7 @@ void gsicp_gicp_destroy(gsicp_gicp* g) {
     if (g->ev_xs2) (void)hipEventDestroy(g->ev_xs2);
     delete g;
 }
-int gsicp_gicp_set_max_correspondence_distance(gsicp_gicp* g, double d) { g->max_corr = d; g->grid_valid = false; return 0; }
+int gsicp_gicp_set_max_correspondence_distance(gsicp_gicp* g, double d) { g->max_corr = d; g->grid_valid = false; g->spec_valid = false; g->dist_exact = false; return 0; }
 int gsicp_gicp_set_max_knn_distance(gsicp_gicp* g, double d) { g->max_knn = d; g->src.cov_valid = false; return 0; }
 int gsicp_gicp_set_correspondence_randomness(gsicp_gicp* g, int k) {
     if (k < 1 || k > 64) { g_last_error = "k must be in [1, 64]"; return -2; }
@@ -2230,6 +2259,7 @@ int wait_for_producer(gsicp_gicp* g, void* producer_stream) {
     return 0;
 }
 int upload_points_device(gsicp_gicp* g, Cloud& c, const float* xyz, int n, void* producer_stream, int wait) {
+    c.pts_pending = false;     // a host upload that was never consumed is superseded
     if (n < 0 || (n > 0 && !xyz)) { g_last_error = "bad device point array"; return -2; }
     c.n = n; c.n_track = n; c.cov_valid = false; c.qs_valid = false;
     if (c.pts.ensure((size_t)n) || c.track.ensure((size_t)n)) { g_last_error = "hipMalloc failed"; return -1; }
@@ -2276,7 +2306,7 @@ int gsicp_gicp_set_target_from_gaussians_device(gsicp_gicp* g, int P, const floa
     if (P < 0 || (P > 0 && (!xyz || !rotation || !scaling || !opacity))) { g_last_error = "set_target_from_gaussians: bad arguments"; return -2; }
     Cloud& t = g->tgt;
     g->grid_valid = false; g->aligned = false;
-    t.n = 0; t.n_track = 0; t.cov_valid = false; t.qs_valid = false;
+    t.n = 0; t.n_track = 0; t.cov_valid = false; t.qs_valid = false; t.pts_pending = false;
     if (P == 0) return 0;
     const int nblocks = (P + 255) / 256;
     const size_t cap = (size_t)P;
@@ -2304,6 +2334,7 @@ int gsicp_gicp_set_target_from_gaussians_device(gsicp_gicp* g, int P, const floa
 int gsicp_gicp_set_source_track_device(gsicp_gicp* g, const int* trackable_idx, int n_track, void* producer_stream, int wait) {
     Cloud& c = g->src;
     if (n_track < 0 || n_track > c.n || (n_track > 0 && !trackable_idx)) { g_last_error = "set_source_track: bad list"; return -2; }
+    if (int rc = flush_points(g, c)) return rc;     // a host-uploaded cloud writes its identity list first
     c.n_track = n_track;
     if (c.track.ensure((size_t)(n_track ? n_track : 1))) { g_last_error = "hipMalloc failed"; return -1; }
     if (n_track > 0) {
@@ -2337,12 +2368,45 @@ int gsicp_gicp_get_source_scales_device(gsicp_gicp* g, float* out_dev, int cap, 
     return fetch_floats_device(g, g->src.scales.p, g->src.n, 3, out_dev, cap, consumer_stream);
 }
 
+// The kernels behind get_source_correspondence [REF mp_Tracker.py:231]: exact distances for the points the gated search left without a match
+// (miss list -> exact nearest neighbour), then the export of (index, squared distance) into page-locked staging, published through the mailbox.
+// Everything they read is on the device (the final correspondences, the pose of the last linearisation), so they can be enqueued right behind
+// the LM kernel without waiting for it: `gsicp_gicp_align` does that once a caller has shown that it asks for correspondences, which takes the
+// host round trip (align returns -> Python -> three launches, each waiting for CUs next to the mapper) out of the frame.
+static int enqueue_correspondence_export(gsicp_gicp* g, int m, unsigned* seq_out) {
+    Cloud &s = g->src, &t = g->tgt;
+    const int n = s.n_track;
+    if (!g->dist_exact && g->grid.use_grid && n > 0 && t.n_track > 0) {
+        const float gate = (float)g->max_corr * (float)g->max_corr;
+        gsicp::ProfileScope ps(gsicp::ST_GICP_MISS, g->stream);
+        hipLaunchKernelGGL(miss_list_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, g->sqd.p, g->corr.p, gate, g->miss.p,
+                           g->counters.p);
+        if (g->tg_valid)
+            hipLaunchKernelGGL(nn1_grid_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
+                               g->result.p->lin_pose, g->tg_params.p, g->tg_start.p, g->tg_sorted.p, t.n_track, g->sqd.p);
+        else
+            hipLaunchKernelGGL(brute_nn_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
+                               g->result.p->lin_pose, g->sorted.p, t.n_track, g->sqd.p);
+        GC(hipGetLastError());
+        g->dist_exact = true;
+    }
+    if (g->h_corr.ensure((size_t)m) || g->h_sqd.ensure((size_t)m)) { g_last_error = "hipHostMalloc failed"; return -1; }
+    const unsigned seq = ++g->seq;
+    hipLaunchKernelGGL(export_corr_kernel, dim3((m + 255) / 256), dim3(256), 0, g->stream, m, g->corr.p, g->sqd.p, g->h_corr.p, g->h_sqd.p,
+                       g->counters.p + 1, g->mailbox, seq);
+    GC(hipGetLastError());
+    *seq_out = seq;
+    return 0;
+}
+
 int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     Cloud &s = g->src, &t = g->tgt;
     if (s.n == 0 || t.n == 0) { g_last_error = "align: source and target must be set"; return -2; }
     hipEvent_t e0 = g->ev0, e1 = g->ev1;
     GC(hipEventRecord(e0, g->stream));
     int launches = 0;
+    if (int rc = flush_points(g, s)) return rc;
+    if (int rc = flush_points(g, t)) return rc;
     if (!s.cov_valid) { if (int rc = calc_cov(g, s)) return rc; ++launches; }
     if (!t.cov_valid) { if (int rc = calc_cov(g, t)) return rc; ++launches; }
     if (!g->grid_valid) { if (int rc = build_grid(g)) return rc; launches += 4; }
@@ -2386,9 +2450,15 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
         ++launches;
         GC(hipGetLastError());
         GC(hipEventRecord(e1, g->stream));
+        g->dist_exact = false; g->spec_valid = false;
+        if (g->spec_corr && attempt == 0 && s.n_track > 0) {       // the correspondence kernels ride behind the LM kernel (no host round trip)
+            if (int rc_ = enqueue_correspondence_export(g, s.n_track, &g->spec_seq)) return rc_;
+            g->spec_valid = true; g->spec_m = s.n_track;
+        }
         if (int rc_ = wait_mailbox(g, &g->mailbox->align_seq, a.seq)) return rc_;
         g->host_result = g->mailbox->result;
         if (g->host_result.failed != 2) break;
+        g->dist_exact = false; g->spec_valid = false;              // what rode behind a failed launch exported nothing of use
         // The grid barrier gave up: some workgroup never became resident (the GPU was saturated by a co-tenant for longer than the spin
         // budget) or the abort flag was set.  Barrier state may be stale: drain, reset, and re-run the registration as ONE workgroup —
         // grid_sum then needs no cross-workgroup barrier at all, so it cannot fail this way (slower, still entirely on the device).
@@ -2403,7 +2473,7 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     g->stats_pending = true;   // the events are read lazily (gsicp_gicp_last_align_stats): e1 completes a few us after the mailbox write
     if (g->host_result.failed == 2) { g_last_error = "align: the grid barrier timed out even with a single workgroup"; return -1; }
     std::memcpy(out, g->host_result.final_pose, sizeof(double) * 16);
-    g->aligned = true; g->dist_exact = false;
+    g->aligned = true;
     g->stats[0] = launches; g->stats[1] = g->host_result.lm_trials; g->stats[2] = g->host_result.cost;
     g->stats[3] = g->host_result.converged; g->stats[4] = ms * 1000.0; g->stats[5] = g->host_result.failed;
     return g->host_result.iterations;
@@ -2411,29 +2481,14 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
 
 int gsicp_gicp_get_source_correspondence(gsicp_gicp* g, int32_t* idx, float* d2, int cap) {
     if (!g->aligned) { g_last_error = "get_source_correspondence before align"; return -2; }
-    Cloud &s = g->src, &t = g->tgt;
-    const int n = s.n_track;
-    if (!g->dist_exact && g->grid.use_grid && n > 0 && t.n_track > 0) {
-        const float gate = (float)g->max_corr * (float)g->max_corr;
-        gsicp::ProfileScope ps(gsicp::ST_GICP_MISS, g->stream);
-        hipLaunchKernelGGL(miss_list_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, g->sqd.p, g->corr.p, gate, g->miss.p,
-                           g->counters.p);
-        if (g->tg_valid)
-            hipLaunchKernelGGL(nn1_grid_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
-                               g->result.p->lin_pose, g->tg_params.p, g->tg_start.p, g->tg_sorted.p, t.n_track, g->sqd.p);
-        else
-            hipLaunchKernelGGL(brute_nn_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
-                               g->result.p->lin_pose, g->sorted.p, t.n_track, g->sqd.p);
-        GC(hipGetLastError());
-        g->dist_exact = true;
-    }
+    const int n = g->src.n_track;
     const int m = n < cap ? n : cap;
-    if (m > 0) {   // page-locked staging, then a plain memcpy into the caller's arrays once the stream has drained
-        if (g->h_corr.ensure((size_t)m) || g->h_sqd.ensure((size_t)m)) { g_last_error = "hipHostMalloc failed"; return -1; }
-        const unsigned seq = ++g->seq;
-        hipLaunchKernelGGL(export_corr_kernel, dim3((m + 255) / 256), dim3(256), 0, g->stream, m, g->corr.p, g->sqd.p, g->h_corr.p, g->h_sqd.p,
-                           g->counters.p + 1, g->mailbox, seq);
-        GC(hipGetLastError());
+    g->spec_corr = true;        // from now on align enqueues these kernels itself
+    if (m > 0) {   // page-locked staging, then a plain memcpy into the caller's arrays once the export has been published
+        unsigned seq = g->spec_seq;
+        if (!(g->spec_valid && g->spec_m >= m)) {
+            if (int rc = enqueue_correspondence_export(g, m, &seq)) return rc;
+        }
         if (int rc_ = wait_mailbox(g, &g->mailbox->export_seq, seq)) return rc_;
         std::memcpy(idx, g->h_corr.p, sizeof(int) * m);
         std::memcpy(d2, g->h_sqd.p, sizeof(float) * m);
