@@ -511,17 +511,18 @@ struct BlendArgs {
 };
 
 // ================================================================================================================
-// "Strip" blend kernels (default).  A 256-thread workgroup owns a 16x16 tile; wave s owns the 16x4 strip of rows
-// 4s..4s+3 and runs on its own — no workgroup barrier anywhere.  Per 64 list entries a wave
-//   1. loads the entries with one coalesced vector load and keeps those whose strip bit (computed at binning time
-//      from the Gaussian's alpha >= 1/255 footprint) is set — typically a minority, since a Gaussian of ~10 px
-//      radius touches one or two of a tile's four strips;
+// "Strip" blend kernels (default; the word is kept from rounds 1-2, when a wave owned a 16x4 strip of rows).  A 16x16 tile is cut into four
+// 8x8 pixel BLOCKS; one wave64 owns block s (s & 1: right half, s >> 1: lower half; lane = 8 * row + column inside the block) and runs on
+// its own — in the forward as a 64-thread workgroup per (tile, block), no workgroup barrier anywhere.  Per 64 list entries a wave
+//   1. loads the entries with one coalesced vector load and keeps those whose block bit (computed at binning time from the
+//      Gaussian's alpha >= 1/255 footprint, then made exact against the block rectangle by refine_block_bits) is set — on the
+//      benchmark map 1.6 of a tile's four blocks per entry;
 //   2. compacts the survivors with ballot/mbcnt, gathers their 48-byte records with all lanes in parallel into a
 //      wave-private LDS slab (the gather latency is paid once per batch, not once per entry);
 //   3. walks the compacted slab with wave-uniform LDS broadcast reads.
-// Entries that cannot touch the strip therefore cost 1/64 of a vector instruction instead of a full evaluation, and
+// Entries that cannot touch the block therefore cost 1/64 of a vector instruction instead of a full evaluation, and
 // the four waves never wait for each other.  Exactness is untouched: the per-pixel alpha / transmittance tests are
-// still what decides, the strip bit only removes entries every pixel of the strip would have rejected anyway.
+// still what decides, the block bit only removes entries every pixel of the block would have rejected anyway.
 // ================================================================================================================
 constexpr int SLAB = 64;
 
@@ -627,15 +628,15 @@ __device__ inline float swap16_add(float a, float b) {
 }
 
 // ================================================================================================================
-// Backward, tile workgroups (default).  One 256-thread workgroup per tile; wave s owns strip s exactly as in the forward (own
-// compaction by strip bit, own slab, own pixel state), but the four waves meet once per 64-entry batch so that every (tile, entry)
+// Backward, tile workgroups (default).  One 256-thread workgroup per tile; wave s owns the 8x8 block s exactly as in the forward (own
+// compaction by block bit, own slab, own pixel state), but the four waves meet once per 64-entry batch so that every (tile, entry)
 // gradient record is written ONCE:
-//   * each wave reduces its ten partial gradients per staged entry across the 64 lanes and parks them in LDS at the entry's position
-//     inside the batch (s_part[wave][position]); a 64-bit mask per wave says which positions it wrote;
-//   * after one workgroup barrier, 192 threads add the (up to four) strip records of each batch position in strip order and store the
+//   * each wave reduces its ten partial gradients per staged entry across the 64 lanes and parks them in LDS OVER the entry's own,
+//     already consumed Gaussian record (s_slot[wave][compacted slot]); two 64-bit masks per wave say which batch positions it kept / wrote;
+//   * after one workgroup barrier, 192 threads add the (up to four) block records of each batch position in block order and store the
 //     48-byte entry record straight into entry_sum[emission slot] — the array the per-Gaussian pass (preprocess_backward) streams.
-// Against the per-(entry, strip) slot scheme this removes the slot buffer (240 B per duplicate), the entry_sum kernel that re-read it,
-// and ~60 % of the gradient write traffic; results stay bit-reproducible (fixed reduction tree, fixed strip order, no atomics).
+// Against the per-(entry, block) slot scheme of round 1 this removes the slot buffer (240 B per duplicate), the entry_sum kernel that re-read it,
+// and ~60 % of the gradient write traffic; results stay bit-reproducible (fixed reduction tree, fixed block order, no atomics).
 // The per-entry body is branch-free: an entry a pixel does not blend enters with alpha = 0, which makes T, the behind-colour A and all
 // ten gradient terms no-ops by arithmetic (T * rcp(1) = T, 0 * c + 1 * A = A, w = 0) instead of by exec masking + zero fills, and the
 // behind-colour recurrence is applied eagerly (A <- alpha c + (1 - alpha) A after the entry) rather than lazily before the next one.
