@@ -188,7 +188,8 @@ int gsicp_gicp_set_target_covariances_fromqs(gsicp_gicp*, const float* rots_flat
 int gsicp_gicp_align(gsicp_gicp*, const double* initial_pose, double* final_pose);
 /* One entry per trackable source point: nearest-target index (-1 when farther than the correspondence gate) and
  * the squared distance to the nearest target point, as of the last linearisation  [REF mp_Tracker.py:231].
- * Returns the number of entries. */
+ * Returns the number of entries.  The first call on an object computes and exports on demand; from then on gsicp_gicp_align
+ * enqueues the kernels behind its own (the reference asks after every align), and this call waits for the export and copies. */
 int gsicp_gicp_get_source_correspondence(gsicp_gicp*, int32_t* target_index, float* sq_distance, int capacity);
 /* ---- Device-pointer overloads (additive — the numpy-style entry points above are unchanged) ----------
  * The reference hands the map's trackable Gaussians to the tracker through host memory on every tracking keyframe while the
