@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B: the persistent LM kernel compiled under a register cap (amdgpu_waves_per_eu 2 / 3 / 4: 256 / 168 / 128 registers, spilling) against the
-# product's 256 VGPRs + 114 AGPRs.  Variant libraries libgsicp_hip_wN.so are swapped in for libgsicp_hip.so on the (scratch) GPU box copy.
+# product's 256 VGPRs + 114 AGPRs.  Variant libraries libgsicp_hip_wN.so (python tools/build_align_variants.py) are swapped in for libgsicp_hip.so on the (scratch) GPU box copy.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/ab_align_regs
 mkdir -p $OUT
