@@ -282,6 +282,57 @@ def test_filters_and_errors():
     assert idx.tolist() == [3, 7, 9] and np.all(d2 == 0.0)
 
 
+def test_repeated_frames_on_one_object_equal_fresh_objects():
+    """Round 3's two launch savings must not change a bit: (i) `set_input_*` + `set_*_filter` are one deferred, fused ingest launch — also when
+    no filter call follows (the first consumer flushes the cloud), when the cloud is replaced before it was consumed, and when the filter
+    arrives alone; (ii) after an object's first `get_source_correspondence`, `align` enqueues the correspondence kernels itself — the second
+    frame of an object therefore takes the other path than its first, and both must equal what a fresh object returns, with the getter
+    called once, twice or not at all in between, and across a gate change."""
+    import pygicp
+    sp1 = synth.s_pair(synth.REPLICA, motion=synth.se3((0.0, 1.0, 0.0), (0.02, 0.0, 0.0)))       # part of the source beyond the gate
+    sp2 = synth.s_pair(synth.REPLICA, motion=synth.se3((0.3, -0.4, 0.2), (0.004, -0.003, 0.002)))
+
+    def frame(reg, sp, gate, with_filter=True, ask=1):
+        if getattr(reg, "_gate_set", None) != gate:                   # like the reference: the gate is set once, not per frame
+            reg.set_max_correspondence_distance(gate)
+            reg._gate_set = gate
+        reg.set_input_source(sp["points_b"])
+        if with_filter:
+            reg.set_source_filter(len(sp["trackable_b"]), filt(len(sp["points_b"]), sp["trackable_b"]))
+        T = reg.align(sp["pose_a"])
+        got = [reg.get_source_correspondence() for _ in range(ask)]
+        for g_ in got[1:]:
+            assert np.array_equal(g_[0], got[0][0]) and np.array_equal(g_[1], got[0][1])
+        return T, (got[0] if got else None)
+
+    def fresh(sp, gate, with_filter=True):
+        reg = pygicp.FastGICP()
+        reg.set_max_knn_distance(99999.0)
+        pw = world(sp1["points_a"], sp1["pose_a"])
+        reg.set_input_target(np.zeros((7, 3)))                        # replaced before anything consumed it
+        reg.set_input_target(pw)
+        reg.set_target_filter(len(sp1["trackable_a"]), filt(len(pw), sp1["trackable_a"]))
+        reg.calculate_target_covariance_with_filter()
+        return reg, frame(reg, sp, gate, with_filter)
+
+    def same(a, b):
+        return np.array_equal(np.asarray(a[0]), np.asarray(b[0])) and np.array_equal(a[1][0], b[1][0]) and np.array_equal(a[1][1], b[1][1])
+
+    g1, g2 = synth.REPLICA["max_corr"], 2.5 * synth.REPLICA["max_corr"]
+    reg, first = fresh(sp1, g1)
+    assert (first[1][0] < 0).mean() > 0.2                             # the exact-distance kernels have work to do
+    assert same(frame(reg, sp2, g1, ask=2), fresh(sp2, g1)[1])        # second frame: the kernels ride behind the LM kernel
+    frame(reg, sp1, g1, ask=0)                                        # a frame whose correspondences nobody asks for
+    assert same(frame(reg, sp1, g1), first)
+    assert same(frame(reg, sp2, g2), fresh(sp2, g2)[1])               # another gate: grid rebuilt, speculation follows
+    sp3 = dict(sp2, points_b=np.ascontiguousarray(sp2["points_b"][sp2["trackable_b"]]))        # a small cloud, every point trackable
+    unfiltered = fresh(sp3, g1, with_filter=False)[1]
+    assert same(frame(reg, sp3, g1, with_filter=False), unfiltered)   # no filter call: the first consumer ingests the cloud
+    reg.set_max_correspondence_distance(g2)                           # gate changed between align and the getter: recomputed on demand
+    idx, d2 = reg.get_source_correspondence()
+    assert len(idx) == len(sp3["points_b"]) and (idx >= 0).sum() >= (unfiltered[1][0] >= 0).sum()
+
+
 def test_distances_beyond_gate_are_exact():
     """The reference exports the raw nearest-neighbour distance even when it exceeds the gate (thresholds at
     mp_Tracker.py:235 sit above max_corr^2)."""
