@@ -2393,6 +2393,9 @@ static int enqueue_correspondence_export(gsicp_gicp* g, int m, unsigned* seq_out
         GC(hipGetLastError());
         g->dist_exact = true;
     }
+    if ((size_t)m > g->h_corr.cap || (size_t)m > g->h_sqd.cap) {     // growing frees the old staging: an export an earlier align enqueued (and nobody
+        if (int rc = drain(g)) return rc;                            // fetched) may still be writing it
+    }
     if (g->h_corr.ensure((size_t)m) || g->h_sqd.ensure((size_t)m)) { g_last_error = "hipHostMalloc failed"; return -1; }
     const unsigned seq = ++g->seq;
     hipLaunchKernelGGL(export_corr_kernel, dim3((m + 255) / 256), dim3(256), 0, g->stream, m, g->corr.p, g->sqd.p, g->h_corr.p, g->h_sqd.p,
