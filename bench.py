@@ -110,6 +110,106 @@ def _measure_pmc_traffic(kernel_substr, timeout=120.0):
     return out, None
 
 
+def tracker_vs_map_leg(sizes=(8280, 100_000, 1_000_000), frames=60, fid=155, back=1):
+    """The tracker in its STEADY-STATE configuration [REF mp_Tracker.py:282-288; scene/gaussian_model.py:207-215]: the target is the map's
+    trackable Gaussians (K of them, out of 2K rows: half fail the opacity / trackable selection), handed over at a tracking keyframe either
+    the reference's way — rows selected on the host, `set_input_target(np f32)` + `set_target_covariances_fromqs(np, np)` — or by
+    `set_target_from_gaussians` on the device; then 8 280-point frames are aligned against it.  Per K: wall ms of each hand-off (the index
+    build is lazy, so the first `align` after a hand-off carries it: `first_align_ms`), steady-state host wall us of `align` and
+    `get_source_correspondence`, per-stage device us (hipEvent), LM iterations, the search structure's sizes, and how full its cells are.
+    The map's quaternions / scales come from the HIP tracker's own k-NN export of each keyframe (the oracle is not used here)."""
+    import torch
+    import pygicp
+    from gs_icp_slam_amd import _lib, synth
+    cfg = synth.REPLICA
+    kreg = pygicp.FastGICP()
+    kreg.set_max_knn_distance(99999.0)
+
+    def cov_fn(pw):
+        kreg.set_input_target(pw)
+        kreg.calculate_target_covariance_with_filter()
+        return kreg.get_target_rotationsq(), kreg.get_target_scales()
+
+    poses = synth.trajectory(fid + 1)
+    src, _, trackable, _ = synth.frame_points(cfg, poses[fid])
+    f_src = np.zeros(len(src), np.int32)
+    f_src[trackable] = np.arange(1, len(trackable) + 1)
+    init = poses[fid - back]
+    pc = time.perf_counter
+    out = {"source_points": int(len(trackable)), "gate_m": cfg["max_corr"], "initial_guess": f"pose {back} frame(s) earlier "
+           f"({1e3 * np.linalg.norm(init[:3, 3] - poses[fid][:3, 3]):.1f} mm away)", "sizes": {}}
+    for K in sizes:
+        m = synth.tracker_map(K, cov_fn, n_keyframes=(2 if K < 20_000 else 32))
+        keep = m["trackable"] & (m["opacity"] > m["opacity_th"])
+        tp, tr, ts = (np.ascontiguousarray(m[k][keep]) for k in ("points", "rotations", "scales"))
+        reg = pygicp.FastGICP()
+        reg.set_max_correspondence_distance(cfg["max_corr"])
+        reg.set_max_knn_distance(99999.0)
+
+        def frame(timed=None):
+            t0 = pc(); reg.set_input_source(src); reg.set_source_filter(len(trackable), f_src)
+            t1 = pc(); T = reg.align(init)
+            t2 = pc(); idx, d2 = reg.get_source_correspondence()
+            t3 = pc()
+            if timed is not None:
+                timed.append((t1 - t0, t2 - t1, t3 - t2))
+            return T, idx, d2
+
+        # -- the reference's hand-off (host arrays), three times: the first carries allocations
+        host = []
+        for _ in range(3):
+            t0 = pc(); reg.set_input_target(tp)
+            t1 = pc(); reg.set_target_covariances_fromqs(tr.reshape(-1), ts.reshape(-1))
+            t2 = pc(); frame()
+            t3 = pc()
+            host.append((t1 - t0, t2 - t1, t3 - t2))
+        T_host, idx_host, d2_host = frame()
+        # -- the device hand-off
+        dev = "cuda"
+        g_dev = [torch.from_numpy(m[k]).to(dev) for k in ("points", "rotations", "scales", "opacity")]
+        mask_dev = torch.from_numpy(m["trackable"]).to(dev)
+        torch.cuda.synchronize()
+        devt = []
+        for _ in range(3):
+            t0 = pc(); n_sel = reg.set_target_from_gaussians(*g_dev, trackable_mask=mask_dev, opacity_th=m["opacity_th"])
+            t1 = pc(); frame()
+            t2 = pc()
+            devt.append((t1 - t0, t2 - t1))
+        T_dev, idx_dev, d2_dev = frame()
+        # -- steady state
+        for _ in range(5):
+            frame()
+        timed = []
+        for _ in range(frames):
+            frame(timed)
+        st = reg.last_align_stats()
+        _lib.profile_enable(True)
+        _lib.profile_read()
+        for _ in range(20):
+            frame()
+        stage = {k: round(1e3 * ms / 20, 2) for k, (ms, c) in _lib.profile_read().items() if c > 0 and k.startswith("gicp")}
+        _lib.profile_enable(False)
+        ix = reg.target_index_stats()
+        cells = np.unique(np.floor(tp.astype(np.float64) / ix["cell_m"]).astype(np.int64), axis=0, return_counts=True)[1] if ix["hashed_grid"] else np.zeros(1)
+        gt = poses[fid]
+        med = lambda i, rows: float(statistics.median(r[i] for r in rows))   # noqa: E731
+        out["sizes"][str(K)] = {
+            "target_gaussians": int(keep.sum()), "map_rows": int(len(keep)),
+            "host_handoff_ms": {"set_input_target": round(1e3 * med(0, host[1:]), 3), "set_target_covariances_fromqs": round(1e3 * med(1, host[1:]), 3),
+                                "first_frame_after_it (index build inside align)": round(1e3 * med(2, host[1:]), 3)},
+            "device_handoff_ms": {"set_target_from_gaussians": round(1e3 * med(0, devt[1:]), 3), "first_frame_after_it": round(1e3 * med(1, devt[1:]), 3)},
+            "frame_us": {"set_input_source+filter": round(1e6 * med(0, timed), 1), "align": round(1e6 * med(1, timed), 1),
+                         "get_source_correspondence": round(1e6 * med(2, timed), 1), "frame": round(1e6 * statistics.median(sum(r) for r in timed), 1)},
+            "stage_us": stage, "lm_iterations": st["iterations"], "converged": st["converged"],
+            "pose_error_mm": round(1e3 * float(np.linalg.norm(np.asarray(T_host, np.float64)[:3, 3] - gt[:3, 3])), 4),
+            "in_gate_fraction": round(float((idx_host >= 0).mean()), 4),
+            "device_route_equals_host_route": bool(np.array_equal(idx_host, idx_dev) and np.array_equal(d2_host, d2_dev) and np.array_equal(T_host, T_dev)),
+            "index": dict(ix, occupied_cells=int(len(cells)), mean_points_per_cell=round(float(cells.mean()), 2), max_points_per_cell=int(cells.max())),
+        }
+        del reg, g_dev, mask_dev
+    return out
+
+
 def _spawn_ranks(n):
     import socket
     import subprocess
@@ -698,6 +798,9 @@ def main():
             legs[f"tracker_only_{name}"] = {"frames_per_s": round(1.0 / s_frame, 1), "ms_per_frame": round(1e3 * s_frame, 4), "motion": motions[name],
                                             "lm_iterations": st["iterations"], "converged": st["converged"], "stage_us": pr,
                                             "pose_error_deg_mm": [round(ang, 4), round(mm, 3)], "correspondence_ratio": round(float((idx >= 0).mean()), 3)}
+        # -- the tracker against MAP-sized targets (its steady-state configuration after the first tracking keyframe)
+        if os.environ.get("GSICP_BENCH_MAP_LEG", "1") != "0":
+            legs["tracker_vs_map"] = tracker_vs_map_leg()
         # -- mapper alone: graph replay, eager fused
         s_it = rate(lambda: mapper_iteration(), 100)
         legs["mapper_only"] = {"iterations_per_s": round(1.0 / s_it, 1), "ms_per_iteration": round(1e3 * s_it, 4),

@@ -99,6 +99,7 @@ SIGNATURES = {
     "gsicp_gicp_get_source_scales_device": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gsicp_gicp_num_source": (c_int, [c_void_p]),
     "gsicp_gicp_num_target": (c_int, [c_void_p]),
+    "gsicp_gicp_target_index_stats": (c_int, [c_void_p, c_void_p]),
     "gsicp_gicp_last_align_stats": (c_int, [c_void_p, c_void_p]),
     "gsicp_gicp_get_final_hessian": (c_int, [c_void_p, c_void_p]),
     "gsicp_gicp_debug_abort_next_align": (c_int, [c_void_p]),

@@ -2525,6 +2525,19 @@ int gsicp_gicp_knn_stats(gsicp_gicp* g, double out[12]) {
 }
 int gsicp_gicp_num_source(gsicp_gicp* g) { return g->src.n; }
 int gsicp_gicp_num_target(gsicp_gicp* g) { return g->tgt.n; }
+int gsicp_gicp_target_index_stats(gsicp_gicp* g, double out[8]) {
+    const GridView& G = g->grid;
+    const double slots = (g->grid_valid && G.use_grid) ? (double)G.mask + 1.0 : 0.0;
+    out[0] = g->grid_valid ? (double)G.n_sorted : 0.0;
+    out[1] = (g->grid_valid && G.use_grid) ? 1.0 : 0.0;
+    out[2] = slots;
+    out[3] = slots * 16.0;
+    out[4] = (g->grid_valid && G.use_grid) ? 1.0 / (double)G.inv_h : 0.0;
+    out[5] = g->grid_valid ? (double)G.n_sorted * 16.0 : 0.0;
+    out[6] = g->tg_valid ? (double)KNN_MAX_CELLS : 0.0;   // upper bound; the actual count is chosen on the device
+    out[7] = g->tg_valid ? ((double)KNN_MAX_CELLS + 1.0) * 4.0 + (double)G.n_sorted * 16.0 : 0.0;
+    return 0;
+}
 int gsicp_gicp_last_align_stats(gsicp_gicp* g, double out[6]) {
     if (g->stats_pending) {
         float ms = 0.f;

@@ -283,6 +283,13 @@ class FastGICP:
         return dict(cell=float(out[0]), dims=(int(out[1]), int(out[2]), int(out[3])), whole_grid=int(out[5]), ring1=int(out[6]),
                     ring2=int(out[7]), ring3=int(out[8]), full_scan=int(out[9]))
 
+    def target_index_stats(self):
+        """Sizes of the target search structure as of the last build (diagnostics for map-sized targets)."""
+        out = np.empty(8, np.float64)
+        self._ck(self._lib.gsicp_gicp_target_index_stats(self._h, _vp(out)), "target_index_stats")
+        return dict(targets=int(out[0]), hashed_grid=bool(out[1]), table_slots=int(out[2]), table_bytes=int(out[3]), cell_m=float(out[4]),
+                    sorted_bytes=int(out[5]), dense_cells=int(out[6]), dense_bytes=int(out[7]))
+
     def last_align_stats(self):
         out = np.empty(6, np.float64)
         self._lib.gsicp_gicp_last_align_stats(self._h, _vp(out))

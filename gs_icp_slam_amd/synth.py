@@ -224,6 +224,79 @@ def trajectory(n_frames, step=None, start=None):
     return poses
 
 
+def raycast_pixels(cfg, pose_c2w, u, v):
+    """`raycast_depth` at the given (float) pixel coordinates only — same slab arithmetic, no full image."""
+    u, v = np.asarray(u, np.float64), np.asarray(v, np.float64)
+    dc = np.stack([(u - cfg["cx"]) / cfg["fx"], (v - cfg["cy"]) / cfg["fy"], np.ones_like(u)], -1)
+    d = dc @ pose_c2w[:3, :3].T
+    o = pose_c2w[:3, 3]
+    _, depth = _slab(o, d, ROOM_LO, ROOM_HI)
+    for lo, hi in CUBOIDS:
+        te, tx = _slab(o, d, lo, hi)
+        hit = (te < tx) & (te > 0)
+        depth = np.where(hit & (te < depth), te, depth)
+    return depth
+
+
+def tracker_map_cloud(n_points, n_keyframes=32, seed=5, cfg=REPLICA, keyframe_every=10, first_frame=0):
+    """World-frame points of a MAP as the tracker sees it after many keyframes [REF mp_Tracker.py:282-288; scene/gaussian_model.py:207-215]:
+    the union of `n_keyframes` keyframes of `trajectory` (every `keyframe_every`-th frame), each contributing n_points / n_keyframes
+    back-projected depth samples at randomly picked integer pixels (sensor-quantised depth, the front-end's float32 arithmetic), so the
+    keyframes overlap on the same surfaces the way a real map does.  Returns dict(points (K,3) f32 world, keyframe (K,) int — which keyframe
+    a row came from, z (K,) f32 camera depth, poses: the keyframe poses, frame_ids).  Rows are in keyframe order; callers shuffle."""
+    rng = np.random.default_rng(seed)
+    poses_all = trajectory(first_frame + keyframe_every * n_keyframes + keyframe_every)
+    W, H = cfg["W"], cfg["H"]
+    per = [n_points // n_keyframes + (1 if k < n_points % n_keyframes else 0) for k in range(n_keyframes)]
+    pts, kf, zs, poses, ids = [], [], [], [], []
+    for k in range(n_keyframes):
+        fid = first_frame + keyframe_every * k
+        pose = poses_all[fid]
+        pix = rng.choice(W * H, size=per[k], replace=False) if per[k] <= W * H else rng.integers(0, W * H, per[k])
+        u, v = (pix % W).astype(np.float32), (pix // W).astype(np.float32)
+        depth = raycast_pixels(cfg, pose, u, v)
+        d16 = np.clip(np.round(depth * cfg["depth_scale"]), 0, 65535).astype(np.uint16)
+        z = d16.astype(np.float32) / np.float32(cfg["depth_scale"])
+        x_pre = (u - np.float32(cfg["cx"])) / np.float32(cfg["fx"])
+        y_pre = (v - np.float32(cfg["cy"])) / np.float32(cfg["fy"])
+        pc = np.stack([x_pre * z, y_pre * z, z], -1).astype(np.float32)
+        keep = (z != 0) & (z <= cfg["depth_trunc"])
+        pc, z = pc[keep], z[keep]
+        pw = (pc.astype(np.float64) @ pose[:3, :3].T + pose[:3, 3]).astype(np.float32)
+        pts.append(pw); kf.append(np.full(len(pw), k, np.int32)); zs.append(z); poses.append(pose); ids.append(fid)
+    return dict(points=np.concatenate(pts), keyframe=np.concatenate(kf), z=np.concatenate(zs), poses=poses, frame_ids=ids)
+
+
+def tracker_map(n_target, cov_fn, n_keyframes=32, seed=5, cfg=REPLICA, pass_fraction=0.5, opacity_th=0.05):
+    """A synthetic MAP of Gaussians sized so that ~n_target of them pass the tracker hand-off's selection
+    `opacity > opacity_th and trackable` [REF scene/gaussian_model.py:207-215]: n_target / pass_fraction rows in random order, positions from
+    `tracker_map_cloud`, rotations (xyzw) / scales from `cov_fn(world_points_of_one_keyframe) -> (rots (n,4), scales (n,3))` — the k-NN
+    covariance export of whichever registration object the caller hands in (the oracle in tests, the HIP tracker in bench.py) — with the
+    scales shrunk as the mapper's initialisation shrinks them (scales / clamp_min(2 z^1.5, 1)) [REF scene/gaussian_model.py:143-145].
+    Rows failing the selection are split between non-trackable ones and low-opacity ones."""
+    total = int(round(n_target / pass_fraction))
+    cloud = tracker_map_cloud(total, n_keyframes=n_keyframes, seed=seed, cfg=cfg)
+    pts, kf, z = cloud["points"], cloud["keyframe"], cloud["z"]
+    rots = np.zeros((len(pts), 4), np.float32)
+    scales = np.zeros((len(pts), 3), np.float32)
+    for k in range(n_keyframes):
+        sel = np.where(kf == k)[0]
+        r, s = cov_fn(pts[sel])
+        rots[sel] = np.reshape(r, (-1, 4))
+        scales[sel] = np.reshape(s, (-1, 3))
+    scales = (scales / np.maximum(2.0 * z[:, None] ** 1.5, 1.0)).astype(np.float32)
+    rng = np.random.default_rng(seed + 1)
+    perm = rng.permutation(len(pts))
+    pts, rots, scales = pts[perm], rots[perm], scales[perm]
+    u = rng.random(len(pts))
+    fail = u >= pass_fraction
+    trackable = ~(fail & (u < pass_fraction + 0.5 * (1.0 - pass_fraction)))          # first half of the failing rows: not trackable
+    opacity = np.where(fail & trackable, rng.uniform(0.0, opacity_th, len(pts)),      # second half: opacity at or below the threshold
+                       rng.uniform(opacity_th + 1e-3, 1.0, len(pts))).astype(np.float32)
+    return dict(points=pts, rotations=rots, scales=scales, opacity=opacity, trackable=trackable, opacity_th=float(opacity_th),
+                poses=cloud["poses"], frame_ids=cloud["frame_ids"])
+
+
 # ------------------------------------------------------------------------------------------ surfel map
 def _faces():
     """(origin, edge_u, edge_v, inward/outward normal) rectangles of the room (facing in) and cuboids (facing out)."""

@@ -223,6 +223,10 @@ int gsicp_gicp_knn_stats(gsicp_gicp* g, double out[12]);
 int gsicp_gicp_align_trace(gsicp_gicp* g, unsigned long long* out, int cap_pairs);
 int gsicp_gicp_num_source(gsicp_gicp*);
 int gsicp_gicp_num_target(gsicp_gicp*);
+/* Sizes of the target search structure as of the last build (align builds it lazily after a target / gate change):
+ * out = {trackable targets, uses the hashed grid (0 = ungated scan), hash-table slots, hash-table bytes (keys + values), cell edge (m),
+ * bytes of the cell-sorted point copy, dense-grid cell capacity of the exact-distance export, its bytes}.  No synchronisation. */
+int gsicp_gicp_target_index_stats(gsicp_gicp*, double out[8]);
 /* out[0..5]: kernel launches of the last align, LM trials, final cost, converged flag, device microseconds, reserved */
 int gsicp_gicp_last_align_stats(gsicp_gicp*, double out[6]);
 /* Robustness of the persistent align kernel's grid barrier.  The launch never exceeds the number of workgroups the device can hold at

@@ -379,3 +379,161 @@ def test_knn_covariances_match_oracle_on_awkward_clouds(name):
     np.testing.assert_allclose(sg, so, rtol=2e-5, atol=1e-7)
     cg, co = quat_cov(qg.astype(np.float64), sg.astype(np.float64)), quat_cov(qo.astype(np.float64), so.astype(np.float64))
     np.testing.assert_allclose(cg, co, atol=2e-6 * max(1.0, float(np.abs(co).max())))
+
+
+# ---------------------------------------------------------------------------------------------- map-sized targets (steady state)
+def _oracle_knn_export(pw):
+    import oracle
+    r = oracle.OracleGICP()
+    r.set_max_knn_distance(99999.0)
+    r.set_input_target(pw)
+    r.calculate_target_covariance_with_filter()
+    return r.get_target_rotationsq(), r.get_target_scales()
+
+
+_MAP_CACHE = {}
+
+
+def _tracker_map(K):
+    if K not in _MAP_CACHE:
+        _MAP_CACHE.clear()                       # one map at a time (2 M rows at K = 1e6)
+        _MAP_CACHE[K] = synth.tracker_map(K, _oracle_knn_export)
+    return _MAP_CACHE[K]
+
+
+def _source_frame(fid):
+    cfg = synth.REPLICA
+    poses = synth.trajectory(fid + 1)
+    pts, _, trackable, _ = synth.frame_points(cfg, poses[fid])
+    return poses, pts, trackable
+
+
+@pytest.mark.parametrize("back", [1, 8])
+@pytest.mark.parametrize("K", [100_000, 1_000_000])
+def test_align_against_map_sized_target(K, back):
+    """The tracker's STEADY-STATE configuration [REF mp_Tracker.py:282-288; scene/gaussian_model.py:207-215; gs_icp_slam.py:86 (capacity 10 M)]:
+    after the first tracking keyframe the target is the MAP's trackable Gaussians — here ~K of them out of 2K rows (32 keyframes of the
+    synthetic trajectory, random order, k-NN quaternions / shrunk scales, half the rows non-trackable or at / below the opacity threshold) — handed
+    over as `set_input_target(points f32)` + `set_target_covariances_fromqs(rots.flatten(), scales.flatten())`.  The source is one 8 280-point
+    frame between two keyframes; the initial guess is the pose `back` frames earlier (7 mm / 56 mm away).
+    Three routes to the same target must agree with the oracle and with each other:
+      (i)   the reference's route: rows selected on the host, numpy in;
+      (ii)  all 2K rows + `set_target_filter` (the selection as a filter): correspondence indices then refer to the unselected array;
+      (iii) `set_target_from_gaussians`: selection + covariances on the device.
+    Bars: correspondence indices and squared distances bit-exact (also beyond the gate), pose <= 1e-6, same LM iteration count."""
+    import oracle
+    import pygicp
+    import torch
+    cfg = synth.REPLICA
+    m = _tracker_map(K)
+    keep = m["trackable"] & (m["opacity"] > m["opacity_th"])
+    sel = np.where(keep)[0]
+    assert abs(len(sel) - K) < 0.02 * K
+    fid = 155
+    poses, src, trackable = _source_frame(fid)
+    f_src = filt(len(src), trackable)
+    init = poses[fid - back]
+    tp, tr, ts = m["points"][sel], m["rotations"][sel], m["scales"][sel]
+
+    def frame(reg):
+        reg.set_input_source(src)
+        reg.set_source_filter(len(trackable), f_src)
+        T = reg.align(init)
+        idx, d2 = reg.get_source_correspondence()
+        return T, idx, d2
+
+    def host_route(reg):
+        reg.set_max_correspondence_distance(cfg["max_corr"])
+        reg.set_max_knn_distance(99999.0)
+        reg.set_input_target(tp)
+        reg.set_target_covariances_fromqs(tr.flatten(), ts.flatten())
+        return frame(reg)
+
+    oreg, reg = oracle.OracleGICP(), pygicp.FastGICP()
+    To, io, do = host_route(oreg)
+    Tp, ip, dp = host_route(reg)
+    st = reg.last_align_stats()
+    ang, mm = pose_err(Tp, poses[fid])
+    print(f"map-sized target K={len(sel)} back={back}: HIP {st}, oracle {oreg.stats()}, pose error {ang:.5f} deg / {mm:.3f} mm, "
+          f"in-gate {np.mean(do < cfg['max_corr'] ** 2):.3f}")
+    assert ip.shape == io.shape == (len(trackable),)
+    assert np.array_equal(ip, io), f"{(ip != io).sum()} correspondence indices differ"
+    assert np.array_equal(dp, do), f"max |d2 diff| {np.abs(dp - do).max()}"
+    np.testing.assert_allclose(Tp, To, rtol=0, atol=1e-6)
+    assert st["iterations"] == oreg.iterations and st["barrier_retries"] == 0
+    assert ang < 0.01 and mm < 0.5
+
+    # (ii) the selection as a target filter over all rows
+    f_tgt = filt(len(m["points"]), sel)
+    res = []
+    for r2 in (oracle.OracleGICP(), pygicp.FastGICP()):
+        r2.set_max_correspondence_distance(cfg["max_corr"])
+        r2.set_input_target(m["points"])
+        r2.set_target_filter(len(sel), f_tgt)
+        r2.set_target_covariances_fromqs(m["rotations"].flatten(), m["scales"].flatten())
+        res.append(frame(r2))
+    (T2o, i2o, d2o), (T2p, i2p, d2p) = res
+    assert np.array_equal(i2p, i2o) and np.array_equal(d2p, d2o)
+    np.testing.assert_allclose(T2p, T2o, rtol=0, atol=1e-6)
+    hit = ip >= 0
+    assert np.array_equal(i2p >= 0, hit) and np.array_equal(i2p[hit], sel[ip[hit]]) and np.array_equal(d2p, dp)   # same match, index into the full array
+    np.testing.assert_array_equal(T2p, Tp)
+
+    # (iii) the device hand-off
+    dev = "cuda"
+    r3 = pygicp.FastGICP()
+    r3.set_max_correspondence_distance(cfg["max_corr"])
+    n = r3.set_target_from_gaussians(torch.from_numpy(m["points"]).to(dev), torch.from_numpy(m["rotations"]).to(dev),
+                                     torch.from_numpy(m["scales"]).to(dev), torch.from_numpy(m["opacity"]).to(dev),
+                                     trackable_mask=torch.from_numpy(m["trackable"]).to(dev), opacity_th=m["opacity_th"])
+    assert n == len(sel)
+    T3, i3, d3 = frame(r3)
+    assert np.array_equal(i3, ip) and np.array_equal(d3, dp)
+    np.testing.assert_array_equal(T3, Tp)
+
+
+def test_map_sized_target_with_points_beyond_the_gate():
+    """A map-sized target that covers only PART of what the source sees (the first 6 keyframes of the trajectory, viewed from frame 200): a
+    large share of the source has no neighbour inside the gate, so the miss list, the dense exact-NN grid over 1e5 targets and the export
+    all work at scale; distances beyond the gate are the raw nearest-neighbour d2, as the reference's thresholds need [REF mp_Tracker.py:235]."""
+    import oracle
+    import pygicp
+    cfg = synth.REPLICA
+    cloud = synth.tracker_map_cloud(100_000, n_keyframes=6, seed=9)
+    rots, scales = _oracle_knn_export(cloud["points"])
+    fid = 200
+    poses, src, trackable = _source_frame(fid)
+    f_src = filt(len(src), trackable)
+    out = []
+    for reg in (oracle.OracleGICP(), pygicp.FastGICP()):
+        reg.set_max_correspondence_distance(cfg["max_corr"])
+        reg.set_input_target(cloud["points"])
+        reg.set_target_covariances_fromqs(rots, scales)
+        reg.set_input_source(src)
+        reg.set_source_filter(len(trackable), f_src)
+        T = reg.align(poses[fid - 1])
+        out.append((T,) + tuple(reg.get_source_correspondence()))
+    (To, io, do), (Tp, ip, dp) = out
+    frac = float((io < 0).mean())
+    print(f"partial map: {frac:.3f} of the source beyond the gate, max d2 {do.max():.4f}")
+    assert 0.1 < frac < 0.95
+    assert np.array_equal(ip, io) and np.array_equal(dp, do)
+    np.testing.assert_allclose(Tp, To, rtol=0, atol=1e-6)
+
+
+def test_knn_covariances_of_a_map_sized_cloud():
+    """`calculate_target_covariance_with_filter` above the single-workgroup grid build (> 32 768 points: the four-launch counting sort) on a
+    1e5-point multi-keyframe cloud: exported scales / covariances equal the oracle's kd-tree k-NN to summation-order tolerance."""
+    import pygicp
+    cloud = synth.tracker_map_cloud(100_000, n_keyframes=6, seed=9)
+    qo, so = _oracle_knn_export(cloud["points"])
+    reg = pygicp.FastGICP()
+    reg.set_max_knn_distance(99999.0)
+    reg.set_input_target(cloud["points"])
+    reg.calculate_target_covariance_with_filter()
+    qg = np.reshape(reg.get_target_rotationsq(), (-1, 4)).astype(np.float64)
+    sg = np.reshape(reg.get_target_scales(), (-1, 3)).astype(np.float64)
+    qo, so = np.reshape(qo, (-1, 4)).astype(np.float64), np.reshape(so, (-1, 3)).astype(np.float64)
+    print("knn stats", reg.knn_stats())
+    np.testing.assert_allclose(sg, so, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(quat_cov(qg, sg), quat_cov(qo, so), rtol=0, atol=2e-7)
