@@ -190,7 +190,11 @@ def tracker_vs_map_leg(sizes=(8280, 100_000, 1_000_000), frames=60, fid=155, bac
         stage = {k: round(1e3 * ms / 20, 2) for k, (ms, c) in _lib.profile_read().items() if c > 0 and k.startswith("gicp")}
         _lib.profile_enable(False)
         ix = reg.target_index_stats()
-        cells = np.unique(np.floor(tp.astype(np.float64) / ix["cell_m"]).astype(np.int64), axis=0, return_counts=True)[1] if ix["hashed_grid"] else np.zeros(1)
+        for lv in ix["levels"]:      # how full the cells are (numpy recount on the host; the library reports the sizes)
+            fine = np.floor(tp.astype(np.float64) / (0.5 * lv["cell_m"])).astype(np.int64)
+            cc, fc = (np.unique(a_, axis=0, return_counts=True)[1] for a_ in (fine >> 1, fine))
+            lv.update(points_per_coarse_cell_mean_max=[round(float(cc.mean()), 2), int(cc.max())],
+                      points_per_fine_cell_mean_max=[round(float(fc.mean()), 2), int(fc.max())])
         gt = poses[fid]
         med = lambda i, rows: float(statistics.median(r[i] for r in rows))   # noqa: E731
         out["sizes"][str(K)] = {
@@ -204,7 +208,7 @@ def tracker_vs_map_leg(sizes=(8280, 100_000, 1_000_000), frames=60, fid=155, bac
             "pose_error_mm": round(1e3 * float(np.linalg.norm(np.asarray(T_host, np.float64)[:3, 3] - gt[:3, 3])), 4),
             "in_gate_fraction": round(float((idx_host >= 0).mean()), 4),
             "device_route_equals_host_route": bool(np.array_equal(idx_host, idx_dev) and np.array_equal(d2_host, d2_dev) and np.array_equal(T_host, T_dev)),
-            "index": dict(ix, occupied_cells=int(len(cells)), mean_points_per_cell=round(float(cells.mean()), 2), max_points_per_cell=int(cells.max())),
+            "index": ix,
         }
         del reg, g_dev, mask_dev
     return out

@@ -63,19 +63,21 @@ constexpr int NRED = 28;  // 21 (upper H) + 6 (b) + 1 (cost)
 
 struct GridView {
     int use_grid;             // 0 -> brute force over `n_sorted` points
-    float inv_h;              // 1 / cell size
+    float inv_hf, hf;         // FINE cell edge hf = gate radius x 1.001 and its inverse; a hashed COARSE cell is a 2x2x2 block of fine cells
     unsigned mask;            // table capacity - 1
-    const unsigned long long* keys;
-    const unsigned long long* vals;   // start << 32 | count
-    const float4* sorted;     // xyz + original index bits, sorted by cell key
+    const unsigned long long* keys;   // coarse-cell key per slot (EMPTY_KEY = free); probe sequences start at 4-slot buckets
+    const unsigned* ords;             // per slot: ordinal of the coarse cell
+    const uint2* cells;               // [ordinal * 8 + octant] = {first index in `sorted`, count} of that fine cell
+    const float4* sorted;     // xyz + original index bits, sorted by (coarse cell, octant)
     int n_sorted;
 };
 
 // ---------------------------------------------------------------------------------------------- device helpers
+// 20 bits per axis (coarse cells of >= 4 cm: +-20 km), so that key << 3 | octant still fits the 63 bits the radix sort looks at
 __device__ inline unsigned long long cell_key(int cx, int cy, int cz) {
-    const unsigned long long o = 1ull << 20;
-    return ((unsigned long long)(cx + (long long)o) & 0x1FFFFFull) << 42 | ((unsigned long long)(cy + (long long)o) & 0x1FFFFFull) << 21 |
-           ((unsigned long long)(cz + (long long)o) & 0x1FFFFFull);
+    const unsigned long long o = 1ull << 19;
+    return ((unsigned long long)(cx + (long long)o) & 0xFFFFFull) << 40 | ((unsigned long long)(cy + (long long)o) & 0xFFFFFull) << 20 |
+           ((unsigned long long)(cz + (long long)o) & 0xFFFFFull);
 }
 __device__ inline unsigned hash_key(unsigned long long k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
@@ -85,10 +87,22 @@ __device__ inline float dist2(float qx, float qy, float qz, float px, float py, 
     const float dx = qx - px, dy = qy - py, dz = qz - pz;
     return dx * dx + dy * dy + dz * dz;
 }
+constexpr unsigned NO_CELL = 0xFFFFFFFFu;
 
-// Exact nearest neighbour among the 8 cells around q (complete for every target point within h/2 of q).
-// Ties -> lowest original index.  Returns best squared distance / index (FLT_MAX / -1 if the cells are empty).
-__device__ inline void grid_nn(const GridView& g, float qx, float qy, float qz, float& best_d, int& best_i) {
+// Exact nearest neighbour among the 27 FINE cells around q (complete for every target point within the gate radius of q: a fine cell's
+// edge is the radius x 1.001).  Ties -> lowest original index.  Returns best squared distance / index (FLT_MAX / -1 if the cells are empty).
+//
+// Round 4: map-sized targets.  Until round 3 the index was the coarse grid alone (cell edge = 2 x gate, the 8 cells around q scanned in
+// full): right for a depth frame's cloud (1.5 points per cell), but the tracker's steady-state target is the MAP — 1e5..1e6 Gaussians on the
+// same surfaces, 6..60 points per cell (max 257 measured) — and one lane walking 8 x 57 candidates four loads at a time made a linearisation
+// 200 us (align 655 us at K = 1e6 against 64 us at K = 8 k, profiles/r04_tracker_vs_map_before_octants.json).  Now the points of a coarse cell are
+// sorted by OCTANT (2x2x2 fine cells) and every coarse cell carries the eight {begin, count} pairs: a query visits its own fine cell first,
+// then the 26 around it nearest-first, and skips every fine cell whose box is farther than the best distance so far (strictly: ties still
+// scan, the tie-break is by index).  In a dense map the own cell settles it; the result is the same bits: (d, id) is a total order and
+// a skipped cell cannot hold a smaller pair.  The 27 fine cells live in exactly the 8 coarse cells the old search hashed, so the table
+// probes are unchanged: ONE round of independent bucket loads, one round of 27 {begin, count} loads, then the candidates.
+constexpr int AL_T_CONST = 256;   // = AL_T (threads per workgroup of the align kernel); stride of the per-lane LDS work list
+__device__ __forceinline__ void grid_nn(const GridView& g, float qx, float qy, float qz, float& best_d, int& best_i, uint2* __restrict__ queue) {
     best_d = FLT_MAX; best_i = -1;
     if (!g.use_grid) {
         for (int j = 0; j < g.n_sorted; ++j) {
@@ -99,80 +113,171 @@ __device__ inline void grid_nn(const GridView& g, float qx, float qy, float qz, 
         }
         return;
     }
-    const float fx = qx * g.inv_h, fy = qy * g.inv_h, fz = qz * g.inv_h;
-    const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
-    const int ox = (fx - flx) >= 0.5f ? 1 : -1, oy = (fy - fly) >= 0.5f ? 1 : -1, oz = (fz - flz) >= 0.5f ? 1 : -1;
-    // Latency is everything here (one point per thread, 30-odd dependent loads if done cell by cell).  The table is read in
-    // 4-slot buckets (64-byte aligned: 4 keys + 4 values = four 16-byte loads) and a key's probe sequence starts at its bucket, so
-    // one round of 32 independent loads answers all 8 cells; the sequential continuation only runs when a bucket is full of other
-    // keys (load factor 1/8: ~1e-4 of the lookups).  A per-slot probe loop made the whole wave walk every lane's collision chain,
-    // cell after cell: 7 us of every phase.  Then the first point of every non-empty cell is fetched together.  The result does
-    // not depend on the visiting order: (d, id) is a total order.
-    unsigned long long key[8], cell[8];
-    unsigned slot[8];
-    ulonglong2 ka[8], kb[8], va[8], vb[8];
+    const float flx = floorf(qx * g.inv_hf), fly = floorf(qy * g.inv_hf), flz = floorf(qz * g.inv_hf);
+    const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+    const int px = ix & 1, py = iy & 1, pz = iz & 1;              // which half of its (home) coarse cell the query's fine cell is
+    const int hx = ix >> 1, hy = iy >> 1, hz = iz >> 1;           // home coarse cell (arithmetic shift = floor division)
+    const int sx = px ? 1 : -1, sy = py ? 1 : -1, sz = pz ? 1 : -1;   // the other coarse cell on each axis lies on the side of the query's half
+    // ---- round 1: the 8 coarse cells, one 4-slot bucket each (4 keys + 4 ordinals = three 16-byte loads), all in flight together.  A key's
+    // probe sequence starts at its bucket; the sequential continuation only runs when a bucket is full of other keys (load factor <= 1/8 in
+    // POINTS, far less in cells).  Latency is everything here: one point per thread, one wave per SIMD.
+    unsigned long long key[8];
+    unsigned slot[8], ord[8];
+    ulonglong2 ka[8], kb[8];
+    uint4 oa[8];
     const ulonglong2* K2 = (const ulonglong2*)g.keys;
-    const ulonglong2* V2 = (const ulonglong2*)g.vals;
+    const uint4* O4 = (const uint4*)g.ords;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        key[c] = cell_key(cx + ((c & 1) ? ox : 0), cy + ((c & 2) ? oy : 0), cz + ((c & 4) ? oz : 0));
+        key[c] = cell_key(hx + ((c & 1) ? sx : 0), hy + ((c & 2) ? sy : 0), hz + ((c & 4) ? sz : 0));
         slot[c] = (hash_key(key[c]) << 2) & g.mask;     // first slot of the key's bucket
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const unsigned h2 = slot[c] >> 1;
-        ka[c] = K2[h2]; kb[c] = K2[h2 + 1]; va[c] = V2[h2]; vb[c] = V2[h2 + 1];
+        ka[c] = K2[h2]; kb[c] = K2[h2 + 1]; oa[c] = O4[slot[c] >> 2];
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const unsigned long long k = key[c];
-        unsigned long long v = 0ull;
-        if (ka[c].x == k) v = va[c].x;
-        else if (ka[c].x == EMPTY_KEY) v = 0ull;
-        else if (ka[c].y == k) v = va[c].y;
-        else if (ka[c].y == EMPTY_KEY) v = 0ull;
-        else if (kb[c].x == k) v = vb[c].x;
-        else if (kb[c].x == EMPTY_KEY) v = 0ull;
-        else if (kb[c].y == k) v = vb[c].y;
+        unsigned v = NO_CELL;
+        if (ka[c].x == k) v = oa[c].x;
+        else if (ka[c].x == EMPTY_KEY) v = NO_CELL;
+        else if (ka[c].y == k) v = oa[c].y;
+        else if (ka[c].y == EMPTY_KEY) v = NO_CELL;
+        else if (kb[c].x == k) v = oa[c].z;
+        else if (kb[c].x == EMPTY_KEY) v = NO_CELL;
+        else if (kb[c].y == k) v = oa[c].w;
         else if (kb[c].y != EMPTY_KEY) {          // bucket full of other keys: continue the linear probe
             unsigned sl = (slot[c] + 4) & g.mask;
             for (;;) {
                 const unsigned long long kk = g.keys[sl];
-                if (kk == k) { v = g.vals[sl]; break; }
+                if (kk == k) { v = g.ords[sl]; break; }
                 if (kk == EMPTY_KEY) break;
                 sl = (sl + 1) & g.mask;
             }
         }
-        cell[c] = v;
+        ord[c] = v;
     }
-    float4 p0[8];
+    // ---- round 2: {begin, count} of the 27 fine cells.  Fine cell (dx, dy, dz) relative to the query's: on each axis d = 0 and d = -s stay in
+    // the home coarse cell (octant bit p and p ^ 1), d = +s is the other coarse cell's adjacent half (octant bit p ^ 1).  The coarse ordinal
+    // is picked by three levels of selects shared between the cells (38 selects, not 27 x 7); everything is indexed statically.
+    unsigned A[3][2][2], B[3][3][2], C[3][3][3];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const unsigned start = (unsigned)(cell[c] >> 32), cnt = (unsigned)cell[c];
-        p0[c] = g.sorted[cnt ? start : 0u];     // unconditional load (index 0 is always valid when the grid is in use)
-    }
+    for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const unsigned start = (unsigned)(cell[c] >> 32), cnt = (unsigned)cell[c];
-        if (cnt) {
-            const float d = dist2(qx, qy, qz, p0[c].x, p0[c].y, p0[c].z);
-            const int id = __float_as_int(p0[c].w);
-            if (d < best_d || (d == best_d && id < best_i)) { best_d = d; best_i = id; }
+        for (int cz = 0; cz < 2; ++cz) {
+            const unsigned o0 = ord[0 + 2 * cy + 4 * cz], o1 = ord[1 + 2 * cy + 4 * cz];
+            A[1][cy][cz] = o0;
+            A[2][cy][cz] = px ? o1 : o0;     // dx = +1 is the other coarse cell iff the query sits in the upper half
+            A[0][cy][cz] = px ? o0 : o1;
         }
-        for (unsigned j = 1; j < cnt; j += 4) {   // dense cells: four independent loads per round (the slowest lane of the wave sets the pace)
-            float4 pj[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) pj[u] = g.sorted[start + (j + u < cnt ? j + u : j)];
+    for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (j + u < cnt) {
+        for (int cz = 0; cz < 2; ++cz) {
+            B[dx][1][cz] = A[dx][0][cz];
+            B[dx][2][cz] = py ? A[dx][1][cz] : A[dx][0][cz];
+            B[dx][0][cz] = py ? A[dx][0][cz] : A[dx][1][cz];
+        }
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            C[dx][dy][1] = B[dx][dy][0];
+            C[dx][dy][2] = pz ? B[dx][dy][1] : B[dx][dy][0];
+            C[dx][dy][0] = pz ? B[dx][dy][0] : B[dx][dy][1];
+        }
+    const unsigned obx[3] = {(unsigned)(px ^ 1), (unsigned)px, (unsigned)(px ^ 1)};
+    const unsigned oby[3] = {(unsigned)(py ^ 1) << 1, (unsigned)py << 1, (unsigned)(py ^ 1) << 1};
+    const unsigned obz[3] = {(unsigned)(pz ^ 1) << 2, (unsigned)pz << 2, (unsigned)(pz ^ 1) << 2};
+    uint2 rec[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        const int dx = t % 3, dy = (t / 3) % 3, dz = t / 9;
+        const unsigned o = C[dx][dy][dz];
+        const unsigned idx = (o == NO_CELL ? 0u : o * 8u) + (obx[dx] + oby[dy] + obz[dz]);   // unconditional load (cell 0 exists when the grid is in use)
+        rec[t] = g.cells[idx];
+        if (o == NO_CELL) rec[t].y = 0u;
+    }
+    // squared distance from q to the slab of fine cells at offset -1 / +1 on each axis, made CONSERVATIVE: the cell of a point is
+    // floorf(p * inv_hf) in float arithmetic, so a cell's real extent is blurred by a few ulps of the coordinate, and the candidates'
+    // own distances are rounded — the slack (a thousandth of a cell, or 8 ulps of the coordinate if larger) only ever makes a cell look
+    // nearer, i.e. scans a little more.
+    float gm2[3], gp2[3];
+    {
+        const float q[3] = {qx, qy, qz}, fl[3] = {flx, fly, flz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float slack = fmaxf(g.hf * 1e-3f, fabsf(q[a]) * 9.5367431640625e-07f);
+            const float lo = fl[a] * g.hf, hi = (fl[a] + 1.0f) * g.hf;
+            const float gm = fmaxf((q[a] - lo) - slack, 0.f), gp = fmaxf((hi - q[a]) - slack, 0.f);
+            gm2[a] = gm * gm * 0.9999f; gp2[a] = gp * gp * 0.9999f;
+        }
+    }
+    // ---- round 3+: own fine cell first, then the non-empty neighbours nearest-first (faces, edges, corners), each skipped when its box is
+    // farther than the best pair so far.  The neighbours wait in a per-lane work list in LDS (`queue[k * AL_T]`, filled by static code; an
+    // entry packs the cell's position code, 2 bits per axis, above the count < 2^26), and ONE loop scans: every lane walks ITS OWN list —
+    // skipping pruned entries costs LDS reads only — and takes 8 candidates per trip (8 independent loads: 128 B, one cache line when
+    // aligned), so a wave makes as many trips as its busiest lane has 8-candidate chunks, not one per list slot anybody uses.  (26 statically
+    // unrolled scan loops made the persistent kernel 17 k instructions: it stopped being inlined as a whole and its fp64 accumulators went
+    // through scratch memory.)
+    int nq = 0;
+#pragma unroll
+    for (int pass = 1; pass < 4; ++pass) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int dx = t % 3, dy = (t / 3) % 3, dz = t / 9;
+            if ((dx != 1) + (dy != 1) + (dz != 1) != pass) continue;
+            if (rec[t].y != 0u) {
+                queue[nq * AL_T_CONST] = make_uint2(rec[t].x, rec[t].y | (unsigned)(dx | dy << 2 | dz << 4) << 26);
+                ++nq;
+            }
+        }
+    }
+    unsigned cs = rec[13].x, cc = rec[13].y, cj = 0u;     // the range being scanned (starts with the own cell), offset of its next chunk
+    int qi = 0;
+    for (;;) {
+        while (cj >= cc && qi < nq) {
+            const uint2 e = queue[qi * AL_T_CONST];
+            ++qi;
+            const unsigned code = e.y >> 26;
+            const unsigned cx = code & 3u, cy = (code >> 2) & 3u, cz = code >> 4;
+            const float m2 = (cx == 0u ? gm2[0] : (cx == 2u ? gp2[0] : 0.f)) + (cy == 0u ? gm2[1] : (cy == 2u ? gp2[1] : 0.f)) +
+                             (cz == 0u ? gm2[2] : (cz == 2u ? gp2[2] : 0.f));
+            if (m2 > best_d) continue;
+            cs = e.x; cc = e.y & 0x3FFFFFFu; cj = 0u;
+        }
+        if (cj >= cc) break;
+        // 8 candidates per trip, 16 where more than 8 are left in the range (the second eight sit behind a wave-uniform skip: a sparse
+        // target never issues them, a dense cell halves its trips — every trip is a dependent memory latency)
+        float4 pj[16];
+        const bool wide = cc - cj > 8u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pj[u] = g.sorted[cs + (cj + u < cc ? cj + u : cj)];
+        if (wide) {
+#pragma unroll
+            for (int u = 8; u < 16; ++u) pj[u] = g.sorted[cs + (cj + u < cc ? cj + u : cj)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (cj + u < cc) {
+                const float d = dist2(qx, qy, qz, pj[u].x, pj[u].y, pj[u].z);
+                const int id = __float_as_int(pj[u].w);
+                if (d < best_d || (d == best_d && id < best_i)) { best_d = d; best_i = id; }
+            }
+        }
+        if (wide) {
+#pragma unroll
+            for (int u = 8; u < 16; ++u) {
+                if (cj + u < cc) {
                     const float d = dist2(qx, qy, qz, pj[u].x, pj[u].y, pj[u].z);
                     const int id = __float_as_int(pj[u].w);
                     if (d < best_d || (d == best_d && id < best_i)) { best_d = d; best_i = id; }
                 }
             }
         }
+        cj += wide ? 16u : 8u;
     }
 }
 
@@ -963,37 +1068,70 @@ __global__ __launch_bounds__(256) void cov_fromqs_kernel(int n, int reg_method, 
 }
 
 // ---------------------------------------------------------------------------------------------- hash grid build
+// sort key = coarse-cell key << 3 | octant: a coarse cell's points come out contiguous, ordered by fine cell, in track order within one
 __global__ __launch_bounds__(256) void grid_keys_kernel(int n_track, const int* __restrict__ track, const float4* __restrict__ pts,
-                                                        float inv_h, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+                                                        float inv_hf, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
+                                                        unsigned* __restrict__ n_cells) {
     const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s == 0) { n_cells[0] = 0u; n_cells[1] = 0u; }     // [0] counted runs (read back by the host), [1] ordinal allocator of grid_cells_kernel
     if (s >= n_track) return;
     const int i = track[s];
     const float4 p = pts[i];
-    keys[s] = cell_key((int)floorf(p.x * inv_h), (int)floorf(p.y * inv_h), (int)floorf(p.z * inv_h));
+    const int fx = (int)floorf(p.x * inv_hf), fy = (int)floorf(p.y * inv_hf), fz = (int)floorf(p.z * inv_hf);
+    keys[s] = cell_key(fx >> 1, fy >> 1, fz >> 1) << 3 | (unsigned long long)((fx & 1) | (fy & 1) << 1 | (fz & 1) << 2);
     vals[s] = (unsigned)i;
 }
-// sorted (key, original index) -> sorted float4 records; first element of each run inserts {start,count} in the table
-__global__ __launch_bounds__(256) void grid_fill_kernel(int n, const unsigned long long* __restrict__ skeys, const unsigned* __restrict__ svals,
-                                                        const float4* __restrict__ pts, float4* __restrict__ sorted, unsigned mask,
-                                                        unsigned long long* __restrict__ tkeys, unsigned long long* __restrict__ tvals) {
+// occupied coarse cells (runs of the sorted keys): one atomic per workgroup; the host reads the total back to size the table by CELLS
+__global__ __launch_bounds__(256) void grid_count_cells_kernel(int n, const unsigned long long* __restrict__ skeys, unsigned* __restrict__ n_cells) {
+    __shared__ unsigned s_w[4];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const bool first = s < n && (s == 0 || (skeys[s - 1] >> 3) != (skeys[s] >> 3));
+    const unsigned long long b = __ballot(first);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned c = s_w[0] + s_w[1] + s_w[2] + s_w[3]; if (c) atomicAdd(n_cells, c); }
+}
+// sorted (key, original index) -> sorted float4 records; the first element of each COARSE run takes the next cell ordinal, inserts
+// {coarse key -> ordinal} in the table and clears the cell's eight {begin, count} pairs
+__global__ __launch_bounds__(256) void grid_cells_kernel(int n, const unsigned long long* __restrict__ skeys, const unsigned* __restrict__ svals,
+                                                         const float4* __restrict__ pts, float4* __restrict__ sorted, unsigned mask,
+                                                         unsigned long long* __restrict__ tkeys, unsigned* __restrict__ tords,
+                                                         uint2* __restrict__ cells, unsigned* __restrict__ n_cells) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
     const unsigned id = svals[s];
     float4 p = pts[id];
     p.w = __int_as_float((int)id);
     sorted[s] = p;
-    const unsigned long long key = skeys[s];
-    if (s == 0 || skeys[s - 1] != key) {
-        unsigned cnt = 1;
-        while (s + (int)cnt < n && skeys[s + cnt] == key) ++cnt;
+    const unsigned long long key = skeys[s] >> 3;
+    if (s == 0 || (skeys[s - 1] >> 3) != key) {
+        const unsigned ord = atomicAdd(n_cells + 1, 1u);
         unsigned slot = (hash_key(key) << 2) & mask;   // first slot of the key's 4-slot bucket (grid_nn reads whole buckets)
         for (;;) {
             const unsigned long long prev = atomicCAS(&tkeys[slot], EMPTY_KEY, key);
             if (prev == EMPTY_KEY) break;
             slot = (slot + 1) & mask;
         }
-        tvals[slot] = ((unsigned long long)(unsigned)s << 32) | cnt;
+        tords[slot] = ord;
+        uint4* c4 = (uint4*)(cells + (size_t)ord * 8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c4[k] = make_uint4(0u, 0u, 0u, 0u);
     }
+}
+// second pass (the table is complete): the first element of each FINE run looks its coarse cell up and writes {begin, count}
+__global__ __launch_bounds__(256) void grid_octants_kernel(int n, const unsigned long long* __restrict__ skeys, unsigned mask,
+                                                           const unsigned long long* __restrict__ tkeys, const unsigned* __restrict__ tords,
+                                                           uint2* __restrict__ cells) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const unsigned long long fk = skeys[s];
+    if (s != 0 && skeys[s - 1] == fk) return;
+    unsigned cnt = 1;
+    while (s + (int)cnt < n && skeys[s + cnt] == fk) ++cnt;
+    const unsigned long long key = fk >> 3;
+    unsigned slot = (hash_key(key) << 2) & mask;
+    while (tkeys[slot] != key) slot = (slot + 1) & mask;      // present by construction
+    cells[(size_t)tords[slot] * 8 + (unsigned)(fk & 7ull)] = make_uint2((unsigned)s, cnt);
 }
 // brute-force "grid": just the trackable points in index order
 __global__ __launch_bounds__(256) void gather_track_kernel(int n_track, const int* __restrict__ track, const float4* __restrict__ pts,
@@ -1043,7 +1181,9 @@ struct AlignArgs {
     const double* src_cov;
     const float4* tgt_pts;     // original order
     const double* tgt_cov;
-    GridView grid;
+    GridView grid;             // complete within the gate radius
+    GridView fine;             // dense maps only (use_grid = 0 otherwise): the same structure at a smaller radius, tried first
+    float fine_r2;             // squared radius the fine level is complete within
     float gate;                // squared correspondence gate (FLT_MAX = none)
     double init[12];           // R, t
     int max_iter, lm_max_iter;
@@ -1373,8 +1513,8 @@ __device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, un
 // Linearisation at pose x (R 9, t 3): nearest target inside the gate (fp32 search, fixed order), Mahalanobis matrix, and this
 // thread's share of H (21), b (6), cost (1) over its strided source points.  Writes the correspondences / distances / matrices
 // of the points it owns into the given buffer set.
-__device__ inline void linearize_points(const AlignArgs& a, const double* __restrict__ x, int* __restrict__ corr, float* __restrict__ sqd,
-                                        double* __restrict__ maha, int gtid, int gstride, double* __restrict__ acc, int* tn = nullptr) {
+__device__ __forceinline__ void linearize_points(const AlignArgs& a, const double* __restrict__ x, int* __restrict__ corr, float* __restrict__ sqd,
+                                        double* __restrict__ maha, int gtid, int gstride, double* __restrict__ acc, uint2* __restrict__ queue, int* tn = nullptr) {
     // Register diet (round 3): the pose stays in LDS (`x` points at sh.x0 / sh.xi; every read is a broadcast) instead of 24 + 12 live
     // registers, and the 3x6 Jacobian J = [skew(T p) | -I] is never formed: its zeros and -1s are folded by hand.  Folding is EXACT, not an
     // approximation — 0 * finite = 0, 0 + v = v, (-1) * v = -v, u + (-v) = u - v in IEEE arithmetic (no contraction in this file) — and the
@@ -1393,7 +1533,16 @@ __device__ inline void linearize_points(const AlignArgs& a, const double* __rest
         }
         float bd; int bi;
         if (tn) trace_stamp(a.trace, *tn, 20);
-        grid_nn(a.grid, qx, qy, qz, bd, bi);
+        // A neighbour found inside the fine level's radius is THE nearest neighbour (that level is complete within its radius, and
+        // anything nearer would lie inside it too); otherwise the gate-sized level answers.  Same (d, id) either way.
+        // (One copy of the search code: a loop over the levels, not two inlined calls — the kernel must stay inlinable as a whole, or the
+        // fp64 accumulators and the argument block travel through scratch memory.)
+#pragma nounroll
+        for (int lv = a.fine.use_grid ? 0 : 1; lv < 2; ++lv) {
+            GridView gv = lv == 0 ? a.fine : a.grid;
+            grid_nn(gv, qx, qy, qz, bd, bi, queue);
+            if (lv == 0 && bd < a.fine_r2) break;
+        }
         if (tn) trace_stamp(a.trace, *tn, 21);
         sqd[s] = bd;
         int c = -1;
@@ -1478,14 +1627,22 @@ __device__ inline void linearize_points(const AlignArgs& a, const double* __rest
     }
 }
 
-// The whole Levenberg-Marquardt loop in one persistent launch.  Every grid-wide phase costs ~20 us of cross-XCD barrier and
+// The whole Levenberg-Marquardt loop in one persistent launch.  Every grid-wide phase costs ~15 us of cross-XCD barrier and
 // reduction latency whatever it computes, so the phase count is what matters: the trial-cost phase also linearises at the trial
 // pose into a shadow buffer set and reduces both in ONE barrier.  When the trial is accepted (the common case: every step of
 // the benchmark pairs) the next outer iteration starts from that linearisation instead of spending a phase on it; when it is
 // rejected the speculative result is dropped.  The arithmetic, its order and therefore every result bit are those of the
 // phase-per-linearisation schedule (and of the oracle).
+//
+// Round 4: ONE phase site.  The loop below is a state machine whose every pass ends in the same code — [trial cost with the frozen
+// correspondences, unless this is the opening linearisation] + linearise + grid-wide sum of 29 values — instead of two inlined copies
+// of the linearisation (the opening one at x0, the speculative one at the trial pose).  The opening pass reduces a 29th value that is
+// zero; values 0..27 go through the same folds and adds as before, so every bit is unchanged.  Half the code (the search alone is
+// ~1 k instructions), which keeps the kernel inlined as a whole.
 __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
     __shared__ AlignShared sh;
+    __shared__ uint2 s_queue[26 * AL_T];     // grid_nn's per-lane work list of non-empty neighbour cells: entry k of thread t at [k * AL_T + t]
+    static_assert(AL_T == AL_T_CONST, "grid_nn's work-list stride");
     const int tid = threadIdx.x;
     const int gtid = blockIdx.x * AL_T + tid, gstride = gridDim.x * AL_T;
     const bool leader = blockIdx.x == 0 && tid == 0;
@@ -1499,53 +1656,43 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
     int tn = 0;
     trace_stamp(a.trace, tn, 0);
     int cur = 0;               // which buffer set holds the linearisation in use (wave-uniform, identical in every workgroup)
-    bool have_lin = false;     // the speculative linearisation of the previous trial is this iteration's
+    bool opening = true;       // the next pass is a plain linearisation at x0 (the first pass, or after a step that left no speculative one)
+    int it = 0, trial = 0;
 
-    for (int it = 0; it < a.max_iter; ++it) {
+    while (it < a.max_iter) {
         int* corr_c = cur ? a.corr2 : a.corr;
-        float* sqd_c = cur ? a.sqd2 : a.sqd;
         double* maha_c = cur ? a.maha2 : a.maha;
-        int* corr_n = cur ? a.corr : a.corr2;
-        float* sqd_n = cur ? a.sqd : a.sqd2;
-        double* maha_n = cur ? a.maha : a.maha2;
-        if (!have_lin) {
-            // ---------------- linearize at x0: correspondences + Mahalanobis + H, b, cost
-            double acc[NRED];
-#pragma unroll
-            for (int k = 0; k < NRED; ++k) acc[k] = 0;
-            trace_stamp(a.trace, tn, 1);
-            linearize_points(a, sh.x0, corr_c, sqd_c, maha_c, gtid, gstride, acc, a.trace ? &tn : nullptr);
-            trace_stamp(a.trace, tn, 2);
-            grid_sum<NRED>(acc, sh, a.sync, epoch, tid, a.trace, &tn);
-            if (sh.abort) { failed = 2; break; }
-            if (tid < NRED) sh.spec[tid] = sh.red[tid];
-            __syncthreads();
-        }
-        if (tid < 64) {   // first wave, one element per lane
-            if (tid < 36) {
-                const int r = tid / 6, c = tid % 6, lo = r < c ? r : c, hi = r < c ? c : r;
-                sh.H[tid] = sh.spec[6 * lo - lo * (lo - 1) / 2 + (hi - lo)];       // spec holds the upper triangle row by row
-            }
-            if (tid < 6) sh.b[tid] = sh.spec[21 + tid];
-            if (tid == 0) {
-                sh.y0 = sh.spec[27];
-                if (sh.lambda < 0.0) {
-                    const int diag[6] = {0, 6, 11, 15, 18, 20};
-                    double mx = 0;
-                    for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(sh.spec[diag[i]]));
-                    sh.lambda = a.lm_init * mx;
+        // where this pass's linearisation goes: the set in use (opening pass) or the shadow set (speculative, at the trial pose)
+        int* corr_w = (cur != 0) == opening ? a.corr2 : a.corr;
+        float* sqd_w = (cur != 0) == opening ? a.sqd2 : a.sqd;
+        double* maha_w = (cur != 0) == opening ? a.maha2 : a.maha;
+        if (!opening) {
+            if (trial == 0) {
+                // ---------------- start of an outer iteration: H, b, y0 from the linearisation in use
+                if (tid < 64) {   // first wave, one element per lane
+                    if (tid < 36) {
+                        const int r = tid / 6, c = tid % 6, lo = r < c ? r : c, hi = r < c ? c : r;
+                        sh.H[tid] = sh.spec[6 * lo - lo * (lo - 1) / 2 + (hi - lo)];       // spec holds the upper triangle row by row
+                    }
+                    if (tid < 6) sh.b[tid] = sh.spec[21 + tid];
+                    if (tid == 0) {
+                        sh.y0 = sh.spec[27];
+                        if (sh.lambda < 0.0) {
+                            const int diag[6] = {0, 6, 11, 15, 18, 20};
+                            double mx = 0;
+                            for (int i = 0; i < 6; ++i) mx = fmax(mx, fabs(sh.spec[diag[i]]));
+                            sh.lambda = a.lm_init * mx;
+                        }
+                        sh.nu = 2.0;
+                        sh.accepted = 0;
+                    }
+                    if (blockIdx.x == 0 && tid < 12) a.result->lin_pose[tid] = sh.x0[tid];
                 }
-                sh.nu = 2.0;
-                sh.accepted = 0;
+                __syncthreads();
+                trace_stamp(a.trace, tn, 30);
             }
-            if (blockIdx.x == 0 && tid < 12) a.result->lin_pose[tid] = sh.x0[tid];
-        }
-        __syncthreads();
-
-        trace_stamp(a.trace, tn, 30);
-        // ---------------- LM trials (every workgroup runs the same scalar arithmetic on the same totals)
-        bool step_ok = false;
-        for (int trial = 0; trial < a.lm_max_iter; ++trial) {
+            if (trial >= a.lm_max_iter) { failed = 1; break; }   // "lm not converged"
+            // ---------------- LM trial (every workgroup runs the same scalar arithmetic on the same totals)
             ++lm_trials;
             if (tid < 64) {   // every lane of the first wave runs the same solve (LDS reads are broadcasts); lane 0 publishes
                 double Hl[36], nb[6], d[6];
@@ -1577,16 +1724,20 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
             }
             __syncthreads();
             trace_stamp(a.trace, tn, 3);   // solve + se3_exp done
-            if (sh.state == 2) break;
-            // trial cost with frozen correspondences / Mahalanobis matrices ...
+            if (sh.state == 2) { failed = 1; break; }
+        } else {
+            trace_stamp(a.trace, tn, 1);
+        }
+        // ---------------- the phase: [trial cost with frozen correspondences / Mahalanobis matrices] + linearisation + grid-wide sum
+        double both[NRED + 1];
+#pragma unroll
+        for (int k = 0; k <= NRED; ++k) both[k] = 0;
+        if (!opening) {
             double Rx[9], tx[3];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Rx[i] = sh.xi[i];
 #pragma unroll
             for (int i = 0; i < 3; ++i) tx[i] = sh.xi[9 + i];
-            double both[NRED + 1];
-#pragma unroll
-            for (int k = 0; k <= NRED; ++k) both[k] = 0;
             for (int s = gtid; s < a.n_src; s += gstride) {
                 const int c = corr_c[s];
                 if (c < 0) continue;
@@ -1600,44 +1751,48 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
                 both[NRED] += e[0] * (m[0] * e[0] + m[1] * e[1] + m[2] * e[2]) + e[1] * (m[1] * e[0] + m[3] * e[1] + m[4] * e[2]) +
                               e[2] * (m[2] * e[0] + m[4] * e[1] + m[5] * e[2]);
             }
-            // ... and, in the same phase, the linearisation at the trial pose into the shadow buffers
             trace_stamp(a.trace, tn, 4);   // trial cost done
-            linearize_points(a, sh.xi, corr_n, sqd_n, maha_n, gtid, gstride, both);
-            trace_stamp(a.trace, tn, 5);   // speculative linearisation done
-            grid_sum<NRED + 1>(both, sh, a.sync, epoch, tid, a.trace, &tn);
-            if (sh.abort) { failed = 2; break; }
-            if (tid < 64) {   // first wave: the decision is wave-uniform (every lane reads the same totals), the copies are one element per lane
-                const double yi = sh.red[NRED];
-                const double rho = (sh.y0 - yi) / sh.denom;
-                if (rho < 0) {
-                    const bool conv = is_converged_wave(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps, tid);
-                    if (tid == 0) {
-                        if (conv) {
-                            sh.state = 1;       // upstream returns true without accepting the step
-                        } else {
-                            sh.lambda = sh.nu * sh.lambda;
-                            sh.nu = 2 * sh.nu;
-                            sh.state = 0;
-                        }
-                    }
-                } else {
-                    if (tid < 12) sh.x0[tid] = sh.xi[tid];
-                    if (tid < NRED) sh.spec[tid] = sh.red[tid];
-                    if (blockIdx.x == 0 && tid < 36) a.result->H_final[tid] = sh.H[tid];
-                    if (tid == 0) {
-                        const double f = 2 * rho - 1;
-                        sh.lambda = sh.lambda * fmax(1.0 / 3.0, 1 - f * f * f);
-                        if (leader) a.result->cost = yi;
-                        sh.state = 1;
-                        sh.accepted = 1;
+        }
+        linearize_points(a, opening ? sh.x0 : sh.xi, corr_w, sqd_w, maha_w, gtid, gstride, both, s_queue + tid, (a.trace && opening) ? &tn : nullptr);
+        trace_stamp(a.trace, tn, opening ? 2 : 5);   // (speculative) linearisation done
+        grid_sum<NRED + 1>(both, sh, a.sync, epoch, tid, a.trace, &tn);
+        if (sh.abort) { failed = 2; break; }
+        if (opening) {
+            if (tid < NRED) sh.spec[tid] = sh.red[tid];
+            __syncthreads();
+            opening = false; trial = 0;
+            continue;
+        }
+        if (tid < 64) {   // first wave: the decision is wave-uniform (every lane reads the same totals), the copies are one element per lane
+            const double yi = sh.red[NRED];
+            const double rho = (sh.y0 - yi) / sh.denom;
+            if (rho < 0) {
+                const bool conv = is_converged_wave(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps, tid);
+                if (tid == 0) {
+                    if (conv) {
+                        sh.state = 1;       // upstream returns true without accepting the step
+                    } else {
+                        sh.lambda = sh.nu * sh.lambda;
+                        sh.nu = 2 * sh.nu;
+                        sh.state = 0;
                     }
                 }
+            } else {
+                if (tid < 12) sh.x0[tid] = sh.xi[tid];
+                if (tid < NRED) sh.spec[tid] = sh.red[tid];
+                if (blockIdx.x == 0 && tid < 36) a.result->H_final[tid] = sh.H[tid];
+                if (tid == 0) {
+                    const double f = 2 * rho - 1;
+                    sh.lambda = sh.lambda * fmax(1.0 / 3.0, 1 - f * f * f);
+                    if (leader) a.result->cost = yi;
+                    sh.state = 1;
+                    sh.accepted = 1;
+                }
             }
-            __syncthreads();
-            if (sh.state == 1) { step_ok = true; break; }
         }
-        if (failed) break;
-        if (!step_ok) { failed = 1; break; }   // "lm not converged"
+        __syncthreads();
+        if (sh.state != 1) { ++trial; continue; }     // rejected: another trial with a larger damping
+        // ---------------- the outer iteration is complete
         ++iterations;
         if (tid < 64) {
             const bool conv = is_converged_wave(sh.delta, sh.delta + 9, a.rot_eps, a.trans_eps, tid);
@@ -1645,8 +1800,11 @@ __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
         }
         __syncthreads();
         if (sh.converged) break;
-        have_lin = sh.accepted != 0 && it + 1 < a.max_iter;
+        const bool have_lin = sh.accepted != 0 && it + 1 < a.max_iter;   // the speculative linearisation of this trial is the next iteration's
         if (have_lin) cur ^= 1;   // the shadow set becomes the set in use; correspondences exported are always those of the set in use
+        opening = !have_lin;
+        trial = 0;
+        ++it;
     }
     trace_stamp(a.trace, tn, 99);
     if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[511] = (unsigned long long)tn;
@@ -1692,7 +1850,7 @@ __global__ __launch_bounds__(256) void miss_list_kernel(int n_src, const float* 
     const bool found = sqd[s] < gate;   // exact whenever below the gate (grid completeness radius)
     if (!found) {
         const int k = atomicAdd(n_miss, 1);
-        miss[k] = s;
+        if (k < n_src) miss[k] = s;     // (the counter starts at zero: the bound only guards the buffer)
     }
     (void)corr;
 }
@@ -1737,7 +1895,8 @@ __global__ void empty_kernel() {}
 // Correspondence export straight into pinned host memory (two coalesced streams over PCIe); the last workgroup to finish
 // publishes the sequence number the host is polling.
 __global__ __launch_bounds__(256) void export_corr_kernel(int n, const int* __restrict__ corr, const float* __restrict__ sqd, int* __restrict__ h_corr,
-                                                          float* __restrict__ h_sqd, int* __restrict__ blocks_done, HostMailbox* mb, unsigned seq) {
+                                                          float* __restrict__ h_sqd, int* __restrict__ blocks_done, int* __restrict__ miss_counter,
+                                                          HostMailbox* mb, unsigned seq) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) { h_corr[i] = corr[i]; h_sqd[i] = sqd[i]; }
     __threadfence_system();
@@ -1746,6 +1905,9 @@ __global__ __launch_bounds__(256) void export_corr_kernel(int n, const int* __re
         const int done = __hip_atomic_fetch_add(blocks_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (int)gridDim.x - 1) {
             __hip_atomic_store(blocks_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the miss list behind this export has been consumed: a second on-demand pass after the same align (gate changed between align and
+            // the getter) must start counting from zero again — only the LM kernel zeroed it before (out-of-bounds miss[] writes)
+            __hip_atomic_store(miss_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence_system();
             __hip_atomic_store(&mb->export_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1868,6 +2030,16 @@ struct PinnedBuf {                // page-locked host staging: async copies with
     ~PinnedBuf() { if (p) (void)hipHostFree(p); }
 };
 
+struct IndexLevel {               // one level of the target index (build_level)
+    GridView view{};
+    DevBuf<unsigned long long> tkeys;
+    DevBuf<unsigned> tords, n_cells;
+    DevBuf<uint2> cells;
+    DevBuf<float4> sorted;
+    unsigned n_cells_host = 0;
+    bool cells_known = false;     // n_cells_host was read back (else it is the upper bound n)
+};
+
 struct Cloud {
     int n = 0, n_track = 0;
     DevBuf<float4> pts;
@@ -1893,10 +2065,10 @@ struct gsicp_gicp {
     Cloud src, tgt;
     // target search structure
     bool grid_valid = false;
-    GridView grid{};
-    DevBuf<unsigned long long> gkeys, gskeys, tkeys, tvals, packed;
+    IndexLevel lv[2];                      // [0] complete within the gate; [1] dense maps only: complete within sqrt(fine_r2), tried first
+    float fine_r2 = 0.f;
+    DevBuf<unsigned long long> gkeys, gskeys, packed;
     DevBuf<unsigned> gvals, gsvals;
-    DevBuf<float4> sorted;
     DevBuf<char> sort_temp;
     // per-source-point outputs
     DevBuf<int> corr, corr2, miss, counters, nbr_idx, knn_cell_of;
@@ -2069,53 +2241,105 @@ int calc_cov(gsicp_gicp* g, Cloud& c) {
     return 0;
 }
 
+// One level of the target index: points sorted by (coarse cell, octant), hashed coarse cells, eight {begin, count} pairs per cell, complete
+// within `radius` of any query.  Targets of >= 32 768 points get their table and cell records sized by the number of OCCUPIED cells (one
+// 4-byte read-back: this runs at keyframe rate, and the hand-off that precedes it synchronises anyway): a map has 6-60 points per cell, so
+// the table shrinks from 48 MB to ~3 MB at 1e6 points and the 8 bucket probes of a query come from the L2 instead of HBM.
+int build_level(gsicp_gicp* g, int lvl, double radius) {
+    Cloud& t = g->tgt;
+    const int n = t.n_track;
+    IndexLevel& L = g->lv[lvl];
+    GridView& G = L.view;
+    std::memset(&G, 0, sizeof(G));
+    if (L.sorted.ensure((size_t)n)) { g_last_error = "hipMalloc failed"; return -1; }
+    // fine cell edge = radius x 1.001: every target within the radius of a query lies in the 27 fine cells around the query's (the 0.1 %
+    // covers the float rounding of the cell assignment for coordinates up to ~80 m at a 2 cm radius); hashed coarse cell = 2x2x2 fine cells
+    const float hf = (float)(radius * 1.001);
+    G.use_grid = 1; G.hf = hf; G.inv_hf = 1.0f / hf; G.sorted = L.sorted.p; G.n_sorted = n;
+    size_t temp_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
+                                    (unsigned*)nullptr, (size_t)n, 0, 63, g->stream);
+    if (g->gkeys.ensure(n) || g->gskeys.ensure(n) || g->gvals.ensure(n) || g->gsvals.ensure(n) || L.n_cells.ensure(2) ||
+        g->sort_temp.ensure(temp_bytes ? temp_bytes : 1)) { g_last_error = "hipMalloc failed"; return -1; }
+    const dim3 grid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(grid_keys_kernel, grid, block, 0, g->stream, n, t.track.p, t.pts.p, G.inv_hf, g->gkeys.p, g->gvals.p, L.n_cells.p);
+    GC(rocprim::radix_sort_pairs(g->sort_temp.p, temp_bytes, g->gkeys.p, g->gskeys.p, g->gvals.p, g->gsvals.p, (size_t)n, 0, 63, g->stream));
+    size_t n_cells = (size_t)n;       // upper bound
+    L.cells_known = false;
+    if (n >= (1 << 15)) {
+        hipLaunchKernelGGL(grid_count_cells_kernel, grid, block, 0, g->stream, n, g->gskeys.p, L.n_cells.p);
+        GC(hipMemcpyAsync(&g->mailbox->scratch_u32, L.n_cells.p, sizeof(unsigned), hipMemcpyDeviceToHost, g->stream));
+        if (int rc_ = drain(g)) return rc_;
+        n_cells = g->mailbox->scratch_u32;
+        if (n_cells < 1 || n_cells > (size_t)n) { g_last_error = "target index: bad cell count"; return -1; }
+        L.cells_known = true;
+    }
+    L.n_cells_host = (unsigned)n_cells;
+    // load factor <= 1/8 (in cells when counted, in points otherwise — a depth frame has ~1.5 points per cell): most of the 8 cells a
+    // query probes do not exist, and an unsuccessful linear probe costs ~(1 + 1/(1-a)^2)/2 dependent loads ON AVERAGE but the slowest lane
+    // of a wave sets the pace — at a = 1/2 the 8-cell search took 7 us of every phase
+    size_t cap = 64;
+    while (cap < (size_t)8 * n_cells) cap <<= 1;
+    G.mask = (unsigned)(cap - 1);
+    if (L.tkeys.ensure(cap) || L.tords.ensure(cap) || L.cells.ensure((size_t)8 * n_cells)) { g_last_error = "hipMalloc failed"; return -1; }
+    GC(hipMemsetAsync(L.tkeys.p, 0xFF, cap * 8, g->stream));
+    hipLaunchKernelGGL(grid_cells_kernel, grid, block, 0, g->stream, n, g->gskeys.p, g->gsvals.p, t.pts.p, L.sorted.p, G.mask, L.tkeys.p, L.tords.p,
+                       L.cells.p, L.n_cells.p);
+    hipLaunchKernelGGL(grid_octants_kernel, grid, block, 0, g->stream, n, g->gskeys.p, G.mask, L.tkeys.p, L.tords.p, L.cells.p);
+    GC(hipGetLastError());
+    G.keys = L.tkeys.p; G.ords = L.tords.p; G.cells = L.cells.p;
+    return 0;
+}
+
 int build_grid(gsicp_gicp* g) {
     Cloud& t = g->tgt;
     if (int rc = flush_points(g, t)) return rc;
     const int n = t.n_track;
-    GridView& G = g->grid;
+    GridView& G = g->lv[0].view;
     std::memset(&G, 0, sizeof(G));
+    std::memset(&g->lv[1].view, 0, sizeof(GridView));
+    g->fine_r2 = 0.f;
     g->tg_valid = false;
-    if (g->sorted.ensure((size_t)(n ? n : 1))) { g_last_error = "hipMalloc failed"; return -1; }
-    G.sorted = g->sorted.p; G.n_sorted = n;
+    if (g->lv[0].sorted.ensure((size_t)(n ? n : 1))) { g_last_error = "hipMalloc failed"; return -1; }
+    G.sorted = g->lv[0].sorted.p; G.n_sorted = n;
     gsicp::ProfileScope ps(gsicp::ST_GICP_GRID, g->stream);
     const bool gated = g->max_corr < 1e6 && g->max_corr > 0;
     if (!gated || n == 0) {
         G.use_grid = 0;
-        if (n > 0) hipLaunchKernelGGL(gather_track_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, t.track.p, t.pts.p, g->sorted.p);
+        if (n > 0) hipLaunchKernelGGL(gather_track_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, t.track.p, t.pts.p, g->lv[0].sorted.p);
         GC(hipGetLastError());
         g->grid_valid = true;
         return 0;
     }
-    const float h = (float)(2.0 * g->max_corr * 1.001);
-    G.use_grid = 1; G.inv_h = 1.0f / h;
-    // load factor <= 1/8: most of the 8 cells a query probes do not exist, and an unsuccessful linear probe costs ~(1 + 1/(1-a)^2)/2
-    // dependent loads ON AVERAGE but the slowest lane of a wave sets the pace — at a = 1/2 the 8-cell search took 7 us of every phase
-    size_t cap = 64;
-    while (cap < (size_t)8 * n) cap <<= 1;
-    G.mask = (unsigned)(cap - 1);
-    size_t temp_bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
-                                    (unsigned*)nullptr, (size_t)n, 0, 63, g->stream);
-    if (g->gkeys.ensure(n) || g->gskeys.ensure(n) || g->gvals.ensure(n) || g->gsvals.ensure(n) || g->tkeys.ensure(cap) ||
-        g->tvals.ensure(cap) || g->sort_temp.ensure(temp_bytes ? temp_bytes : 1)) { g_last_error = "hipMalloc failed"; return -1; }
-    const dim3 grid((n + 255) / 256), block(256);
-    hipLaunchKernelGGL(grid_keys_kernel, grid, block, 0, g->stream, n, t.track.p, t.pts.p, G.inv_h, g->gkeys.p, g->gvals.p);
-    GC(rocprim::radix_sort_pairs(g->sort_temp.p, temp_bytes, g->gkeys.p, g->gskeys.p, g->gvals.p, g->gsvals.p, (size_t)n, 0, 63, g->stream));
-    GC(hipMemsetAsync(g->tkeys.p, 0xFF, cap * 8, g->stream));
-    GC(hipMemsetAsync(g->tvals.p, 0, cap * 8, g->stream));
-    hipLaunchKernelGGL(grid_fill_kernel, grid, block, 0, g->stream, n, g->gskeys.p, g->gsvals.p, t.pts.p, g->sorted.p, G.mask, g->tkeys.p, g->tvals.p);
-    GC(hipGetLastError());
-    G.keys = g->tkeys.p; G.vals = g->tvals.p;
+    if (int rc = build_level(g, 0, g->max_corr)) return rc;
+    // EXTREMELY dense maps (>= 64 points per occupied gate-sized coarse cell) get a second level of the same structure at a smaller radius
+    // r1 = f x gate, tried first (linearize_points): a neighbour found inside r1 is the nearest neighbour.  With m points per coarse cell the
+    // targets lie on surfaces at ~m / (2 gate)^2 per unit area; f = sqrt(3.8 / m) puts ~3 expected points inside r1 and ~1 into a fine cell
+    // of the level.  Measured (MI355X, 8 280-point frame 7 mm from its pose, align kernel us, one level | two): m = 17.6 (3e5 Gaussians on
+    // one room corner's surfaces) 109 | 138, m = 57 (1e6) 203 | 190, m = 171 (3e6) 425 | 303 — a query that starts several mm off the
+    // surface falls through to the gate-sized level in the first linearisation, so the second level only pays where cells are very full; the
+    // build costs +25-35 %.  A whole-room Replica map of 1-2 M Gaussians has m ~ 16-32: one level.
+    static const int two_level = [] { const char* v = std::getenv("GSICP_INDEX_LEVELS"); return v ? std::atoi(v) : 2; }();   // A/B switch
+    if (g->lv[0].cells_known && two_level >= 2) {
+        const double m = (double)n / (double)g->lv[0].n_cells_host;
+        double f = std::sqrt(3.8 / m);
+        if (m >= 64.0) {
+            if (f < 0.15) f = 0.15;
+            const double r1 = g->max_corr * f;
+            if (int rc = build_level(g, 1, r1)) return rc;
+            g->fine_r2 = (float)r1 * (float)r1;
+        }
+    }
     // coarse dense grid over the same points for the exact-distance export (nn1_grid_kernel)
     g->tg_valid = false;
+    const dim3 grid((n + 255) / 256), block(256);
     if (!(g->tg_params.ensure(1) || g->tg_cell_of.ensure((size_t)n) || g->tg_count.ensure(KNN_MAX_CELLS + 1) ||
           g->tg_start.ensure(KNN_MAX_CELLS + 1) || g->tg_fill.ensure(KNN_MAX_CELLS + 1) || g->tg_sorted.ensure((size_t)n))) {
-        hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, g->stream, n, (const float4*)g->sorted.p, KNN_H_AREA, KNN_H_VOL,
+        hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, g->stream, n, (const float4*)g->lv[0].sorted.p, KNN_H_AREA, KNN_H_VOL,
                            g->tg_params.p, g->tg_count.p);
-        hipLaunchKernelGGL(knn_count_kernel, grid, block, 0, g->stream, n, (const float4*)g->sorted.p, g->tg_params.p, g->tg_cell_of.p, g->tg_count.p);
+        hipLaunchKernelGGL(knn_count_kernel, grid, block, 0, g->stream, n, (const float4*)g->lv[0].sorted.p, g->tg_params.p, g->tg_cell_of.p, g->tg_count.p);
         hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, g->stream, g->tg_params.p, g->tg_count.p, g->tg_start.p, g->tg_fill.p);
-        hipLaunchKernelGGL(knn_fill_kernel, grid, block, 0, g->stream, n, (const float4*)g->sorted.p, g->tg_cell_of.p, g->tg_fill.p, g->tg_sorted.p);
+        hipLaunchKernelGGL(knn_fill_kernel, grid, block, 0, g->stream, n, (const float4*)g->lv[0].sorted.p, g->tg_cell_of.p, g->tg_fill.p, g->tg_sorted.p);
         GC(hipGetLastError());
         g->tg_valid = true;
     }
@@ -2379,7 +2603,7 @@ int gsicp_gicp_get_source_scales_device(gsicp_gicp* g, float* out_dev, int cap, 
 static int enqueue_correspondence_export(gsicp_gicp* g, int m, unsigned* seq_out) {
     Cloud &s = g->src, &t = g->tgt;
     const int n = s.n_track;
-    if (!g->dist_exact && g->grid.use_grid && n > 0 && t.n_track > 0) {
+    if (!g->dist_exact && g->lv[0].view.use_grid && n > 0 && t.n_track > 0) {
         const float gate = (float)g->max_corr * (float)g->max_corr;
         gsicp::ProfileScope ps(gsicp::ST_GICP_MISS, g->stream);
         hipLaunchKernelGGL(miss_list_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, g->sqd.p, g->corr.p, gate, g->miss.p,
@@ -2389,7 +2613,7 @@ static int enqueue_correspondence_export(gsicp_gicp* g, int m, unsigned* seq_out
                                g->result.p->lin_pose, g->tg_params.p, g->tg_start.p, g->tg_sorted.p, t.n_track, g->sqd.p);
         else
             hipLaunchKernelGGL(brute_nn_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, g->miss.p, g->counters.p, s.track.p, s.pts.p,
-                               g->result.p->lin_pose, g->sorted.p, t.n_track, g->sqd.p);
+                               g->result.p->lin_pose, g->lv[0].sorted.p, t.n_track, g->sqd.p);
         GC(hipGetLastError());
         g->dist_exact = true;
     }
@@ -2399,7 +2623,7 @@ static int enqueue_correspondence_export(gsicp_gicp* g, int m, unsigned* seq_out
     if (g->h_corr.ensure((size_t)m) || g->h_sqd.ensure((size_t)m)) { g_last_error = "hipHostMalloc failed"; return -1; }
     const unsigned seq = ++g->seq;
     hipLaunchKernelGGL(export_corr_kernel, dim3((m + 255) / 256), dim3(256), 0, g->stream, m, g->corr.p, g->sqd.p, g->h_corr.p, g->h_sqd.p,
-                       g->counters.p + 1, g->mailbox, seq);
+                       g->counters.p + 1, g->counters.p, g->mailbox, seq);
     GC(hipGetLastError());
     *seq_out = seq;
     return 0;
@@ -2424,7 +2648,7 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     AlignArgs a;
     std::memset(&a, 0, sizeof(a));
     a.n_src = s.n_track; a.src_track = s.track.p; a.src_pts = s.pts.p; a.src_cov = s.cov.p;
-    a.tgt_pts = t.pts.p; a.tgt_cov = t.cov.p; a.grid = g->grid;
+    a.tgt_pts = t.pts.p; a.tgt_cov = t.cov.p; a.grid = g->lv[0].view; a.fine = g->lv[1].view; a.fine_r2 = g->fine_r2;
     a.gate = g->max_corr >= 1e18 ? FLT_MAX : (float)g->max_corr * (float)g->max_corr;
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) a.init[3 * r + c] = (double)(float)init[4 * r + c];
@@ -2525,17 +2749,25 @@ int gsicp_gicp_knn_stats(gsicp_gicp* g, double out[12]) {
 }
 int gsicp_gicp_num_source(gsicp_gicp* g) { return g->src.n; }
 int gsicp_gicp_num_target(gsicp_gicp* g) { return g->tgt.n; }
-int gsicp_gicp_target_index_stats(gsicp_gicp* g, double out[8]) {
-    const GridView& G = g->grid;
-    const double slots = (g->grid_valid && G.use_grid) ? (double)G.mask + 1.0 : 0.0;
-    out[0] = g->grid_valid ? (double)G.n_sorted : 0.0;
-    out[1] = (g->grid_valid && G.use_grid) ? 1.0 : 0.0;
-    out[2] = slots;
-    out[3] = slots * 16.0;
-    out[4] = (g->grid_valid && G.use_grid) ? 1.0 / (double)G.inv_h : 0.0;
-    out[5] = g->grid_valid ? (double)G.n_sorted * 16.0 : 0.0;
-    out[6] = g->tg_valid ? (double)KNN_MAX_CELLS : 0.0;   // upper bound; the actual count is chosen on the device
-    out[7] = g->tg_valid ? ((double)KNN_MAX_CELLS + 1.0) * 4.0 + (double)G.n_sorted * 16.0 : 0.0;
+int gsicp_gicp_target_index_stats(gsicp_gicp* g, double out[12]) {
+    for (int i = 0; i < 12; ++i) out[i] = 0.0;
+    if (!g->grid_valid) return 0;
+    const GridView& G = g->lv[0].view;
+    out[0] = (double)G.n_sorted;
+    out[1] = G.use_grid ? 1.0 : 0.0;
+    for (int l = 0; l < 2; ++l) {
+        const IndexLevel& L = g->lv[l];
+        if (!L.view.use_grid) continue;
+        unsigned cells = 0;
+        GC(hipStreamSynchronize(g->stream));
+        GC(hipMemcpy(&cells, L.n_cells.p + 1, sizeof(cells), hipMemcpyDeviceToHost));   // ordinals handed out = occupied coarse cells
+        double* o = out + 2 + 5 * l;
+        o[0] = (double)L.view.mask + 1.0;                                   // table slots
+        o[1] = o[0] * 12.0 + (double)L.n_cells_host * 64.0;                 // keys + ordinals + cell records (as allocated)
+        o[2] = 2.0 * (double)L.view.hf;                                     // coarse (hashed) cell edge; a fine cell is half of it
+        o[3] = (double)cells;
+        o[4] = (double)L.view.hf / 1.001;                                   // the radius the level is complete within
+    }
     return 0;
 }
 int gsicp_gicp_last_align_stats(gsicp_gicp* g, double out[6]) {

@@ -346,13 +346,16 @@ __global__ __launch_bounds__(256) void loss_fused_kernel(const float* __restrict
                                                          Win win, float d_max, float dS_scale /* -lambda / (3HW) */, float l1_scale /* (1 - lambda) / (3HW) */,
                                                          float depth_scale /* w_d / (HW d_max) */, float* __restrict__ dL_dimage,
                                                          float* __restrict__ dL_ddepth, float* __restrict__ partial, int tile_mod, int tile_rem) {
-    __shared__ __attribute__((aligned(16))) float s_x[FIN][FXS];        // later: the three derivative maps (FMID x FMS each)
-    __shared__ __attribute__((aligned(16))) float s_y[FIN][FXS];
+    // x and y staging as ONE object: the three derivative maps (FMID x FMS each) later overlay BOTH, and only members of one array are
+    // guaranteed contiguous (separate __shared__ variables may be laid out in any order — ADVICE r3)
+    __shared__ __attribute__((aligned(16))) float s_xy[2][FIN][FXS];
+    float (*const s_x)[FXS] = s_xy[0];
+    float (*const s_y)[FXS] = s_xy[1];
     __shared__ __attribute__((aligned(16))) float s_b[3][FIN][FMS];     // three horizontally filtered moment maps at a time; later the filtered derivative maps
     __shared__ float s_red[4][2];
     static_assert(3 * FMID * FMS <= 2 * FIN * FXS, "derivative maps must fit in the staging buffers");
     static_assert(3 * FMID * LHS <= 3 * FIN * FMS, "filtered derivative maps must fit in the moment buffers");
-    float (*const s_a)[FMID][FMS] = (float (*)[FMID][FMS])&s_x[0][0];
+    float (*const s_a)[FMID][FMS] = (float (*)[FMID][FMS])&s_xy[0][0][0];
     float (*const s_h2)[FMID][LHS] = (float (*)[FMID][LHS])&s_b[0][0][0];
     const int tid = threadIdx.x, lx = tid & 31, ry = tid >> 5;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;

@@ -285,10 +285,11 @@ class FastGICP:
 
     def target_index_stats(self):
         """Sizes of the target search structure as of the last build (diagnostics for map-sized targets)."""
-        out = np.empty(8, np.float64)
+        out = np.empty(12, np.float64)
         self._ck(self._lib.gsicp_gicp_target_index_stats(self._h, _vp(out)), "target_index_stats")
-        return dict(targets=int(out[0]), hashed_grid=bool(out[1]), table_slots=int(out[2]), table_bytes=int(out[3]), cell_m=float(out[4]),
-                    sorted_bytes=int(out[5]), dense_cells=int(out[6]), dense_bytes=int(out[7]))
+        levels = [dict(table_slots=int(o[0]), bytes=int(o[1]), cell_m=float(o[2]), occupied_cells=int(o[3]), radius_m=float(o[4]))
+                  for o in (out[2:7], out[7:12]) if o[0] > 0]
+        return dict(targets=int(out[0]), hashed_grid=bool(out[1]), levels=levels)
 
     def last_align_stats(self):
         out = np.empty(6, np.float64)

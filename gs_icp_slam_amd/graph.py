@@ -239,9 +239,17 @@ class MapperIterationGraph:
         now = self.skipped_steps()
         lost = now - self._skipped_seen
         self._skipped_seen = now
-        if lost <= 0 and not self.overflowed():
-            return 0
+        grow = lost > 0 or self.overflowed()
         need = int(self.num_rendered.item()) if self.num_rendered is not None else 0
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and hasattr(self.rasterizer, "overflow_guard"):
+            # every rank must take the same decision AND the same new capacity: the re-capture below warms up with collectives (ADVICE r3:
+            # a rank-local guard could make ranks diverge and deadlock there), and static exchange sizes derive from the capacity
+            t = torch.tensor([int(grow), need, lost], dtype=torch.int64, device=self.params["means3D"].device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            grow, need, lost = bool(t[0].item()), int(t[1].item()), int(t[2].item())
+        if not grow:
+            return 0
         self.capacity = max(int(self.capacity * growth) + 1, int(1.25 * need) + 4096)
         self._rs = self._rs._replace(capacity=self.capacity)
         dev = self.params["means3D"].device

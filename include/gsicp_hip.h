@@ -224,9 +224,10 @@ int gsicp_gicp_align_trace(gsicp_gicp* g, unsigned long long* out, int cap_pairs
 int gsicp_gicp_num_source(gsicp_gicp*);
 int gsicp_gicp_num_target(gsicp_gicp*);
 /* Sizes of the target search structure as of the last build (align builds it lazily after a target / gate change):
- * out = {trackable targets, uses the hashed grid (0 = ungated scan), hash-table slots, hash-table bytes (keys + values), cell edge (m),
- * bytes of the cell-sorted point copy, dense-grid cell capacity of the exact-distance export, its bytes}.  No synchronisation. */
-int gsicp_gicp_target_index_stats(gsicp_gicp*, double out[8]);
+ * out[0] = trackable targets, out[1] = uses the hashed grid (0 = ungated scan); then per level l = 0 (complete within the gate) and
+ * l = 1 (dense maps only; all zero when absent) at out[2 + 5 l ..]: hash-table slots, bytes of table + cell records, hashed (coarse)
+ * cell edge in metres (a fine cell is half of it), occupied coarse cells, radius the level is complete within.  Synchronises. */
+int gsicp_gicp_target_index_stats(gsicp_gicp*, double out[12]);
 /* out[0..5]: kernel launches of the last align, LM trials, final cost, converged flag, device microseconds, reserved */
 int gsicp_gicp_last_align_stats(gsicp_gicp*, double out[6]);
 /* Robustness of the persistent align kernel's grid barrier.  The launch never exceeds the number of workgroups the device can hold at

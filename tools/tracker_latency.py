@@ -25,9 +25,27 @@ def filt(n, tr):
 reg = pygicp.FastGICP()
 reg.set_max_correspondence_distance(cfg["max_corr"])
 reg.set_max_knn_distance(99999.0)
-reg.set_input_target(pw)
-reg.set_target_filter(len(sp["trackable_a"]), filt(len(pw), sp["trackable_a"]))
-reg.calculate_target_covariance_with_filter()
+if "--map" in sys.argv:   # --map K: the steady-state configuration — a map-sized target of ~K Gaussians, source = frame 155 of the trajectory, guess = frame 154's pose
+    K = int(sys.argv[sys.argv.index("--map") + 1])
+    kreg = pygicp.FastGICP()
+    kreg.set_max_knn_distance(99999.0)
+
+    def cov_fn(p_):
+        kreg.set_input_target(p_)
+        kreg.calculate_target_covariance_with_filter()
+        return kreg.get_target_rotationsq(), kreg.get_target_scales()
+    m = synth.tracker_map(K, cov_fn)
+    keep = m["trackable"] & (m["opacity"] > m["opacity_th"])
+    poses = synth.trajectory(156)
+    pb, _, tb, _ = synth.frame_points(cfg, poses[155])
+    sp = dict(sp, points_b=pb, trackable_b=tb, pose_a=poses[154], pose_b=poses[155])
+    reg.set_input_target(np.ascontiguousarray(m["points"][keep]))
+    reg.set_target_covariances_fromqs(m["rotations"][keep].reshape(-1), m["scales"][keep].reshape(-1))
+    print("map-sized target:", int(keep.sum()), "Gaussians")
+else:
+    reg.set_input_target(pw)
+    reg.set_target_filter(len(sp["trackable_a"]), filt(len(pw), sp["trackable_a"]))
+    reg.calculate_target_covariance_with_filter()
 f_src = filt(len(sp["points_b"]), sp["trackable_b"])
 DEVICE = "--device" in sys.argv   # device-resident frame: front-end kernel -> set_input_source(tensor) -> set_source_trackable
 if DEVICE:
