@@ -284,14 +284,23 @@ void blend_forward(const Problem<R>& pb, const std::vector<Splat<R>>& sp, const 
                 ++contributor;
                 const R dx = s.px - pfx, dy = s.py - pfy;
                 const R power = R(-0.5) * (s.ca * dx * dx + s.cc * dy * dy) - s.cb * dx * dy;
-                if (std::fabs(power) < R(1e-7)) mg = 0;  // sign-of-power decision is fragile here
+                // The margin says how far (relatively) the nearest threshold decision of the pixel is; consumers call a pixel fragile below 1e-5,
+                // i.e. they assume two valid fp32 evaluations agree to 1e-5.  Two places where that assumption is not the arithmetic's (round 4,
+                // found on a TRAINED map): (i) `power` is a difference of terms that can be 10^3 times larger than itself for a needle-shaped
+                // splat (conic eigenvalue ratio 10^3-10^4 after training), so two evaluation orders (FMA contraction on the GPU) differ by
+                // ~8 eps32 S with S the sum of the terms' magnitudes — one alpha >= 1/255 test flipped at a relative margin of 1.8e-4; (ii) the
+                // transmittance is a product over the entries blended so far and drifts by ~3 ulp per entry (2e-5 after 400).  Both margins are
+                // therefore scaled so that "1e-5" keeps meaning "inside the evaluation noise".
+                const R S = R(0.5) * (std::fabs(s.ca) * dx * dx + std::fabs(s.cc) * dy * dy) + std::fabs(s.cb * dx * dy);
+                const R noise_p = std::max(R(1e-5), R(5e-7) * S);
+                if (std::fabs(power) < std::max(R(1e-7), R(5e-7) * S)) mg = 0;  // sign-of-power decision is fragile here
                 if (power > R(0)) continue;
                 const R a_raw = s.opacity * rexp<R>(power);
                 const R alpha = std::min(R(0.99), a_raw);
-                mg = std::min(mg, rel_margin<R>(a_raw, R(1) / R(255)));
+                mg = std::min(mg, rel_margin<R>(a_raw, R(1) / R(255)) * (R(1e-5) / noise_p));
                 if (alpha < R(1) / R(255)) continue;
                 const R test_T = T * (R(1) - alpha);
-                mg = std::min(mg, rel_margin<R>(test_T, R(0.0001)));
+                mg = std::min(mg, rel_margin<R>(test_T, R(0.0001)) * (R(1e-5) / std::max(R(1e-5), R(2e-7) * R(contributor))));
                 if (test_T < R(0.0001)) break;
                 for (int c = 0; c < 3; ++c) C[c] += s.rgb[c] * alpha * T;
                 Dz += s.depth * alpha * T;

@@ -43,7 +43,10 @@ def run_product(g, cam, bg, sh_degree=0, grads=None, tile_mod=1, tile_rem=0, dep
     return out
 
 
-def check_forward(g, cam, bg, sh_degree, hip_lib, label, tol=TOL, max_fragile=2e-4):
+def check_forward(g, cam, bg, sh_degree, hip_lib, label, tol=TOL, max_fragile=2e-4, fp32_noise_cap=None):
+    """`fp32_noise_cap` (trained maps, lists of 300-400 entries per pixel): the image bar becomes min(max(tol, 1e-7 n_contrib), cap) per pixel —
+    two valid fp32 evaluation orders of a 400-term transmittance product drift apart by up to ~N ulps (measured 2.1e-5 at N = 402, where the
+    fp32 oracle is as far from its own fp64 instance) — and the number of pixels beyond `tol` is returned (at most 1e-4 of the image)."""
     o = util.oracle_forward(g, cam, bg, sh_degree)
     p = run_product(g, cam, bg, sh_degree)
     P = g["means3D"].shape[0]
@@ -65,15 +68,28 @@ def check_forward(g, cam, bg, sh_degree, hip_lib, label, tol=TOL, max_fragile=2e
     frac_fragile = 1.0 - ok.mean()
     assert frac_fragile < max_fragile, f"{label}: {frac_fragile:.2e} fragile pixels"
     dc = np.abs(p["color"] - o["color"]).max(0)
-    dd = np.abs(p["depth"] - o["depth"])
-    assert dc[ok].max() <= tol, f"{label}: colour err {dc[ok].max():.3e}"
-    assert (dd[ok] / np.maximum(1.0, np.abs(o["depth"][ok]))).max() <= tol, f"{label}: depth err {dd[ok].max():.3e}"
-    assert np.array_equal(s["n_contrib"][ok], o["n_contrib"][ok]), f"{label}: n_contrib differs on robust pixels"
+    dd = np.abs(p["depth"] - o["depth"]) / np.maximum(1.0, np.abs(o["depth"]))
+    extra = {}
+    if fp32_noise_cap is None:
+        assert dc[ok].max() <= tol, f"{label}: colour err {dc[ok].max():.3e}"
+        assert dd[ok].max() <= tol, f"{label}: depth err {dd[ok].max():.3e}"
+    else:
+        # per-pixel bar: tol, or fp32's drift over the pixel's own blend list where that is larger (1e-7 = 1.7 ulp per blended entry)
+        tol_px = np.minimum(np.maximum(tol, 1e-7 * o["n_contrib"].astype(np.float64)), fp32_noise_cap)
+        over = ok & ((dc > tol) | (dd > tol))
+        extra = dict(pixels_over_1e5=int(over.sum()), max_n_contrib=int(o["n_contrib"].max()),
+                     min_n_contrib_of_a_pixel_over_1e5=int(o["n_contrib"][over].min()) if over.any() else None,
+                     worst_ratio_to_bound=float(max((dc / tol_px)[ok].max(), (dd / tol_px)[ok].max())))
+        assert over.sum() <= 1e-4 * W * H, f"{label}: {int(over.sum())} robust pixels beyond {tol}"
+        assert (dc <= tol_px)[ok].all(), f"{label}: colour err {dc[ok].max():.3e} beyond max(1e-5, 1e-7 n_contrib) at {int((dc > tol_px)[ok].sum())} pixels"
+        assert (dd <= tol_px)[ok].all(), f"{label}: depth err {dd[ok].max():.3e} beyond max(1e-5, 1e-7 n_contrib)"
+    assert np.array_equal(s["n_contrib"][ok], o["n_contrib"][ok]), \
+        f"{label}: n_contrib differs on {int((s['n_contrib'] != o['n_contrib'])[ok].sum())} robust pixels (margins {np.sort(o['margin'][ok & (s['n_contrib'] != o['n_contrib'])])[:5]})"
     np.testing.assert_allclose(s["final_T"][ok], o["final_T"][ok], rtol=max(1e-4, 20 * tol), atol=1e-6)
     # is_used: robust subset relation (flips only through fragile pixels)
     diff = np.flatnonzero(p["is_used"] != o["is_used"])
     assert len(diff) <= max(2, int(1e-4 * P)), f"{label}: is_used differs for {len(diff)} Gaussians"
-    return o, p, dict(fragile=float(frac_fragile), max_color_err=float(dc[ok].max()), max_depth_err=float(dd[ok].max()))
+    return o, p, dict(fragile=float(frac_fragile), max_color_err=float(dc[ok].max()), max_depth_err=float(dd[ok].max()), **extra)
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
@@ -278,24 +294,23 @@ def _write_parity_report(tag, report):
         json.dump(report, fh, indent=1)
 
 
-@pytest.mark.parametrize("depth_mode", [0, 1])
-@pytest.mark.parametrize("res", ["replica", "tum", "replica_stage1", "replica_stage2"])
-def test_full_size_smap_backward(hip_lib, res, depth_mode):
-    """R-bwd at BASELINE sizes: S-map P = 300 k at 1200x680 and 640x480 (and the training_stage sizes), random dL/dcolour and
-    dL/ddepth, both depth rules, all six gradients compared with the fp32 oracle ELEMENT-WISE, EVERY visible Gaussian to the same bound:
-        |hip - oracle| <= 1e-5 * max|oracle| + 1e-4 * |oracle| + min(2 |oracle_f32 - oracle_f64|, 1e-4 * max|oracle|).
-    The last term is the fp32 oracle's OWN rounding noise on that element (conic -> covariance -> quaternion is a sum of products
-    of dL/dSigma ~ 1e5 with derivatives ~ 1e-4 that cancel to O(10): where fp32 cannot do better the bar is what fp32 delivers);
-    the number of elements that need it is reported.
-    Fragile pixels (forward decision margin < 1e-5: exp() differs in the last ulps between libm and the GPU, so an alpha or transmittance
-    test there may legitimately flip; a few per 10^4 pixels) get dL/dcolour = dL/ddepth = 0 on BOTH sides: every term a pixel contributes
-    to any gradient is linear in its dL/dpixel, so such a pixel contributes exactly nothing whichever way its decisions fall, and no
-    Gaussian sees a flipped decision — there is no looser class of Gaussians (round 2 held up to 8 % of the visible set to 5e-3)."""
+def compare_backward(g, cam, depth_mode, label, report_tag, gaussians_label, seed=7, max_fragile=4e-4, cond_scale=False):
+    """All six gradients of (g, cam) under random dL/dcolour, dL/ddepth against the fp32 oracle, ELEMENT-WISE, every visible Gaussian to
+        |hip - oracle| <= f * (1e-5 * max|oracle| + 1e-4 * |oracle|) + min(2 |oracle_f32 - oracle_f64|, 1e-4 * max|oracle|)
+    (fragile pixels get zero upstream gradients on both sides; see test_full_size_smap_backward).  f = 1, except with `cond_scale` (trained
+    maps): f = max(1, (chi / 100)^2), capped so that the term stays <= 2e-2 max|oracle|, where chi is the eigenvalue ratio of the
+    Gaussian's screen-space covariance (from the conic the forward reports).  Training stretches some Gaussians into needles a hundred pixels
+    long and a fraction of a pixel thin (scales like 1.4 mm x 76 mm x 2 um measured); the conic -> covariance derivative divides by det^2, so
+    fp32 carries a relative error ~eps chi^2 there WHATEVER the evaluation order — measured on the trained map: no Gaussian with chi < 100
+    (95.6 % of the map) misses the f = 1 bound, the ones that do have chi 150..11 000 (median 1 500), and on them the fp32 ORACLE is as far
+    from its own fp64 instance as the HIP result is (RMS ratio 0.75-1.00).  The report counts the Gaussians with f > 1 and the elements that
+    need it, and the RMS distances to the fp64 oracle on those Gaussians are asserted (HIP no farther than 2 x the fp32 oracle: the RMS over a few thousand such
+    Gaussians is carried by a handful of outliers — measured ratios 0.59-1.35).
+    Writes the parity report, returns it."""
     import oracle
-    cam = _stage_cam(res)
     W, H = cam["W"], cam["H"]
-    g = synth.s_map(300_000, seed=2)
-    rng = np.random.default_rng(7)
+    P = g["means3D"].shape[0]
+    rng = np.random.default_rng(seed)
     gc = rng.normal(size=(3, H, W)).astype(np.float32)
     gd = rng.normal(size=(H, W)).astype(np.float32)
     bg = [0.0, 0.0, 0.0]
@@ -303,7 +318,7 @@ def test_full_size_smap_backward(hip_lib, res, depth_mode):
     try:
         of = util.oracle_forward(g, cam, bg, 0)
         fragile = of["margin"] <= FRAGILE
-        assert fragile.sum() <= 4e-4 * W * H, f"{int(fragile.sum())} fragile pixels"
+        assert fragile.sum() <= max_fragile * W * H, f"{int(fragile.sum())} fragile pixels"
         gc[:, fragile] = 0.0
         gd[fragile] = 0.0
         o = util.oracle_backward(g, cam, bg, gc, gd, 0)
@@ -311,6 +326,10 @@ def test_full_size_smap_backward(hip_lib, res, depth_mode):
     finally:
         oracle.raster_set_depth_mode(0)
     p = run_product(g, cam, bg, 0, grads=(gc, gd), depth_mode=depth_mode)
+    import os
+    if os.environ.get("GSICP_PARITY_DUMP"):     # the product's gradients for off-line analysis against the oracle (which needs no GPU)
+        os.makedirs(os.environ["GSICP_PARITY_DUMP"], exist_ok=True)
+        np.savez(os.path.join(os.environ["GSICP_PARITY_DUMP"], report_tag + "_hip_grads.npz"), **{k: v for k, v in p["grads"].items() if v is not None})
     assert np.array_equal(p["radii"], of["radii"])
     n_vis = int((of["radii"] > 0).sum())
     tile_len = (of["ranges"][:, 1].astype(np.int64) - of["ranges"][:, 0])
@@ -324,36 +343,140 @@ def test_full_size_smap_backward(hip_lib, res, depth_mode):
 
     pairs = [("means3D", "dL_dmeans3D"), ("opacities", "dL_dopacity"), ("scales", "dL_dscales"), ("rotations", "dL_drots"),
              ("shs", "dL_dsh"), ("means2D", "dL_dmeans2D")]
-    report = dict(resolution=f"{W}x{H}", depth_mode=depth_mode, gaussians=300_000, visible=n_vis, duplicates=int(p["num_rendered"]),
+    report = dict(scene=gaussians_label, resolution=f"{W}x{H}", depth_mode=depth_mode, gaussians=P, visible=n_vis, duplicates=int(p["num_rendered"]),
+                  longest_tile_list=int(tile_len.max()), mean_tile_list=float(tile_len.mean()),
                   fragile_pixels_zeroed=int(fragile.sum()), fragile_fraction=float(fragile.mean()),
                   bound="|hip - oracle32| <= 1e-5 max|g| + 1e-4 |g| + min(2 |oracle32 - oracle64|, 1e-4 max|g|), every visible Gaussian", gradients={})
     failures = []
+    fscale = np.ones((P, 1))
+    if cond_scale:
+        ca, cb, cc = (of["geom"][:, 3 + i].astype(np.float64) for i in range(3))
+        tr, det = ca + cc, ca * cc - cb * cb
+        disc = np.sqrt(np.maximum(tr * tr - 4.0 * det, 0.0))
+        chi = np.where(of["radii"] > 0, (tr + disc) / np.maximum(tr - disc, 1e-300), 1.0)
+        fscale = np.maximum(1.0, (chi / 100.0) ** 2)[:, None]
+        report.update(conditioning="base bound x max(1, (chi / 100)^2), term capped at 2e-2 max|g|; chi = eigenvalue ratio of the screen-space covariance",
+                      gaussians_with_chi_over_100=int((chi > 100.0).sum()), chi_quantiles_50_99_max=[float(v) for v in np.quantile(chi[of["radii"] > 0], [0.5, 0.99, 1.0])])
     for name, key in pairs:
-        a = p["grads"][name].reshape(300_000, -1).astype(np.float64)
-        b = o[key].reshape(300_000, -1).astype(np.float64)
-        b64 = o64[key].reshape(300_000, -1)
+        a = p["grads"][name].reshape(P, -1).astype(np.float64)
+        b = o[key].reshape(P, -1).astype(np.float64)
+        b64 = o64[key].reshape(P, -1)
         if name == "means2D":
             a, b, b64 = a[:, :2], b[:, :2], b64[:, :2]   # the third column is never written by the rasteriser (upstream leaves it zero)
         mx = np.abs(b).max()
         base = 1e-5 * mx + 1e-4 * np.abs(b)
-        bound = base + np.minimum(2.0 * np.abs(b - b64), 1e-4 * mx)
+        bound = np.minimum(base * fscale, np.maximum(base, 2e-2 * mx)) + np.minimum(2.0 * np.abs(b - b64), 1e-4 * mx)
         err = np.abs(a - b)
         ratio = (err / bound).max(1)
         worst = int(np.argmax(ratio))
-        report["gradients"][name] = dict(
+        extra = {}
+        if cond_scale:
+            ill = fscale[:, 0] > 1.0
+            rms_h, rms_o = (float(np.sqrt(((x_ - b64)[ill] ** 2).mean())) if ill.any() else 0.0 for x_ in (a, b))
+            extra = dict(elements_needing_chi_scaling=int((err > base + np.minimum(2.0 * np.abs(b - b64), 1e-4 * mx)).sum()),
+                         rms_to_fp64_on_chi_over_100={"hip": rms_h, "oracle32": rms_o})
+            if rms_h > 2.0 * rms_o + 1e-6 * mx:
+                failures.append(f"{label} grad {name}: on the ill-conditioned Gaussians HIP is farther from the fp64 oracle (rms {rms_h:.3e}) than the fp32 oracle is ({rms_o:.3e})")
+        report["gradients"][name] = dict(**extra, 
             max_ratio_to_bound=float(ratio.max()), max_ratio_to_base_bound=float((err / base).max()), worst_gaussian=worst,
             worst_abs_err=float(err[worst].max()), grad_max=float(mx), max_err_over_grad_max=float(err.max() / mx),
             worst_gaussian_longest_list=list_depth(worst), gaussians_needing_conditioning_term=int((err > base).any(1).sum()),
             elements_needing_conditioning_term=int((err > base).sum()), elements=int(err.size),
             oracle32_vs_oracle64_max_over_grad_max=float(np.abs(b - b64).max() / mx))
         if ratio.max() > 1.0:
-            failures.append(f"{res} depth_mode {depth_mode} grad {name}: worst Gaussian {worst} err {err[worst]} vs oracle {b[worst]} (max|grad| {mx:.3e})")
+            failures.append(f"{label} depth_mode {depth_mode} grad {name}: worst Gaussian {worst} err {err[worst]} vs oracle {b[worst]} (max|grad| {mx:.3e})")
         # culled Gaussians get exactly zero
         assert not a[of["radii"] == 0].any()
     report["passed"] = not failures
-    _write_parity_report(f"{res}_depth{depth_mode}", report)
-    print(f"S-map backward {res} depth_mode {depth_mode}: {report}")
+    _write_parity_report(report_tag, report)
+    print(f"backward {label} depth_mode {depth_mode}: {report}")
     assert not failures, failures
+    return report
+
+
+@pytest.mark.parametrize("depth_mode", [0, 1])
+@pytest.mark.parametrize("res", ["replica", "tum", "replica_stage1", "replica_stage2"])
+def test_full_size_smap_backward(hip_lib, res, depth_mode):
+    """R-bwd at BASELINE sizes: S-map P = 300 k at 1200x680 and 640x480 (and the training_stage sizes), random dL/dcolour and
+    dL/ddepth, both depth rules, all six gradients compared with the fp32 oracle ELEMENT-WISE, EVERY visible Gaussian to the same bound:
+        |hip - oracle| <= 1e-5 * max|oracle| + 1e-4 * |oracle| + min(2 |oracle_f32 - oracle_f64|, 1e-4 * max|oracle|).
+    The last term is the fp32 oracle's OWN rounding noise on that element (conic -> covariance -> quaternion is a sum of products
+    of dL/dSigma ~ 1e5 with derivatives ~ 1e-4 that cancel to O(10): where fp32 cannot do better the bar is what fp32 delivers);
+    the number of elements that need it is reported.
+    Fragile pixels (forward decision margin < 1e-5: exp() differs in the last ulps between libm and the GPU, so an alpha or transmittance
+    test there may legitimately flip; a few per 10^4 pixels) get dL/dcolour = dL/ddepth = 0 on BOTH sides: every term a pixel contributes
+    to any gradient is linear in its dL/dpixel, so such a pixel contributes exactly nothing whichever way its decisions fall, and no
+    Gaussian sees a flipped decision — there is no looser class of Gaussians (round 2 held up to 8 % of the visible set to 5e-3)."""
+    compare_backward(synth.s_map(300_000, seed=2), _stage_cam(res), depth_mode, f"S-map {res}", f"{res}_depth{depth_mode}", "S-map (synthetic surfels, seed 2)")
+
+
+# ---------------------------------------------------------------------------------------------- a TRAINED map, several keyframe poses
+_TRAINED = {}
+
+
+def _trained_map():
+    """The map the fused loop (tools/slam_demo.py) builds on the 240-frame synthetic sequence: >= 1 600 mapper iterations (6 per frame + 200 after
+    the last), keyframe growth, pruning.  Thousands of Adam steps have stretched and overlapped the Gaussians the way a real run does —
+    the mapper's actual workload [REF mp_Mapper.py:200-223], unlike the untrained S-map surfels.  Built once per session in a child process."""
+    if not _TRAINED:
+        import os
+        import subprocess
+        import sys
+        import tempfile
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(tempfile.mkdtemp(prefix="gsicp_trained_"), "map.npz")
+        subprocess.run([sys.executable, os.path.join(root, "tools", "slam_demo.py"), "240", "--iters", "6", "--post-iters", "200", "--no-asserts",
+                        "--save-map", path], check=True, cwd=root, stdout=subprocess.DEVNULL, timeout=900)
+        z = np.load(path)
+        assert int(z["mapper_iterations"]) >= 1500
+        _TRAINED.update(g={k: np.ascontiguousarray(z[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")}, poses=z["keyframe_poses"],
+                        iterations=int(z["mapper_iterations"]))
+    return _TRAINED
+
+
+def _trained_poses(hip_lib):
+    """First keyframe, a middle one, the last one, and the keyframe whose view has the LONGEST tile list (found with the product's own ranges)."""
+    t = _trained_map()
+    if "pick" not in t:
+        cfg = synth.REPLICA
+        longest = []
+        for k, pose in enumerate(t["poses"]):
+            cam = synth.make_camera(cfg["W"], cfg["H"], cfg["fx"], cfg["fy"], pose)
+            p = run_product(t["g"], cam, [0, 0, 0], 0)
+            s = util.read_scratch(hip_lib, p["scratch"], t["g"]["means3D"].shape[0], p["num_rendered"], cfg["W"], cfg["H"])
+            longest.append(int((s["ranges"][:, 1].astype(np.int64) - s["ranges"][:, 0]).max()))
+        n = len(t["poses"])
+        pick = []
+        for k in (0, n // 2, n - 1, int(np.argmax(longest))):
+            if k not in pick:
+                pick.append(k)
+        t["pick"], t["longest"] = pick, longest
+    return t["pick"]
+
+
+@pytest.mark.parametrize("which", [0, 1, 2, 3])
+def test_trained_map_forward_and_backward(hip_lib, which):
+    """Rasteriser parity on a TRAINED map from several keyframe poses at 1200x680: lists / ranges / radii / n_contrib
+    bit-exact; images within 1e-5 outside the fragile pixels (their fraction is reported, bound 2e-3 here: a trained map's lists are 250 entries long on
+    average, up to 835, so a pixel takes far more threshold decisions, and the oracle's margin counts a decision as fragile inside the evaluation noise of ITS operands: 8 eps x the
+    magnitude of power's cancelling terms for the alpha tests, 2e-7 x entries blended for the transmittance test — oracle/raster_oracle.cpp) EXCEPT where a pixel blends 300-420 entries: there two fp32 evaluation orders of the transmittance
+    product differ by up to 2e-5 (measured: 19 of 816 000 pixels of keyframe 0, all with n_contrib >= 320; the fp32 oracle is as far from
+    its own fp64 instance on them), so the bar per pixel is max(1e-5, 1e-7 x its n_contrib) (1.7 ulp per blended entry, capped at 1e-4), at most 1e-4
+    of the pixels may exceed 1e-5, and their number is reported; and all six gradients to the bound of test_full_size_smap_backward, its base term scaled by the conditioning of the
+    Gaussian's screen-space covariance where that exceeds 100 (compare_backward: 4.4 % of the trained map, needles that fp32 itself cannot resolve)."""
+    t = _trained_map()
+    pick = _trained_poses(hip_lib)
+    if which >= len(pick):
+        pytest.skip("the longest-list keyframe is one of the other three")
+    k = pick[which]
+    cfg = synth.REPLICA
+    cam = synth.make_camera(cfg["W"], cfg["H"], cfg["fx"], cfg["fy"], t["poses"][k])
+    label = f"trained map ({t['iterations']} iterations, {t['g']['means3D'].shape[0]} Gaussians), keyframe {k} of {len(t['poses'])}"
+    o, p, stats = check_forward(t["g"], cam, [0, 0, 0], 0, hip_lib, label, max_fragile=2e-3, fp32_noise_cap=1e-4)
+    print(label, "num_rendered", p["num_rendered"], "longest tile list", t["longest"][k], stats)
+    rep = compare_backward(t["g"], cam, 0, label, f"trained_kf{k}_depth0", label, max_fragile=2e-3, cond_scale=True)
+    rep.update(forward=stats, keyframe=int(k), longest_list_is_max_over_keyframes=bool(t["longest"][k] == max(t["longest"])))
+    _write_parity_report(f"trained_kf{k}_depth0", rep)
 
 
 def test_alpha_normalised_depth_mode_forward_and_backward(hip_lib):

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--scale-semantics", choices=["stddev", "variance"], default="stddev")
     ap.add_argument("--json", default=None, help="write the run summary and the quality curve here")
     ap.add_argument("--no-asserts", action="store_true")
+    ap.add_argument("--save-map", default=None, help="write the trained map (ACTIVATED parameters as the rasteriser takes them) and the keyframe poses to this .npz "
+                    "(tests/test_raster_gpu.py::test_trained_map_* compare the rasteriser with the oracle on it)")
     ap.add_argument("--dump", default=None, help="directory for side-by-side (ground truth | render | accumulated alpha) PNGs of a few frames at the final checkpoint")
     args = ap.parse_args()
 
@@ -85,6 +87,7 @@ def main():
     class Keyframe:
         def __init__(self, pose, rgb_dev, d16_dev):
             cam = synth.make_camera(W, H, cfg["fx"], cfg["fy"], pose)
+            self.pose = np.asarray(pose, np.float64).copy()
             self.view = torch.from_numpy(cam["viewmatrix"]).to(dev)
             self.proj = torch.from_numpy(cam["projmatrix"]).to(dev)
             self.campos = torch.from_numpy(cam["campos"]).to(dev)
@@ -290,6 +293,12 @@ def main():
           f"{store.n} Gaussians, graph captures {captures}, re-captures {recaptures}, skipped optimiser steps {mg.skipped_steps()}")
     print(f"worst pose error {worst[0]:.4f} deg / {worst[1]:.3f} mm; loop wall {t_loop:.2f} s = {(args.frames - 1) / t_loop:.1f} frames/s "
           f"with {args.iters} mapper iterations per frame (frame maker before the loop: {t_gen:.1f} s)")
+    if args.save_map:
+        with torch.no_grad():
+            np.savez(args.save_map, means3D=store.live("xyz").cpu().numpy(), shs=store.live("f_dc").cpu().numpy(),
+                     opacities=torch.sigmoid(store.live("opacity")).cpu().numpy(), scales=torch.exp(store.live("scaling")).cpu().numpy(),
+                     rotations=torch.nn.functional.normalize(store.live("rotation")).cpu().numpy(),
+                     keyframe_poses=np.stack([k_.pose for k_ in keyframes]), mapper_iterations=train_iter, frames=args.frames)
     if args.json:
         import json
         with open(args.json, "w") as fh:
