@@ -108,6 +108,12 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
                      ("psnr", r"PSNR:\s*([-\d.eE+naninf]+)"), ("ssim", r"SSIM:\s*([-\d.eE+naninf]+)")):
         m = re.search(pat, out)
         res[key] = float(m.group(1)) if m else None
+    # GSICP_ATE_DETAIL=1 (tests/refstubs/sitecustomize.py): the reference's "ATE RMSE" is the MEAN aligned translation error [REF mp_Tracker.py:479];
+    # the true RMSE / median / maximum of the same per-frame errors are printed next to it
+    m = re.search(r"ATE detail: true_rmse_cm ([-\d.eE+]+) mean_cm ([-\d.eE+]+) median_cm ([-\d.eE+]+) max_cm ([-\d.eE+]+)", out)
+    if m:
+        res.update(ate_true_rmse_cm=float(m.group(1)), ate_mean_cm=float(m.group(2)), ate_median_cm=float(m.group(3)), ate_max_cm=float(m.group(4)),
+                   ate_statistic_printed_by_the_reference="mean of the aligned translation errors (labelled 'ATE RMSE')")
     return res, out
 
 
