@@ -932,20 +932,6 @@ def main():
             if name == "steady":
                 legs["tracker_only_steady"].update(target_gaussians=case.n_target, worst_pose_error_deg_mm=[round(case.worst[0], 4), round(case.worst[1], 3)],
                                                    index=case.reg.target_index_stats())
-        # -- rounds 1-3's headline composite for continuity: SURVEY 8(d)'s S-pair re-aligned against a frame-sized target, concurrent with the mapper
-        #    (which now cycles its keyframe views); round 3 measured 0.3685 ms with ONE view
-        if worker is not None and free_running and steady:
-            def pair_block(steps):
-                jobs.put((cases["survey"], steps))
-                for _ in range(steps):
-                    mapper_iteration()
-                done.get()
-            for _ in range(3):
-                pair_block(10)
-            pb = timed_blocks(None, args.steps, reps, whole=pair_block)
-            legs["survey_pair_step"] = {"frames_per_s": round(args.steps / statistics.median(pb), 1), "ms_per_step": round(1e3 * statistics.median(pb) / args.steps, 4),
-                                        "what": "the headline of rounds 1-3: tracker frame on SURVEY 8(d)'s S-pair (7 LM iterations, frame-sized target, lands 60 mm off) "
-                                                "concurrent with one mapper iteration"}
         # -- the tracker against MAP-sized targets (its steady-state configuration after the first tracking keyframe)
         if os.environ.get("GSICP_BENCH_MAP_LEG", "1") != "0":
             legs["tracker_vs_map"] = tracker_vs_map_leg()
@@ -1099,7 +1085,7 @@ def main():
     # ---------------- the reference's OWN two-process system on the drop-ins: BASELINE's metric as SURVEY 8(d) defines it ----------------
     # System FPS [REF mp_Tracker.py:333] and ATE (the reference's mean statistic [REF mp_Tracker.py:334, 479] and a true RMSE) of the unmodified
     # gs_icp_slam_unlimit.py on a 400-frame synthetic Replica-layout sequence, PSNR / SSIM of its end-of-run pass [REF mp_Mapper.py:335-422]
-    ref_run = None
+    ref_run = ref_run_fused = None
     if rank == 0 and world == 1 and args.only is None and not args.no_reference_leg and not args.no_legs and os.environ.get("GSICP_BENCH_CHILD") != "1":
         import subprocess
         torch.cuda.synchronize()
@@ -1112,6 +1098,16 @@ def main():
         except Exception as e:   # noqa: BLE001 — the reference run must not take the benchmark line with it
             ref_run = {"status": "failed", "why": f"{type(e).__name__}: {e}"}
         ref_run["leg_wall_s"] = round(time.perf_counter() - t0r, 1)
+        # the same run with SURVEY 8(f)'s rows applied to the reference's files (oracle/make_refpy.py --fused; gs_icp_slam_amd/refglue.py)
+        ref_run_fused = None
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "refpy_fused", "mp_Mapper.pyc")):
+            try:
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_slam.py"), "--synthetic", "400", "--cache", "/tmp/gsicp_synth_cache",
+                                     "--timeout", "240", "--fused"], capture_output=True, text=True, timeout=420)
+                line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                ref_run_fused = json.loads(line[-1]) if line else {"status": "failed", "why": (pr.stderr or pr.stdout)[-400:]}
+            except Exception as e:   # noqa: BLE001
+                ref_run_fused = {"status": "failed", "why": f"{type(e).__name__}: {e}"}
 
     # ---------------- multi-GPU bookkeeping ----------------
     ranks_seen = None
@@ -1204,7 +1200,7 @@ def main():
             "legs": legs, "roofline": roofline, "roofline_longest_kernel": roofline_align, "cpu_baseline": cpu,
         }
         if ref_run is not None:
-            out["legs"] = dict(out["legs"] or {}, reference_system_run=ref_run)
+            out["legs"] = dict(out["legs"] or {}, reference_system_run=ref_run, reference_system_run_fused=ref_run_fused)
         print(json.dumps(out))
     if worker is not None:
         jobs.put(None)

@@ -1,0 +1,213 @@
+"""The "next" rows of SURVEY.md §8(f) INSIDE the reference's own two-process system.
+
+INTEGRATION.md §6-8 describes the fused mapper iteration, the capacity-based map store, the device-resident hand-off and the front-end kernel as
+few-line edits of `mp_Mapper.py`, `mp_Tracker.py`, `scene/gaussian_model.py` and `scene/shared_objs.py`.  This module is what those few lines call;
+`oracle/make_refpy.py --fused` applies the edits as an AST transform at build time (into the git-ignored `oracle/_ref/refpy_fused`; no reference
+source enters this repository) and `tools/run_reference_slam.py --fused` runs the result.  The edits, all of them:
+
+  scene/gaussian_model.py   + `patch_gaussian_model(GaussianModel)` after the class                                              (rank 4, rank 1)
+        the map lives in a `GaussianStore(stable=True)`: create_from_pcd2_tensor / add_from_pcd2_tensor append rows in place, prune_large_and_transparent
+        is one stream compaction, training_setup builds `FusedAdam(capturable=True)` over the store's buffers; `_xyz`, `_opacity`, ... stay readable
+        (live [:n] views), so render_3 (end-of-run evaluation), save_ply and get_trackable_gaussians_tensor keep working                [REF :134-231, 409-492, 580-592]
+  mp_Mapper.py              the statements between `self.training=True` and `self.training = False` (render_3, mask, l1 / ssim / depth loss,
+        backward, prune every 200, optimizer.step, zero_grad) -> `fused_mapping_iteration(self, viewpoint_cam, gt_image, gt_depth_image)`:
+        set_view + ONE hipGraph replay (one capture per resolution for the whole run)                                                (rank 1)  [REF :219-262]
+  scene/shared_objs.py      + `patch_shared_targets(SharedTargetPoints)`: the tracker's new target crosses the process boundary as DEVICE tensors
+        (HIP-IPC, like SharedGaussians in the other direction) instead of pinned-less host copies                                   (rank 2)  [REF :99-126]
+  mp_Tracker*.py            `get_values_np()` -> `get_values_tensor()` at the tracking keyframe (pygicp takes the device tensors), and
+        + `patch_tracker(Tracker)`: downsample_and_make_pointcloud2 runs the front-end kernel (same return values, bit for bit)      (ranks 2, 3)  [REF :282-288, 415-431]
+
+Everything here calls the product (store, graph, optimiser, tracker mirror); nothing falls back to the reference's torch chain when the HIP library is missing.
+"""
+import math
+import os
+
+import torch
+
+from . import _lib
+from .gaussian_store import GaussianStore, rows_from_gicp
+from .optim import FusedAdam
+
+
+# ------------------------------------------------------------------------------------------------------------------ scene/gaussian_model.py
+def _refresh_views(gm):
+    st = gm._store
+    gm._xyz, gm._features_dc, gm._features_rest = st.live("xyz"), st.live("f_dc"), st.live("f_rest")
+    gm._opacity, gm._scaling, gm._rotation = st.live("opacity"), st.live("scaling"), st.live("rotation")
+    gm.max_radii2D = st.view("aux", "max_radii2D")
+    gm.xyz_gradient_accum, gm.denom = st.view("aux", "xyz_gradient_accum"), st.view("aux", "denom")
+    gm.trackable_mask = st.trackable_mask
+
+
+def patch_gaussian_model(cls):
+    """Store-backed replacements for the GaussianModel methods the mapping process calls [REF mp_Mapper.py:131-136, 163-187, 244-245]."""
+    if getattr(cls, "_gsicp_fused", False):
+        return cls
+    plain_update_lr = cls.update_learning_rate
+
+    def create_from_pcd2_tensor(self, points, colors, rots_, scales_, z_vals_, trackable_idxs):
+        capacity = int(os.environ.get("GSICP_FUSED_CAPACITY", "1500000"))
+        n_rest = (self.max_sh_degree + 1) ** 2 - 1
+        self._store = GaussianStore(capacity, n_rest=n_rest, device=points.device, stable=True)
+        rows, mask = rows_from_gicp(points.float(), colors.float(), rots_.float(), scales_.float(), z_vals_.float(), trackable_idxs, self.max_sh_degree)
+        self._store.append(rows, mask)
+        _refresh_views(self)
+        self.keyframe_idx = torch.ones((self._store.n, 1), dtype=torch.bool, device=points.device)
+
+    def add_from_pcd2_tensor(self, points, colors, rots_, scales_, z_vals_, trackable_idxs):
+        rows, mask = rows_from_gicp(points.float(), colors.float(), rots_.float(), scales_.float(), z_vals_.float(),
+                                    trackable_idxs if len(trackable_idxs) != 0 else None, self.max_sh_degree)
+        self._store.append(rows, mask)          # rows written in place, live count bumped on the device: the captured iteration keeps replaying
+        _refresh_views(self)
+
+    def training_setup(self, training_args):
+        from utils.general_utils import get_expon_lr_func     # the reference's own scheduler [REF scene/gaussian_model.py:233-236]
+        self.percent_dense = training_args.percent_dense
+        lrs = {"xyz": training_args.position_lr_init * self.spatial_lr_scale, "f_dc": training_args.feature_lr, "f_rest": training_args.feature_lr / 20.0,
+               "opacity": training_args.opacity_lr, "scaling": training_args.scaling_lr, "rotation": training_args.rotation_lr}
+        self.optimizer = self._store.attach(FusedAdam, lrs, lr=0.0, eps=1e-15, capturable=True)
+        self.xyz_scheduler_args = get_expon_lr_func(lr_init=training_args.position_lr_init * self.spatial_lr_scale,
+                                                    lr_final=training_args.position_lr_final * self.spatial_lr_scale,
+                                                    lr_delay_mult=training_args.position_lr_delay_mult, max_steps=training_args.position_lr_max_steps)
+
+    def update_learning_rate(self, iteration):
+        out = plain_update_lr(self, iteration)
+        self.optimizer.sync_lr()                # the capturable optimiser reads its learning rates from the device
+        return out
+
+    def prune_large_and_transparent(self, min_opacity, extent):
+        with torch.no_grad():
+            remove = (torch.sigmoid(self._store.live("opacity")) < min_opacity).squeeze(-1)
+            if extent is not None:
+                remove = torch.logical_or(remove, torch.exp(self._store.live("scaling")).max(dim=1).values > 0.1 * extent)
+            self._store.prune(remove)           # one order-preserving compaction of all 23 arrays; addresses unchanged
+        _refresh_views(self)
+
+    def get_trackable_gaussians_tensor(self, opacity_th):
+        with torch.no_grad():
+            keep = torch.logical_and((self.get_opacity > opacity_th).squeeze(-1), self.trackable_mask)
+            out = self.get_xyz[keep], self.get_rotation[keep], self.get_scaling[keep]
+        return out if os.environ.get("GSICP_FUSED_DEVICE_TARGETS", "1") == "1" else tuple(t.cpu() for t in out)
+
+    for fn in (create_from_pcd2_tensor, add_from_pcd2_tensor, training_setup, update_learning_rate, prune_large_and_transparent,
+               get_trackable_gaussians_tensor):
+        setattr(cls, fn.__name__, fn)
+    cls._gsicp_fused = True
+    return cls
+
+
+# ------------------------------------------------------------------------------------------------------------------ mp_Mapper.py
+_STAMPS = []
+
+
+def _stamp(mapper):
+    """In-system mapper cadence (GSICP_ANNOUNCE, set by tools/run_reference_slam.py): entry times of the iterations; at process exit the interval
+    statistics are printed — the counterpart of what the drop-in call trace yields for the untouched loop (one iteration = the time between two
+    rasteriser forward calls)."""
+    if not os.environ.get("GSICP_ANNOUNCE"):
+        return
+    import time
+    if not _STAMPS:
+        import atexit
+
+        def report():
+            if len(_STAMPS) > 2:
+                d = sorted(b - a for a, b in zip(_STAMPS[:-1], _STAMPS[1:]))
+                print(f"GSICP_FUSED_MAPPER iterations {len(_STAMPS)} median_ms {1e3 * d[len(d) // 2]:.4f} mean_ms {1e3 * sum(d) / len(d):.4f} "
+                      f"p90_ms {1e3 * d[int(0.9 * (len(d) - 1))]:.4f} captures {mapper.__dict__.get('_gsicp_captures', 0)} gaussians {mapper.gaussians._store.n}", flush=True)
+        atexit.register(report)
+    _STAMPS.append(time.perf_counter())
+
+
+@_lib.traced("refglue.fused_mapping_iteration")
+def fused_mapping_iteration(mapper, viewpoint_cam, gt_image, gt_depth_image):
+    """What stands where [REF mp_Mapper.py:219-262] stood: one keyframe selection launch + one hipGraph replay (activations inside the rasteriser,
+    forward, fused L1 + SSIM + depth loss, backward, capturable Adam), the prune every 200 iterations, and the list-capacity check."""
+    from .graph import MapperIterationGraph
+    gm = mapper.gaussians
+    store = gm._store
+    _stamp(mapper)
+    H, W = int(gt_image.shape[-2]), int(gt_image.shape[-1])
+    graphs = gm.__dict__.setdefault("_gsicp_graphs", {})
+    mg = graphs.get((H, W))
+    if mg is None:
+        params = {"means3D": store.params["xyz"], "shs": store.params["f_dc"], "opacities": store.params["opacity"],
+                  "scales": store.params["scaling"], "rotations": store.params["rotation"]}
+        if store.n_rest != 0:
+            raise RuntimeError("fused mapping iteration: sh_degree > 0 needs the f_dc / f_rest concatenation inside the graph (not built: the reference runs sh_degree 0)")
+        mg = MapperIterationGraph(params, gm.optimizer, H, W, math.tan(float(viewpoint_cam.FoVx[0]) * 0.5), math.tan(float(viewpoint_cam.FoVy[0]) * 0.5),
+                                  sh_degree=gm.active_sh_degree, capacity=int(os.environ.get("GSICP_FUSED_LIST_CAPACITY", str(1 << 23))),
+                                  bg=mapper.background, lambda_dssim=mapper.lambda_dssim, warmup=1, live_count=store.live_count)
+        mg.set_view(viewpoint_cam.world_view_transform, viewpoint_cam.full_proj_transform, viewpoint_cam.camera_center, gt_image.contiguous(),
+                    gt_depth_image.contiguous())
+        mg.capture()                            # applies no optimiser update (the warm-up is rolled back)
+        graphs[(H, W)] = mg
+        mapper.__dict__["_gsicp_captures"] = mapper.__dict__.get("_gsicp_captures", 0) + 1
+    if mapper.train_iter % 200 == 0:            # the reference prunes BEFORE the step of these iterations [REF mp_Mapper.py:244-245]
+        gm.prune_large_and_transparent(0.005, mapper.prune_th)
+    mg.set_view(viewpoint_cam.world_view_transform, viewpoint_cam.full_proj_transform, viewpoint_cam.camera_center, gt_image.contiguous(),
+                gt_depth_image.contiguous())
+    # Bounded run-ahead: a graph launch returns at once, so this loop could queue thousands of iterations ahead of the GPU — and the TRACKER process's
+    # small kernels would wait behind them (measured without the bound: tracker 17 ms per frame, System FPS 66 instead of 167).  The reference's own
+    # iteration is throttled by its synchronous forward; here at most `GSICP_FUSED_INFLIGHT` (2) replays are in flight.
+    ring = gm.__dict__.setdefault("_gsicp_ring", [torch.cuda.Event() for _ in range(max(1, int(os.environ.get("GSICP_FUSED_INFLIGHT", "2"))))])
+    slot = mapper.train_iter % len(ring)
+    if mapper.train_iter >= len(ring):
+        ring[slot].synchronize()
+    loss = mg.step()
+    ring[slot].record()
+    if mapper.train_iter % 50 == 49:            # duplicate lists outgrown: steps were skipped on the device; enlarge, re-capture, repeat them
+        lost = mg.ensure_capacity()
+        for _ in range(lost):
+            mg.step()
+    return loss
+
+
+# ------------------------------------------------------------------------------------------------------------------ scene/shared_objs.py
+def patch_shared_targets(cls):
+    """SharedTargetPoints [REF scene/shared_objs.py:99-126] with DEVICE buffers: the mapper writes the trackable Gaussians with a device-to-device
+    copy, the tracker process reads them through HIP-IPC (how SharedGaussians already crosses in the other direction).  The writer synchronises
+    before it raises `target_gaussians_ready` [REF mp_Mapper.py:170-171]: the flag is host shared memory, the copies are asynchronous."""
+    if getattr(cls, "_gsicp_fused", False) or os.environ.get("GSICP_FUSED_DEVICE_TARGETS", "1") != "1":
+        return cls
+    plain_init, plain_input = cls.__init__, cls.input_values
+
+    def __init__(self, num_points):
+        plain_init(self, min(int(num_points), int(os.environ.get("GSICP_FUSED_TARGET_CAPACITY", "3000000"))))
+        self.xyz, self.rots, self.scales = self.xyz.cuda(), self.rots.cuda(), self.scales.cuda()
+
+    def input_values(self, new_xyz, new_rots, new_scales):
+        plain_input(self, new_xyz, new_rots, new_scales)
+        torch.cuda.synchronize()
+
+    cls.__init__, cls.input_values = __init__, input_values
+    cls._gsicp_fused = True
+    return cls
+
+
+# ------------------------------------------------------------------------------------------------------------------ mp_Tracker.py
+def patch_tracker(cls):
+    """Tracker.downsample_and_make_pointcloud2 [REF mp_Tracker.py:415-431] through the front-end kernel: depth and colour go to the device, ONE launch
+    picks / converts / compacts / back-projects, the four arrays come back as numpy with the values the reference's torch-CPU chain yields bit for bit
+    (tests/test_frontend.py, tests/test_hostcode_pinned.py) — the rest of Tracker.tracking keeps its numpy interface."""
+    if getattr(cls, "_gsicp_fused", False):
+        return cls
+    import numpy as np
+
+    def downsample_and_make_pointcloud2(self, depth_img, rgb_img):
+        from .frontend import DepthFrontEnd
+        fe = self.__dict__.get("_gsicp_frontend")
+        if fe is None:
+            fe = DepthFrontEnd(self.H, self.W, self.fx, self.fy, self.cx, self.cy, self.downsample_rate, self.depth_scale, self.depth_trunc)
+            self.__dict__["_gsicp_frontend"] = fe
+        d = np.ascontiguousarray(depth_img)
+        if d.dtype == np.uint16:
+            d_dev = torch.from_numpy(d.view(np.int16)).cuda()
+        else:
+            d_dev = torch.from_numpy(d.astype(np.float32)).cuda()
+        pc = fe.make_pointcloud(d_dev, torch.from_numpy(np.ascontiguousarray(rgb_img)).cuda())
+        return pc.points.cpu().numpy(), pc.colors.cpu().numpy(), pc.z_values.cpu().numpy(), pc.trackable_idx.cpu().numpy().astype(np.int64)
+
+    cls.downsample_and_make_pointcloud2 = downsample_and_make_pointcloud2
+    cls._gsicp_fused = True
+    return cls

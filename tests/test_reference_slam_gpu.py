@@ -70,3 +70,25 @@ def test_untouched_reference_runs_on_compiled_extension_modules_at_all_three_bou
     assert res["raster_binding"].startswith("compiled"), res
     assert res["processes_that_loaded_it"] >= 2          # tracker (pygicp at import) and mapper (_C at its first render)
     assert res["ate_rmse_cm"] <= 0.03, res["ate_rmse_cm"]
+
+
+def test_fused_rows_inside_the_reference_two_process_system():
+    """SURVEY 8(f)'s rows EXECUTED inside the reference's own two processes: INTEGRATION.md 6-8's few-line edits are applied
+    to the reference's files as an AST transform at build time (oracle/make_refpy.py --fused -> oracle/_ref/refpy_fused, byte-code only) and call
+    gs_icp_slam_amd/refglue.py: the map in a GaussianStore(stable=True), FusedAdam(capturable), the iteration as ONE hipGraph replay captured once for
+    the whole run, the tracker's new target as device tensors through HIP-IPC, the front-end kernel.  Same sequence and entry point as the untouched
+    run of the test above.  Thresholds within ~20-30 % of the MI355X measurement of round 4 (400 frames unlimited: mapper iteration 0.57 ms median
+    against 16.8 ms untouched, System FPS 135 against 113, ATE 0.01 cm both, PSNR 35.2 dB against 28.4)."""
+    sys.path.insert(0, ROOT)
+    from tools.run_reference_slam import find_reference
+    if find_reference(fused=True) is None:
+        pytest.skip("oracle/_ref/refpy_fused not built (python oracle/make_refpy.py where /root/reference exists)")
+    res = _run(["--synthetic", "300", "--limit30", "--fused"])
+    assert res["variant"].startswith("FUSED") and res["reference"].endswith("refpy_fused")
+    assert res["processes_that_loaded_it"] >= 3
+    assert 24.0 < res["system_fps"] <= 30.5, res["system_fps"]
+    assert res["ate_rmse_cm"] <= 0.03, res["ate_rmse_cm"]
+    fm = res["fused_mapper"]
+    assert fm["graph_captures"] == 1, fm                       # keyframe growth and pruning never re-captured
+    assert fm["median_ms_per_iteration"] < 1.2, fm             # 16.8 ms in the untouched system
+    assert res["psnr"] > 33.0 and res["ssim"] > 0.95, (res["psnr"], res["ssim"])     # untouched, same run: 33.8 dB / 0.971

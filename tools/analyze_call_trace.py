@@ -52,6 +52,13 @@ def main(d):
                             dropin_ms_by_call={n: round(1e3 * v / len(fr), 3) for n, v in sorted(per.items())})
             out["tracker"] = dict(plain_frames=stat(lambda f: not f["key"]), mapping_keyframes=stat(lambda f: f["key"] and not f["tkey"]),
                                   tracking_keyframes=stat(lambda f: f["tkey"]), all=stat(lambda f: True))
+        elif "refglue.fused_mapping_iteration" in names:     # the FUSED system (tools/run_reference_slam.py --fused): one call per mapper iteration
+            it = [e for e in ev if e[0] == "refglue.fused_mapping_iteration"]
+            if len(it) > 3:
+                dt = np.diff([e[1] for e in it])
+                out["mapper"] = dict(iterations=len(it), median_ms_per_iteration=round(1e3 * float(np.median(dt)), 3),
+                                     mean_ms_per_iteration=round(1e3 * float(dt.mean()), 3), p90_ms_per_iteration=round(1e3 * float(np.quantile(dt, 0.9)), 3),
+                                     call_ms=round(1e3 * float(np.median([b - a for _, a, b in it])), 3), variant="fused: one hipGraph replay per iteration")
         elif "raster.forward" in names:
             fw = [e for e in ev if e[0] == "raster.forward"]
             bw = [e for e in ev if e[0] == "raster.backward"]

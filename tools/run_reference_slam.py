@@ -25,7 +25,10 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def find_reference(explicit=None):
+def find_reference(explicit=None, fused=False):
+    if fused:      # the AST-transformed byte-code of oracle/make_refpy.py --fused (INTEGRATION.md 6-8's edits applied; gs_icp_slam_amd/refglue.py)
+        cand = os.path.join(ROOT, "oracle", "_ref", "refpy_fused")
+        return cand if os.path.exists(os.path.join(cand, "mp_Tracker.pyc")) else None
     for cand in (explicit, os.environ.get("GSICP_REFERENCE"), "/root/reference", os.path.join(ROOT, "oracle", "_ref", "refpy")):
         if cand and (os.path.exists(os.path.join(cand, "mp_Tracker.py")) or os.path.exists(os.path.join(cand, "mp_Tracker.pyc"))):
             return cand
@@ -76,6 +79,7 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MPLBACKEND", "Agg")
     env["GSICP_ANNOUNCE"] = "1"
+    env.setdefault("GSICP_ATE_DETAIL", "1")       # tests/refstubs/sitecustomize.py: print the true RMSE next to the reference's mean statistic
     # Three processes x torch's default intra-op pool (one thread per hardware thread, spinning after every parallel region) exhaust a
     # container's cgroup CPU quota within the first ~20 ms of every 100 ms scheduler period and the whole system then stalls for the
     # rest of it (measured: tracker frames and mapper iterations both alternate 10 ms / 90 ms).  The per-frame CPU work of the reference is
@@ -110,6 +114,10 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
         res[key] = float(m.group(1)) if m else None
     # GSICP_ATE_DETAIL=1 (tests/refstubs/sitecustomize.py): the reference's "ATE RMSE" is the MEAN aligned translation error [REF mp_Tracker.py:479];
     # the true RMSE / median / maximum of the same per-frame errors are printed next to it
+    m = re.search(r"GSICP_FUSED_MAPPER iterations (\d+) median_ms ([-\d.eE+]+) mean_ms ([-\d.eE+]+) p90_ms ([-\d.eE+]+) captures (\d+) gaussians (\d+)", out)
+    if m:
+        res["fused_mapper"] = dict(iterations=int(m.group(1)), median_ms_per_iteration=float(m.group(2)), mean_ms_per_iteration=float(m.group(3)),
+                                   p90_ms_per_iteration=float(m.group(4)), graph_captures=int(m.group(5)), gaussians=int(m.group(6)))
     m = re.search(r"ATE detail: true_rmse_cm ([-\d.eE+]+) mean_cm ([-\d.eE+]+) median_cm ([-\d.eE+]+) max_cm ([-\d.eE+]+)", out)
     if m:
         res.update(ate_true_rmse_cm=float(m.group(1)), ate_mean_cm=float(m.group(2)), ate_median_cm=float(m.group(3)), ate_max_cm=float(m.group(4)),
@@ -135,12 +143,14 @@ def main():
     ap.add_argument("--trace", default=None, help="directory for the drop-in call trace (GSICP_CALL_TRACE): one file per process")
     ap.add_argument("--omp-threads", type=int, default=1, help="OMP_NUM_THREADS for the reference's processes (0 = leave the environment alone)")
     ap.add_argument("--log", default=None, help="write the reference's full stdout here")
+    ap.add_argument("--fused", action="store_true", help="run the reference with INTEGRATION.md 6-8's few-line edits applied (oracle/make_refpy.py --fused: fused mapper "
+                    "iteration as one hipGraph over a GaussianStore, device-resident target hand-off, front-end kernel) instead of the untouched files")
     ap.add_argument("--compiled-pygicp", action="store_true", help="let the reference's `import pygicp` resolve to the compiled pybind11 module "
                     "integration/pygicp.<abi>.so instead of the ctypes mirror package")
     ap.add_argument("--compiled-ext", action="store_true", help="all three native boundaries as compiled extension modules: --compiled-pygicp plus "
                     "`diff_gaussian_rasterization` / `simple_knn._C` from integration/torch_ext/ (the pybind11 torch extension `_C` over the C ABI)")
     a = ap.parse_args()
-    ref = find_reference(a.reference)
+    ref = find_reference(a.reference, fused=a.fused)
     if ref is None:
         print(json.dumps({"status": "not measured", "why": "no reference tree (/root/reference or oracle/_ref/refpy) on this machine"}))
         return 0
@@ -178,7 +188,8 @@ def main():
                    compiled_pygicp=a.compiled_pygicp, compiled_ext=a.compiled_ext)
     res.update(status="measured" if res["returncode"] == 0 and res["system_fps"] is not None else "failed", dataset=a.dataset,
                data="synthetic" if a.synthetic else "real", frames=a.synthetic or None, dataset_type=dataset_type(a.config),
-               flags=flags or flags_for(a.config), entry="gs_icp_slam.py (30 FPS cap)" if a.limit30 else "gs_icp_slam_unlimit.py")
+               flags=flags or flags_for(a.config), entry="gs_icp_slam.py (30 FPS cap)" if a.limit30 else "gs_icp_slam_unlimit.py",
+               variant="FUSED: INTEGRATION.md 6-8's edits applied by oracle/make_refpy.py --fused" if a.fused else "untouched reference files")
     if a.log:
         with open(a.log, "w") as fh:
             fh.write(log)
