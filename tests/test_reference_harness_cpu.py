@@ -156,3 +156,35 @@ def test_subset_of_a_cached_sequence_is_the_sequence_prefix(tmp_path):
     assert sorted(os.listdir(os.path.join(part, "images"))) == ["frame000000.jpg", "frame000001.jpg"]
     assert len(open(os.path.join(part, "traj.txt")).readlines()) == 2
     assert open(os.path.join(part, "images", "frame000001.jpg"), "rb").read() == open(os.path.join(full, "images", "frame000001.jpg"), "rb").read()
+
+
+def test_fused_transform_edits_exactly_the_documented_statements():
+    """oracle/make_refpy.py --fused (INTEGRATION.md 6-8's few-line edits as an AST transform, byte-code only): the edited modules import with the
+    stand-ins, carry the calls into gs_icp_slam_amd/refglue.py where the reference's statements stood, and everything else of the mapping /
+    tracking functions is still there.  (The run needs a GPU: tests/test_reference_slam_gpu.py::test_fused_rows_inside_...)"""
+    _reference_dir()      # builds both trees where /root/reference exists
+    fused = os.path.join(ROOT, "oracle", "_ref", "refpy_fused")
+    if not os.path.exists(os.path.join(fused, "mp_Mapper.pyc")):
+        pytest.skip("oracle/_ref/refpy_fused not built on this machine")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, STUBS]))
+    code = ("import sys, types; sys.path.insert(0, %r); sys.argv = ['x']\n"
+            "import mp_Mapper, mp_Tracker, mp_Tracker_unlimit, scene.gaussian_model as gm, scene.shared_objs as so\n"
+            "from gs_icp_slam_amd import refglue\n"
+            "def names(f):\n"
+            "    out, todo = set(), [f.__code__]\n"
+            "    while todo:\n"
+            "        c = todo.pop(); out |= set(c.co_names); todo += [k for k in c.co_consts if isinstance(k, types.CodeType)]\n"
+            "    return out\n"
+            "m = names(mp_Mapper.Mapper.mapping)\n"
+            "assert 'fused_mapping_iteration' in m and mp_Mapper.fused_mapping_iteration is refglue.fused_mapping_iteration\n"
+            "assert not ({'render_3', 'l1_loss', 'ssim', 'backward', 'zero_grad'} & m), m      # the replaced statements are gone ...\n"
+            "assert {'add_from_pcd2_tensor', 'get_trackable_gaussians_tensor', 'mapping_cams', 'new_keyframes', 'train_iter'} <= m   # ... the loop around them is not\n"
+            "for T in (mp_Tracker.Tracker, mp_Tracker_unlimit.Tracker):\n"
+            "    t = names(T.tracking)\n"
+            "    assert 'get_values_tensor' in t and 'get_values_np' not in t and 'set_target_covariances_fromqs' in t and T._gsicp_fused\n"
+            "assert gm.GaussianModel._gsicp_fused and gm.GaussianModel.create_from_pcd2_tensor.__module__ == 'gs_icp_slam_amd.refglue'\n"
+            "assert gm.GaussianModel.save_ply.__module__ == 'scene.gaussian_model'            # untouched methods stay the reference's\n"
+            "assert so.SharedTargetPoints._gsicp_fused and so.SharedGaussians.__init__.__module__ == 'scene.shared_objs'\n"
+            "print('fused ok')\n") % fused
+    r = subprocess.run([sys.executable, "-W", "ignore", "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fused ok" in r.stdout, r.stderr[-3000:]
