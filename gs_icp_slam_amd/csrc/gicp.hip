@@ -2311,6 +2311,7 @@ int build_grid(gsicp_gicp* g) {
         g->grid_valid = true;
         return 0;
     }
+    if (n >= (1 << 26)) { g_last_error = "target index: more than 2^26 trackable targets (a work-list entry packs a cell's count in 26 bits)"; return -2; }
     if (int rc = build_level(g, 0, g->max_corr)) return rc;
     // EXTREMELY dense maps (>= 64 points per occupied gate-sized coarse cell) get a second level of the same structure at a smaller radius
     // r1 = f x gate, tried first (linearize_points): a neighbour found inside r1 is the nearest neighbour.  With m points per coarse cell the

@@ -3,7 +3,7 @@
 # usage: bash tools/capture_profiles.sh r03      (outputs under gpurun_out/<tag>/)
 # Counter passes are separate from the kernel-trace pass and never combined with other trace domains.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -12,8 +12,9 @@ export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 30 --warmup 5 --repeats 3 --no-cpu-baseline --no-legs"
 cd /tmp
 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
-python $ROOT/bench.py --res tum --no-cpu-baseline > $OUT/bench_tum.json 2>> $OUT/bench.err
-python $ROOT/bench.py --pair basin --no-cpu-baseline --no-legs > $OUT/bench_basin.json 2>> $OUT/bench.err
+python $ROOT/bench.py --res tum --no-cpu-baseline --no-legs > $OUT/bench_tum.json 2>> $OUT/bench.err
+python $ROOT/bench.py --tracker pair --pair survey --no-cpu-baseline --no-legs > $OUT/bench_pair_survey.json 2>> $OUT/bench.err   # rounds 1-3's headline composite
+python $ROOT/bench.py --tracker pair --pair basin --no-cpu-baseline --no-legs > $OUT/bench_pair_basin.json 2>> $OUT/bench.err
 python $ROOT/bench.py --no-graph --no-cpu-baseline --no-legs > $OUT/bench_eager.json 2>> $OUT/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- $BENCH > /dev/null 2> $OUT/fetch.err
@@ -30,6 +31,8 @@ GSICP_BENCH_FORCE_COLLECTIVES=1 python $ROOT/bench.py --only mapper --no-cpu-bas
 python $ROOT/tools/rccl_graph_probe.py > $OUT/rccl_graph_probe.json 2>> $OUT/bench.err
 # tracker: phase trace of the persistent LM kernel and the k-NN ring statistics on SURVEY 8(d)'s pair
 (cd $ROOT && GSICP_ALIGN_TRACE=1 GSICP_KNN_STATS=1 timeout 120 python tools/tracker_latency.py --survey > $OUT/tracker_latency_survey.txt 2>&1)
+(cd $ROOT && GSICP_ALIGN_TRACE=1 timeout 120 python tools/tracker_latency.py --map 300000 > $OUT/tracker_latency_map300k.txt 2>&1)
+(cd $ROOT && timeout 200 python tools/tracker_vs_map.py 8280 100000 300000 1000000 3000000 > $OUT/tracker_vs_map.json 2>> $OUT/bench.err)
 # the UNTOUCHED reference system on the drop-ins (synthetic sequences; one ray-cast sequence is shared through --cache): the 30-FPS-capped entry point
 # (the map has to converge through the reference's own optimiser), the unlimited one with the drop-in call trace, and the TUM branch (TUM on-disk
 # layout, tum.sh flags).  The 1500-frame unlimited run of round 3 is captured by tools/capture_reference_runs.sh.
@@ -38,6 +41,12 @@ C=/tmp/gsicp_cache
 timeout 600 python tools/run_reference_slam.py --cache $C --synthetic 400 --timeout 500 --trace $OUT/trace_ref --log $OUT/reference_run_unlimit400.log > $OUT/reference_run_unlimit400.json 2> $OUT/reference_run.err
 python tools/analyze_call_trace.py $OUT/trace_ref > $OUT/reference_call_trace.json 2>> $OUT/reference_run.err
 timeout 600 python tools/run_reference_slam.py --cache $C --synthetic 300 --limit30 --timeout 500 > $OUT/reference_run_limit30_300.json 2>> $OUT/reference_run.err
+# the same system with SURVEY 8(f)'s rows applied (oracle/make_refpy.py --fused): 400 frames unlimited with the call trace, 300 frames capped, 1500 frames unlimited (+ the untouched 1500)
+timeout 600 python tools/run_reference_slam.py --cache $C --synthetic 400 --fused --timeout 500 --trace $OUT/trace_fused > $OUT/reference_run_fused_unlimit400.json 2>> $OUT/reference_run.err
+python tools/analyze_call_trace.py $OUT/trace_fused > $OUT/reference_call_trace_fused.json 2>> $OUT/reference_run.err
+timeout 600 python tools/run_reference_slam.py --cache $C --synthetic 300 --limit30 --fused --timeout 500 > $OUT/reference_run_fused_limit30_300.json 2>> $OUT/reference_run.err
+timeout 900 python tools/run_reference_slam.py --cache $C --synthetic 1500 --timeout 700 > $OUT/reference_run_unlimit1500.json 2>> $OUT/reference_run.err
+timeout 900 python tools/run_reference_slam.py --cache $C --synthetic 1500 --fused --timeout 700 > $OUT/reference_run_fused_unlimit1500.json 2>> $OUT/reference_run.err
 timeout 400 python tools/run_reference_slam.py --synthetic 60 --shape tum --noise --limit30 --timeout 300 > $OUT/reference_run_tum_layout60.json 2>> $OUT/reference_run.err
 # map quality: PSNR / SSIM / depth-L1 against mapper iterations (device-resident loop, ONE captured graph), and the scale-semantics coverage experiment
 timeout 300 python tools/slam_demo.py 52 --iters 5 --prune-every 120 > $OUT/slam_demo.txt 2>&1
@@ -53,5 +62,5 @@ python tools/pmc_calibration.py report $OUT/calib_fetch $OUT/calib_write > $OUT/
 GSICP_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 20 --warmup 5 --repeats 3 --no-cpu-baseline > $OUT/bench_gpus2_gloo_one_gpu.json 2>> $OUT/bench.err
 # keep only the small files (the merge-back limit is 64 MiB)
 find $OUT -name '*.csv' -size +20M -delete
-rm -rf $OUT/trace_ref $OUT/calib_fetch $OUT/calib_write
+rm -rf $OUT/trace_ref $OUT/trace_fused $OUT/calib_fetch $OUT/calib_write
 ls -la $OUT | head -60

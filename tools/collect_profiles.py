@@ -51,10 +51,17 @@ def find(d, pattern):
 def last_json_line(path):
     if not os.path.exists(path):
         return None
-    for line in reversed(open(path).read().splitlines()):
-        if line.startswith("{"):
-            return json.loads(line)
-    return None
+    txt = open(path).read()
+    for line in reversed(txt.splitlines()):
+        if line.startswith("{") and line.rstrip().endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    try:
+        return json.loads(txt)          # an indented (multi-line) document
+    except ValueError:
+        return None
 
 
 def pmc_means(d):
@@ -79,14 +86,16 @@ def main():
     os.makedirs(dst, exist_ok=True)
     for name in ("bench", "bench_tum", "bench_basin", "bench_eager", "bench_under_rocprof", "reference_run_replica", "reference_run_tum_shaped",
                  "reference_run_unlimit400", "reference_run_limit30_300", "reference_run_tum_layout60", "bench_gpus2_gloo_one_gpu",
-                 "mfma_cov_experiment", "bench_mapper_only", "bench_tracker_only", "bench_force_collectives", "rccl_graph_probe"):
+                 "mfma_cov_experiment", "bench_mapper_only", "bench_tracker_only", "bench_force_collectives", "rccl_graph_probe",
+                 "bench_pair_survey", "bench_pair_basin", "tracker_vs_map", "reference_run_fused_unlimit400", "reference_run_fused_limit30_300",
+                 "reference_run_unlimit1500", "reference_run_fused_unlimit1500"):
         j = last_json_line(os.path.join(src, name + ".json"))
         if j is not None:
             json.dump(j, open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
             if "value" in j:
                 print(name, j["value"], j["unit"], j["ms_per_step"], "ms/step")
-    for name in ("slam_demo.txt", "reference_call_trace.json", "tracker_latency_survey.txt", "map_quality_curve.json", "scale_coverage.json",
-                 "pmc_calibration.json"):
+    for name in ("slam_demo.txt", "reference_call_trace.json", "reference_call_trace_fused.json", "tracker_latency_survey.txt", "tracker_latency_map300k.txt",
+                 "map_quality_curve.json", "scale_coverage.json", "pmc_calibration.json"):
         if os.path.exists(os.path.join(src, name)):
             import shutil
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
@@ -100,6 +109,10 @@ def main():
                     fh.write(",".join([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
                                        r["MaxNs"], r["StdDev"]]) + "\n")
             print("kernel stats" + suffix + ":", len(rows), "kernels")
+    reports = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "parity_report", "*.json")))
+    if reports:     # written by tests/test_raster_gpu.py (one file per scene / resolution / depth rule)
+        json.dump({os.path.basename(f)[:-5]: json.load(open(f)) for f in reports}, open(os.path.join(dst, f"{tag}_parity_report.json"), "w"), indent=1)
+        print("parity report:", len(reports), "cases")
     fetch, write = pmc_means(os.path.join(src, "fetch")), pmc_means(os.path.join(src, "write"))
     if fetch or write:
         traffic = {}
