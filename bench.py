@@ -243,6 +243,7 @@ def main():
     ap.add_argument("--tracker", choices=["steady", "pair"], default="steady",
                     help="tracker half of the headline step: `steady` = the steady-state configuration (frames of a trajectory against the MAP's trackable "
                          "Gaussians, keyframe cadence inside the timed region); `pair` = rounds 1-3's headline (one S-pair re-aligned against a frame-sized target; --pair)")
+    ap.add_argument("--mapper-inflight", type=int, default=2, help="mapper iterations the host may have in flight (queued graph launches) inside a timed block")
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the run of the reference's own two-process system (System FPS / ATE / PSNR keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (tracker-only, mapper-only, eager, drop-in reference loop)")
@@ -627,13 +628,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    inflight = [torch.cuda.Event() for _ in range(max(1, args.mapper_inflight))]
+
     def free_running_block(steps):
         """`steps` tracker frames on the worker thread and `steps` mapper iterations on this one, each half at its own pace, as the
         reference's two processes run [REF gs_icp_slam.py:121-131: Tracker.run and Mapper.run never wait for each other per frame]; the
         block ends when BOTH halves have finished all their steps."""
         jobs.put(steps)
-        for _ in range(steps):
+        for i in range(steps):
+            # bounded run-ahead, as in the fused in-system loop (gs_icp_slam_amd/refglue.py): a graph launch returns at once, so this thread could queue
+            # the whole block ahead of the GPU, and the tracker's tracking keyframe — whose hand-off is ordered after everything queued on the
+            # mapper's stream — would wait for all of it (measured: 15 ms stalls, 0.47 instead of 0.36 ms per step at 100-step blocks).  The
+            # reference's own mapper is throttled by its synchronous forward; here at most `--mapper-inflight` iterations are in flight.
+            ev = inflight[i % len(inflight)]
+            if i >= len(inflight):
+                ev.synchronize()
             loss, radii = mapper_iteration()
+            ev.record()
         T, idx, d2 = done.get()
         last.update(T=T, loss=loss, radii=radii)
 
@@ -1172,6 +1183,7 @@ def main():
                        "tracker_mapper_overlap": worker is not None,
                        "step_coupling": ("free-running: K tracker frames and K mapper iterations run concurrently, each at its own pace; the block ends when both are done"
                                          if free_running else ("lockstep: both halves joined after every step" if worker is not None else "one half after the other")),
+                       "mapper_iterations_in_flight": args.mapper_inflight,
                        "mapper_iteration": (("one hipGraph replay per iteration" + (" (tile all-gather + gradient all-reduce captured inside)" if (world > 1 or force_coll) else ""))
                                             if mg is not None else "eager launches from Python"),
                        "rccl_graph_probe": rccl_graph_probe,

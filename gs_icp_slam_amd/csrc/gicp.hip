@@ -1409,6 +1409,12 @@ __device__ inline double row_sum_last(double v) {
 __device__ inline void trace_stamp(unsigned long long* trace, int& n, int tag) {
     if (trace && blockIdx.x == 0 && threadIdx.x == 0 && n < 250) { trace[2 * n] = (unsigned long long)tag; trace[2 * n + 1] = wall_clock64(); ++n; }
 }
+// The fence-free grid barrier inside grid_sum rests on gfx94x / gfx950 behaviour: agent-scope atomic stores are written through to
+// the coherence point, vmcnt covers stores, and a thread re-reads after the barrier only what it wrote itself (the same s = gtid + k * gstride
+// mapping in linearize_points, the trial-cost loop and the final copy).  This file is built for gfx950 only; refuse anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "gicp.hip: the grid barrier of gicp_align_kernel assumes gfx942 / gfx950 memory behaviour (see grid_sum)"
+#endif
 template <int NV>
 __device__ inline void grid_sum(double* vals, AlignShared& sh, AlignSync* sy, unsigned& epoch, int tid, unsigned long long* trace = nullptr,
                                 int* trace_n = nullptr) {
@@ -2103,6 +2109,7 @@ struct gsicp_gicp {
     // by the first get_source_correspondence call of this object — the reference asks after every align [REF mp_Tracker.py:231] — so a caller
     // that never asks never pays for them
     bool spec_corr = false, spec_valid = false;
+    int spec_valid_unfetched = 0;          // aligns since the last get_source_correspondence (8 in a row switch the speculation off again)
     unsigned spec_seq = 0;
     int spec_m = 0;
     std::vector<float> h_stage;
@@ -2684,7 +2691,9 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
         GC(hipGetLastError());
         GC(hipEventRecord(e1, g->stream));
         g->dist_exact = false; g->spec_valid = false;
+        if (g->spec_corr && g->spec_valid_unfetched >= 8) g->spec_corr = false;   // the caller stopped asking: stop enqueueing the export
         if (g->spec_corr && attempt == 0 && s.n_track > 0) {       // the correspondence kernels ride behind the LM kernel (no host round trip)
+            ++g->spec_valid_unfetched;
             if (int rc_ = enqueue_correspondence_export(g, s.n_track, &g->spec_seq)) return rc_;
             g->spec_valid = true; g->spec_m = s.n_track;
         }
@@ -2717,6 +2726,7 @@ int gsicp_gicp_get_source_correspondence(gsicp_gicp* g, int32_t* idx, float* d2,
     const int n = g->src.n_track;
     const int m = n < cap ? n : cap;
     g->spec_corr = true;        // from now on align enqueues these kernels itself
+    g->spec_valid_unfetched = 0;
     if (m > 0) {   // page-locked staging, then a plain memcpy into the caller's arrays once the export has been published
         unsigned seq = g->spec_seq;
         if (!(g->spec_valid && g->spec_m >= m)) {
