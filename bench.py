@@ -911,8 +911,12 @@ def main():
                     torch.cuda.synchronize()
                     jobs.put((200, acc))
                     if mode == "co_tenant":
-                        for _ in range(200):
+                        for i_ in range(200):       # same bounded run-ahead as the timed blocks
+                            ev_ = inflight[i_ % len(inflight)]
+                            if i_ >= len(inflight):
+                                ev_.synchronize()
                             mapper_iteration()
+                            ev_.record()
                     done.get()
                     torch.cuda.synchronize()
                 n_f = acc.pop("frames")
