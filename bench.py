@@ -940,7 +940,7 @@ def main():
                 case.step()
             pr = {k: round(1e3 * ms / 20, 2) for k, (ms, c) in _lib.profile_read().items() if c > 0 and k.startswith("gicp")}
             _lib.profile_enable(False)
-            ang, mm = case.pose_error(T)
+            ang, mm = tuple(case.worst) if name == "steady" else case.pose_error(T)     # steady: worst over every frame tracked
             legs[f"tracker_only_{name}"] = {"frames_per_s": round(1.0 / s_frame, 1), "ms_per_frame": round(1e3 * s_frame, 4), "motion": motions[name],
                                             "lm_iterations": st["iterations"], "converged": st["converged"], "stage_us": pr,
                                             "pose_error_deg_mm": [round(ang, 4), round(mm, 3)], "correspondence_ratio": round(float((idx >= 0).mean()), 3)}

@@ -19,8 +19,9 @@ python $ROOT/bench.py --no-graph --no-cpu-baseline --no-legs > $OUT/bench_eager.
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- $BENCH > /dev/null 2> $OUT/fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- $BENCH > /dev/null 2> $OUT/write.err
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY \
-          --kernel-trace --output-format csv -d $OUT/sq -o p -- $BENCH > /dev/null 2> $OUT/sq.err
+# two passes of four counters (eight in one pass produced no counter file on this stack in round 4); tools/collect_profiles.py merges them
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/sq -o p -- $BENCH > /dev/null 2> $OUT/sq.err
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/sq2 -o p -- $BENCH > /dev/null 2> $OUT/sq2.err
 # each half ALONE under the kernel trace: per-kernel durations without the other half's co-tenancy (the iteration is the sum of these)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_mapper -o bench -- python $ROOT/bench.py --only mapper --steps 50 --warmup 5 --repeats 2 --no-cpu-baseline --no-legs > $OUT/bench_mapper_only_under_rocprof.json 2> $OUT/kt_mapper.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_tracker -o bench -- python $ROOT/bench.py --only tracker --steps 50 --warmup 5 --repeats 2 --no-cpu-baseline --no-legs > $OUT/bench_tracker_only_under_rocprof.json 2> $OUT/kt_tracker.err

@@ -127,6 +127,8 @@ def main():
         json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
         print("traffic:", {k: (v["fetch_bytes"] + v["write_bytes"]) // 1000000 for k, v in traffic.items()}, "MB")
     sq = pmc_means(os.path.join(src, "sq"))
+    for k_, v_ in pmc_means(os.path.join(src, "sq2")).items():      # second counter pass (tools/capture_profiles.sh)
+        sq.setdefault(k_, {}).update(v_)
     if sq:
         cols = sorted({c for v in sq.values() for c in v})
         with open(os.path.join(dst, f"{tag}_rocprofv3_pmc_sq.csv"), "w") as fh:
