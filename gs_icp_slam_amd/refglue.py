@@ -150,6 +150,17 @@ def fused_mapping_iteration(mapper, viewpoint_cam, gt_image, gt_depth_image):
     # Bounded run-ahead: a graph launch returns at once, so this loop could queue thousands of iterations ahead of the GPU — and the TRACKER process's
     # small kernels would wait behind them (measured without the bound: tracker 17 ms per frame, System FPS 66 instead of 167).  The reference's own
     # iteration is throttled by its synchronous forward; here at most `GSICP_FUSED_INFLIGHT` (2) replays are in flight.
+    # diagnostic (GSICP_FUSED_MIN_PERIOD_MS): hold the mapper to a minimum period per iteration, e.g. the untouched loop's 16.8 ms — separates
+    # "the fused iteration computes something else" from "a mapper that iterates 30x more often changes the map the tracker aligns against"
+    period = float(os.environ.get("GSICP_FUSED_MIN_PERIOD_MS", "0"))
+    if period > 0:
+        import time
+        t_prev = gm.__dict__.get("_gsicp_t_prev")
+        if t_prev is not None:
+            wait = t_prev + 1e-3 * period - time.perf_counter()
+            if wait > 0:
+                time.sleep(wait)
+        gm.__dict__["_gsicp_t_prev"] = time.perf_counter()
     ring = gm.__dict__.setdefault("_gsicp_ring", [torch.cuda.Event() for _ in range(max(1, int(os.environ.get("GSICP_FUSED_INFLIGHT", "2"))))])
     slot = mapper.train_iter % len(ring)
     if mapper.train_iter >= len(ring):

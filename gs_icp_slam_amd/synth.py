@@ -206,7 +206,7 @@ def render_frame(cfg, pose_c2w, noise_seed=None, holes=0.0):
     return rgb, d16
 
 
-def trajectory(n_frames, step=None, start=None):
+def trajectory(n_frames, step=None, start=None, speed=1.0, jitter=0.0, jitter_seed=0):
     """Camera-to-world poses of a smooth synthetic sequence of ANY length that stays inside the analytic room: the camera rides a tilted
     ellipse in the cuboid-free half of the room (|x - c_x| <= 0.75 m, |z - c_z| <= 0.55 m) while its yaw and pitch sway slowly, so that floor,
     walls and the interior cuboids stay in view.  Per frame at most ~7 mm and ~0.25 deg — the order of Replica's inter-frame motion.
@@ -216,11 +216,18 @@ def trajectory(n_frames, step=None, start=None):
         for _ in range(n_frames - 1):
             poses.append(poses[-1] @ step)
         return poses
+    # `speed` scales the motion per frame (2 = 14 mm / 0.5 deg: a fast hand-held sweep); `jitter` adds a zero-mean hand tremor per frame
+    # (metres of translation; the same number x 10 in degrees of rotation about every axis), deterministic in `jitter_seed`
+    rng = np.random.default_rng(jitter_seed) if jitter > 0 else None
     poses = []
     for k in range(n_frames):
-        th = 0.009 * k
-        pos = (-0.1 + 0.75 * math.cos(th), -0.1 + 0.12 * math.sin(2.0 * th), -0.9 + 0.55 * math.sin(th))
-        poses.append(se3((10.0 + 6.0 * math.sin(1.1 * th), 30.0 + 35.0 * math.sin(0.7 * th), 0.0), pos))
+        th = 0.009 * k * speed
+        pos = np.array([-0.1 + 0.75 * math.cos(th), -0.1 + 0.12 * math.sin(2.0 * th), -0.9 + 0.55 * math.sin(th)])
+        ang = np.array([10.0 + 6.0 * math.sin(1.1 * th), 30.0 + 35.0 * math.sin(0.7 * th), 0.0])
+        if rng is not None and k > 0:
+            pos = pos + rng.normal(0.0, jitter, 3)
+            ang = ang + rng.normal(0.0, 10.0 * jitter, 3)
+        poses.append(se3(tuple(ang), tuple(pos)))
     return poses
 
 

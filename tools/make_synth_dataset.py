@@ -75,11 +75,11 @@ def _write_tum_lists(out, poses):
                 fh.write(tum_stamp(i, sub * TUM_DT / 3.0) + " " + " ".join("%.9f" % v for v in list(t) + list(q)) + "\n")
 
 
-def write_dataset(out, frames=30, shape="replica", noise=False, quality=95, layout="replica"):
+def write_dataset(out, frames=30, shape="replica", noise=False, quality=95, layout="replica", speed=1.0, jitter=0.0):
     cfg = synth.REPLICA if shape == "replica" else synth.TUM
     for sub in (("rgb", "depth") if layout == "tum" else ("images", "depth_images")):
         os.makedirs(os.path.join(out, sub), exist_ok=True)
-    poses = synth.trajectory(frames)
+    poses = synth.trajectory(frames, speed=speed, jitter=jitter)
     jobs = [(out, shape, i, pose, noise, quality, layout) for i, pose in enumerate(poses)]
     workers = max(1, min(16, (os.cpu_count() or 2) // 2, frames))
     if workers > 1:   # the CPU ray-caster costs ~1 s per 1200x680 frame

@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--cache", default=None, help="directory that keeps synthetic sequences between runs: a run of N frames re-uses (symlinks) the "
                     "first N frames of a longer cached sequence of the same kind instead of ray-casting again")
     ap.add_argument("--noise", action="store_true")
+    ap.add_argument("--speed", type=float, default=1.0, help="synthetic sequence: motion per frame relative to the default (~7 mm / 0.25 deg); 2 = a fast hand-held sweep")
+    ap.add_argument("--jitter", type=float, default=0.0, help="synthetic sequence: hand tremor per frame (sigma in metres of translation, x 10 in degrees of rotation)")
     ap.add_argument("--limit30", action="store_true", help="run gs_icp_slam.py (tracker capped at 30 FPS [REF mp_Tracker.py:323]) instead of the _unlimit variant")
     ap.add_argument("--timeout", type=float, default=600.0)
     ap.add_argument("--trace", default=None, help="directory for the drop-in call trace (GSICP_CALL_TRACE): one file per process")
@@ -164,7 +166,7 @@ def main():
         tmp = tempfile.mkdtemp(prefix="gsicp_synth_")
         cached = None
         if a.cache and layout == "replica":
-            kind = f"{a.shape}_{'noisy' if a.noise else 'clean'}_"
+            kind = f"{a.shape}_{'noisy' if a.noise else 'clean'}_s{a.speed:g}_j{a.jitter:g}_"
             os.makedirs(a.cache, exist_ok=True)
             have = sorted((int(d[len(kind):]), d) for d in os.listdir(a.cache) if d.startswith(kind) and d[len(kind):].isdigit())
             fit = [d for n, d in have if n >= a.synthetic]
@@ -172,10 +174,10 @@ def main():
                 cached = os.path.join(a.cache, fit[0])
             else:
                 cached = os.path.join(a.cache, kind + str(a.synthetic))
-                write_dataset(cached, a.synthetic, a.shape, a.noise, layout=layout)
+                write_dataset(cached, a.synthetic, a.shape, a.noise, layout=layout, speed=a.speed, jitter=a.jitter)
             subset_dataset(cached, a.synthetic, tmp)
         else:
-            write_dataset(tmp, a.synthetic, a.shape, a.noise, layout=layout)
+            write_dataset(tmp, a.synthetic, a.shape, a.noise, layout=layout, speed=a.speed, jitter=a.jitter)
         a.dataset, a.config = tmp, os.path.join(tmp, "caminfo.txt")
         flags = flags_for(a.config, a.shape)
     if not a.dataset or not os.path.isdir(a.dataset):
@@ -187,7 +189,8 @@ def main():
     res, log = run(ref, a.dataset, a.config, out_dir, unlimit=not a.limit30, timeout=a.timeout, flags=flags, trace_dir=a.trace, omp_threads=a.omp_threads,
                    compiled_pygicp=a.compiled_pygicp, compiled_ext=a.compiled_ext)
     res.update(status="measured" if res["returncode"] == 0 and res["system_fps"] is not None else "failed", dataset=a.dataset,
-               data="synthetic" if a.synthetic else "real", frames=a.synthetic or None, dataset_type=dataset_type(a.config),
+               data="synthetic" if a.synthetic else "real", frames=a.synthetic or None,
+               synthetic_motion=(dict(speed=a.speed, jitter_m=a.jitter, sensor_noise=bool(a.noise)) if a.synthetic else None), dataset_type=dataset_type(a.config),
                flags=flags or flags_for(a.config), entry="gs_icp_slam.py (30 FPS cap)" if a.limit30 else "gs_icp_slam_unlimit.py",
                variant="FUSED: INTEGRATION.md 6-8's edits applied by oracle/make_refpy.py --fused" if a.fused else "untouched reference files")
     if a.log:
