@@ -78,6 +78,33 @@ def _fuse_tracker(tree):
     return edits + _append_patch(tree, "patch_tracker", "Tracker")
 
 
+def _lift_mapping_block(tree, src, out_dir):
+    """The reference's OWN training statements [REF mp_Mapper.py:219-262] as a callable: the slice between `self.training=True` and
+    `self.training = False` of Mapper.mapping, wrapped as `reference_training_block(self, viewpoint_cam, gt_image, gt_depth_image, new_keyframe=False)`
+    under the module's own imports, byte-compiled into the PLAIN tree (`_lifted_mapping_block.pyc`).  Test infrastructure: lets a GPU test run the
+    reference's iteration and the fused one side by side on the box where only byte-code exists (tests/refglue_iteration_probe.py)."""
+    block = None
+    for node in ast.walk(tree):
+        body = getattr(node, "body", None)
+        if not isinstance(body, list):
+            continue
+        i0 = next((i for i, st in enumerate(body) if _is_self_training_assign(st, True)), None)
+        i1 = next((i for i, st in enumerate(body) if _is_self_training_assign(st, False)), None)
+        if i0 is not None and i1 is not None and i1 > i0:
+            block = body[i0 + 1:i1]
+    if block is None:
+        raise RuntimeError("make_refpy: Mapper.mapping's training block not found")
+    imports = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    ret = ast.Return(ast.Tuple(elts=[ast.Name(id=n, ctx=ast.Load()) for n in ("loss", "image", "depth_image")], ctx=ast.Load()))
+    fn = ast.FunctionDef(name="reference_training_block",
+                         args=ast.arguments(posonlyargs=[], args=[ast.arg(arg=a) for a in ("self", "viewpoint_cam", "gt_image", "gt_depth_image", "new_keyframe")],
+                                            kwonlyargs=[], kw_defaults=[], defaults=[ast.Constant(False)]),
+                         body=list(block) + [ret], decorator_list=[])
+    mod = ast.Module(body=imports + [fn], type_ignores=[])
+    _compile_tree(mod, src, os.path.join(out_dir, "_lifted_mapping_block.pyc"), os.path.join("<reference, lifted>", "mp_Mapper.py"))
+    return len(block)
+
+
 FUSED_EDITS = {
     "mp_Mapper.py": _fuse_mapper,
     "mp_Tracker.py": _fuse_tracker,
@@ -118,6 +145,8 @@ def main_fused():
             _compile_tree(tree, src, dst, dfile)
         else:
             py_compile.compile(src, cfile=dst, dfile=dfile, doraise=True)
+    with open(os.path.join(REF, "mp_Mapper.py"), "rb") as fh:       # the untouched training statements as a callable, into the PLAIN tree
+        report["_lifted_mapping_block (plain tree)"] = _lift_mapping_block(ast.parse(fh.read()), os.path.join(REF, "mp_Mapper.py"), OUT)
     missing = [r for r in FUSED_EDITS if r not in report]
     if missing:
         raise RuntimeError(f"make_refpy --fused: files to edit not found: {missing}")

@@ -92,3 +92,69 @@ def test_fused_rows_inside_the_reference_two_process_system():
     assert fm["graph_captures"] == 1, fm                       # keyframe growth and pruning never re-captured
     assert fm["median_ms_per_iteration"] < 1.2, fm             # 16.8 ms in the untouched system
     assert res["psnr"] > 33.0 and res["ssim"] > 0.95, (res["psnr"], res["ssim"])     # untouched, same run: 33.8 dB / 0.971
+
+
+def test_fused_gaussian_model_equals_the_reference_methods(tmp_path):
+    """Row (f4) PINNED IN-SYSTEM: the store-backed `GaussianModel` methods that `oracle/make_refpy.py --fused` patches in
+    (gs_icp_slam_amd/refglue.py: create_from_pcd2_tensor, add_from_pcd2_tensor, training_setup, update_learning_rate, prune_large_and_transparent,
+    get_trackable_gaussians_tensor) against the REFERENCE'S OWN methods, both executed here from their byte-code trees on the same seeded inputs
+    (tests/refglue_probe.py): every parameter tensor, every activated getter, the trackable mask, the learning rates and the exported target are
+    identical bit for bit after the first keyframe, a tracking keyframe, a mapping keyframe, a prune and a keyframe after the prune."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from tools.run_reference_slam import find_reference
+    plain, fused = os.path.join(ROOT, "oracle", "_ref", "refpy"), find_reference(fused=True)
+    if fused is None or not os.path.exists(os.path.join(plain, "mp_Mapper.pyc")):
+        pytest.skip("oracle/_ref/refpy{,_fused} not built")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests", "refstubs")]), GSICP_FUSED_DEVICE_TARGETS="1")
+    outs = []
+    for tree in (plain, fused):
+        out = str(tmp_path / (os.path.basename(tree) + ".npz"))
+        r = subprocess.run([sys.executable, "-W", "ignore", os.path.join(ROOT, "tests", "refglue_probe.py"), tree, out], env=env, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0 and "probe ok" in r.stdout, r.stderr[-3000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        assert a[k].shape == b[k].shape, (k, a[k].shape, b[k].shape)
+        assert np.array_equal(a[k], b[k]), f"{k}: max |diff| {np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() if a[k].dtype.kind == 'f' else 'n/a'}"
+    assert a["pruned._xyz"].shape[0] < a["mapping_keyframe._xyz"].shape[0]        # the prune removed something
+
+
+def test_fused_iteration_tracks_the_references_own_statements(tmp_path):
+    """Row (f1) AGAINST THE REFERENCE'S OWN CODE: twelve mapper iterations over three keyframe views of one first-keyframe map, once through the
+    training statements of `Mapper.mapping` themselves [REF mp_Mapper.py:219-262] — lifted unmodified into a callable at build time (byte-code in
+    the plain tree: render_3 on the drop-in rasteriser, the torch l1 / ssim chain, loss.backward(), torch.optim.Adam over the reference's
+    GaussianModel) — and once through `refglue.fused_mapping_iteration` over the patched GaussianModel (one hipGraph replay per iteration).
+    Same losses (1e-4 relative: fp32 evaluation order of the loss) and the same trajectory in parameter space: per tensor, the distance between
+    the two end states is a small fraction of the distance either travelled (Adam divides by sqrt(v): where a gradient is at rounding level the
+    two chains may step in opposite directions, so single elements are not held to the bar, the norm is)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from tools.run_reference_slam import find_reference
+    plain, fused = os.path.join(ROOT, "oracle", "_ref", "refpy"), find_reference(fused=True)
+    if fused is None or not os.path.exists(os.path.join(plain, "_lifted_mapping_block.pyc")):
+        pytest.skip("oracle/_ref/refpy{,_fused} (with the lifted training block) not built")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests", "refstubs")]))
+    res = {}
+    for mode, tree, n in (("ref", plain, 12), ("fused", fused, 12), ("ref0", plain, 0)):
+        out = str(tmp_path / (mode + ".npz"))
+        r = subprocess.run([sys.executable, "-W", "ignore", os.path.join(ROOT, "tests", "refglue_iteration_probe.py"), tree, mode.rstrip("0"), out, str(n)],
+                           env=env, capture_output=True, text=True, timeout=400)
+        assert r.returncode == 0 and "probe ok" in r.stdout, r.stderr[-3000:]
+        res[mode] = np.load(out)
+    a, b, start = res["ref"], res["fused"], res["ref0"]
+    print("losses reference:", a["losses"], "\nlosses fused:    ", b["losses"])
+    np.testing.assert_allclose(b["losses"], a["losses"], rtol=1e-4, atol=1e-6)
+    assert a["losses"][-1] < a["losses"][0]
+    stats = {}
+    for k in ("xyz", "f_dc", "opacity", "scaling", "rotation"):
+        move = np.abs(a[k] - start[k]).astype(np.float64)
+        diff = np.abs(a[k] - b[k]).astype(np.float64)
+        stats[k] = dict(travelled=float(np.linalg.norm(move)), apart=float(np.linalg.norm(diff)), largest_move=float(move.max()),
+                        within_1pct=float((diff <= 1e-2 * move.max()).mean()), within_10pct=float((diff <= 1e-1 * move.max()).mean()), worst=float(diff.max()))
+        print(k, stats[k])
+    for k, s_ in stats.items():
+        assert s_["travelled"] > 0 and s_["apart"] <= 1e-2 * s_["travelled"], (k, s_)      # measured: 1e-6 .. 5e-5 of the distance travelled, xyz 1.7e-3
+        assert s_["within_1pct"] >= 0.999, (k, s_)       # Adam steps by lr x a sign-like ratio: an element whose gradient sits at rounding level may go the other way
