@@ -17,7 +17,7 @@ With N > 1 GPUs the mapper's tiles are sharded across ranks (strong scaling; gs_
 replica on every rank (it does not shard — DESIGN.md).
 
 Timing: `--repeats` back-to-back blocks, each EXACTLY `--steps` steps bracketed by barrier + torch.cuda.synchronize() on both sides
-(max over ranks); `value` is the median block.  Rank 0 prints ONE JSON line with `roofline` (SURVEY §8(d) byte model over hipEvent kernel
+(max over ranks); `value` is all timed steps over all timed seconds (the mean block).  Rank 0 prints ONE JSON line with `roofline` (SURVEY §8(d) byte model over hipEvent kernel
 time), `cpu_baseline` (the OpenMP GICP oracle on this host's cores) and `legs`: each half alone, both tracker pairs, the mapper iteration
 launched eagerly, and `dropin_reference_loop` — what the UNMODIFIED mp_Mapper.py executes on top of the drop-in rasteriser (torch
 activations, synchronous forward, torch l1/ssim, torch.optim.Adam).
@@ -233,7 +233,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median block is reported")
+    ap.add_argument("--repeats", type=int, default=5, help="minimum number of timed blocks of --steps steps (more are run until --min-seconds); the mean block is reported")
     ap.add_argument("--gaussians", type=int, default=300_000)
     ap.add_argument("--res", choices=["replica", "tum"], default="replica")
     ap.add_argument("--pair", choices=["survey", "basin"], default="survey",
@@ -679,7 +679,7 @@ def main():
         step()
     free_running = worker is not None and not args.lockstep
     blocks = timed_blocks(step, args.steps, max(1, args.repeats), whole=free_running_block if free_running else None, min_seconds=args.min_seconds)
-    dt = statistics.median(blocks)
+    dt = sum(blocks) / len(blocks)     # every timed step over every timed second: blocks with a tracking keyframe (every 40th frame) count at their share
     if mg is not None and (mg.overflowed() or mg.skipped_steps() > 0):
         raise RuntimeError(f"capacity overflowed during the timed region: R = {int(mg.num_rendered.item())} (capacity {mg.capacity}), "
                            f"{mg.skipped_steps()} optimiser steps skipped")
@@ -760,7 +760,7 @@ def main():
         for _ in range(max(3, args.warmup // 2)):
             kf_step()
         kf_blocks = timed_blocks(kf_step, args.steps, max(1, args.repeats), whole=kf_free_block if (free_running and args.only is None) else None)
-        dtk = statistics.median(kf_blocks)
+        dtk = sum(kf_blocks) / len(kf_blocks)
         if use_graph and (mgk.overflowed() or mgk.skipped_steps() > 0):
             raise RuntimeError("keyframe-parallel leg: capacity overflowed during the timed region")
         kf_leg = {"mode": "keyframes", "value": round(world * args.steps / dtk, 3), "unit": "frames/s (N tracker-frame replicas + N mapper views per step)",
@@ -1174,7 +1174,7 @@ def main():
             "data": "synthetic",
             "repeats": len(headline_blocks), "timed_seconds": round(sum(headline_blocks), 3),
             "block_ms_per_step": [round(1e3 * b_ / args.steps, 4) for b_ in headline_blocks[:40]],
-            "block_ms_per_step_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "statistic": "median block",
+            "block_ms_per_step_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "statistic": "mean over the timed blocks (all timed steps / all timed seconds)",
             # BASELINE's metric as SURVEY 8(d) defines it — what the reference ITSELF prints when its unmodified two-process system runs on the drop-ins
             # (400-frame synthetic Replica-layout sequence, gs_icp_slam_unlimit.py, replica.sh's flags); the whole record is legs.reference_system_run
             "system_fps": rr.get("system_fps"), "ate_cm": rr.get("ate_rmse_cm"), "ate_true_rmse_cm": rr.get("ate_true_rmse_cm"), "psnr": rr.get("psnr"),

@@ -412,13 +412,54 @@ struct KnnGrid {
     unsigned ring_hist[5];   // diagnostics: queries settled by whole-grid coverage [0], after ring 1 / 2 [1], [2], by the full scan [4]
 };
 
-// single workgroup: bounding box -> grid parameters, and clears the cell counters
-__global__ __launch_bounds__(1024) void knn_grid_params_kernel(int n, const float4* __restrict__ pts, float h_area, float h_vol,
-                                                               KnnGrid* __restrict__ gp, unsigned* __restrict__ cell_count) {
-    __shared__ float s_lo[3][16], s_hi[3][16];
+// grid parameters from the bounding box (one definition for every builder below: same arithmetic, same grid)
+__device__ inline KnnGrid knn_grid_from_box(const float L[3], const float E[3], int n, float h_area, float h_vol) {
+    const float emax = fmaxf(fmaxf(E[0], E[1]), fmaxf(E[2], 1e-6f));
+    // depth-camera clouds are surfaces: spacing ~ sqrt(area / n); 20 neighbours sit within ~2.5 spacings, and a
+    // cell edge of 4 leaves room for the density to vary across the cloud before a second ring is needed.  The volume term covers
+    // genuinely volumetric clouds.  Either way the search below is exact; h only decides how much it scans.
+    const float area = E[0] * E[1] + E[1] * E[2] + E[0] * E[2];
+    const float vol = fmaxf(E[0], 1e-3f * emax) * fmaxf(E[1], 1e-3f * emax) * fmaxf(E[2], 1e-3f * emax);
+    float h = fmaxf(h_area * sqrtf(area / (float)n), h_vol * cbrtf(vol / (float)n));
+    h = fmaxf(h, emax * (1.f / 1024.f));
+    int nx, ny, nz;
+    for (;;) {
+        nx = (int)(E[0] / h) + 1; ny = (int)(E[1] / h) + 1; nz = (int)(E[2] / h) + 1;
+        if ((long long)nx * ny * nz <= KNN_MAX_CELLS) break;
+        h *= 1.25f;
+    }
+    KnnGrid g;
+    g.ox = L[0]; g.oy = L[1]; g.oz = L[2]; g.h = h; g.inv_h = 1.f / h;
+    g.nx = nx; g.ny = ny; g.nz = nz; g.ncells = nx * ny * nz;
+    for (int i = 0; i < 5; ++i) g.ring_hist[i] = 0u;
+    return g;
+}
+
+// Clouds beyond KNN_FUSED_MAX_N points (a map's trackable Gaussians at every tracking keyframe, distCUDA2's new keyframe points, large
+// frames): the build as SIX chip-wide launches — partial boxes, parameters + counter reset, count, tile sums, scan, fill.  The scratch of
+// the build (partial boxes, tile sums) follows the KnnGrid record in the same allocation (KNN_PARAM_SLOTS records); the search kernels
+// only ever see its first record.  Rounds 1-3 ran the box and the scan as ONE workgroup each (52 + 125 us at 1.5e5 points, 350 us of box
+// alone at 1e6): half of a tracking keyframe's index build.
+constexpr int KNN_BOX_WGS = 256;             // partial boxes
+constexpr int KNN_SCAN_TILE = 4096;          // counters per scan workgroup (1024 threads x 4)
+constexpr int KNN_SCAN_TILES = KNN_MAX_CELLS / KNN_SCAN_TILE + 1;   // covers counter index ncells (= 0: its exclusive prefix is the total)
+constexpr int KNN_CELL_SLOTS = KNN_SCAN_TILES * KNN_SCAN_TILE;      // counter arrays are whole tiles (aligned 16-byte loads of the last one)
+constexpr int KNN_PARAM_WGS = 32;
+struct KnnBuild {
+    KnnGrid g;
+    unsigned tile_sum[KNN_SCAN_TILES + 3];
+    float part[6][KNN_BOX_WGS];              // lo x/y/z, hi x/y/z per workgroup of knn_box_kernel
+};
+constexpr int KNN_PARAM_SLOTS = (int)((sizeof(KnnBuild) + sizeof(KnnGrid) - 1) / sizeof(KnnGrid));
+
+__global__ __launch_bounds__(256) void knn_box_kernel(int n, const float4* __restrict__ pts, KnnGrid* __restrict__ gp) {
+    KnnBuild* const kb = (KnnBuild*)gp;
+    __shared__ float s_v[6][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = tid; i < n; i += 1024) {
+    const int stride = (int)gridDim.x * 256;
+#pragma unroll 4
+    for (int i = (int)blockIdx.x * 256 + tid; i < n; i += stride) {
         const float4 p = pts[i];
         lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
         hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
@@ -430,38 +471,45 @@ __global__ __launch_bounds__(1024) void knn_grid_params_kernel(int n, const floa
             lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
             hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
         }
-        if (lane == 0) { s_lo[d][wave] = lo[d]; s_hi[d][wave] = hi[d]; }
+        if (lane == 0) { s_v[d][wave] = lo[d]; s_v[3 + d][wave] = hi[d]; }
     }
     __syncthreads();
+    if (tid < 6) {
+        const float a = s_v[tid][0], b = s_v[tid][1], c = s_v[tid][2], e = s_v[tid][3];
+        kb->part[tid][blockIdx.x] = tid < 3 ? fminf(fminf(a, b), fminf(c, e)) : fmaxf(fmaxf(a, b), fmaxf(c, e));
+    }
+}
+// every workgroup folds the partial boxes (minima and maxima: any order gives the same bits), derives the same parameters and clears its
+// share of the cell counters [0, ncells]; workgroup 0 publishes the record
+__global__ __launch_bounds__(1024) void knn_grid_params_kernel(int n, int n_parts, float h_area, float h_vol, KnnGrid* __restrict__ gp,
+                                                               unsigned* __restrict__ cell_count) {
+    const KnnBuild* const kb = (const KnnBuild*)gp;
+    __shared__ float s_v[6][16];
     __shared__ int s_ncells;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        float v = d < 3 ? FLT_MAX : -FLT_MAX;
+        for (int b = tid; b < n_parts; b += 1024) v = d < 3 ? fminf(v, kb->part[d][b]) : fmaxf(v, kb->part[d][b]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = d < 3 ? fminf(v, __shfl_xor(v, off, 64)) : fmaxf(v, __shfl_xor(v, off, 64));
+        if (lane == 0) s_v[d][wave] = v;
+    }
+    __syncthreads();
     if (tid == 0) {
         float L[3], E[3];
         for (int d = 0; d < 3; ++d) {
-            float l = s_lo[d][0], u = s_hi[d][0];
-            for (int w = 1; w < 16; ++w) { l = fminf(l, s_lo[d][w]); u = fmaxf(u, s_hi[d][w]); }
+            float l = s_v[d][0], u = s_v[3 + d][0];
+            for (int w = 1; w < 16; ++w) { l = fminf(l, s_v[d][w]); u = fmaxf(u, s_v[3 + d][w]); }
             L[d] = l; E[d] = fmaxf(u - l, 0.f);
         }
-        const float emax = fmaxf(fmaxf(E[0], E[1]), fmaxf(E[2], 1e-6f));
-        // depth-camera clouds are surfaces: spacing ~ sqrt(area / n); 20 neighbours sit within ~2.5 spacings, and a
-        // cell edge of 4 leaves room for the density to vary across the cloud before a second ring is needed.  The volume term covers
-        // genuinely volumetric clouds.  Either way the search below is exact; h only decides how much it scans.
-        const float area = E[0] * E[1] + E[1] * E[2] + E[0] * E[2];
-        const float vol = fmaxf(E[0], 1e-3f * emax) * fmaxf(E[1], 1e-3f * emax) * fmaxf(E[2], 1e-3f * emax);
-        float h = fmaxf(h_area * sqrtf(area / (float)n), h_vol * cbrtf(vol / (float)n));
-        h = fmaxf(h, emax * (1.f / 1024.f));
-        int nx, ny, nz;
-        for (;;) {
-            nx = (int)(E[0] / h) + 1; ny = (int)(E[1] / h) + 1; nz = (int)(E[2] / h) + 1;
-            if ((long long)nx * ny * nz <= KNN_MAX_CELLS) break;
-            h *= 1.25f;
-        }
-        gp->ox = L[0]; gp->oy = L[1]; gp->oz = L[2]; gp->h = h; gp->inv_h = 1.f / h;
-        gp->nx = nx; gp->ny = ny; gp->nz = nz; gp->ncells = nx * ny * nz;
-        for (int i = 0; i < 5; ++i) gp->ring_hist[i] = 0u;
-        s_ncells = nx * ny * nz;
+        const KnnGrid g = knn_grid_from_box(L, E, n, h_area, h_vol);
+        if (blockIdx.x == 0) *gp = g;
+        s_ncells = g.ncells;
     }
     __syncthreads();
-    for (int c = tid; c <= s_ncells; c += 1024) cell_count[c] = 0u;
+    const int ncells = s_ncells;
+    for (int c = (int)blockIdx.x * 1024 + tid; c <= ncells; c += (int)gridDim.x * 1024) cell_count[c] = 0u;
 }
 __device__ inline void knn_cell_of(const KnnGrid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
     cx = (int)((x - g.ox) * g.inv_h); cy = (int)((y - g.oy) * g.inv_h); cz = (int)((z - g.oz) * g.inv_h);
@@ -481,31 +529,68 @@ __global__ __launch_bounds__(256) void knn_count_kernel(int n, const float4* __r
     cell_of[i] = c;
     atomicAdd(&cell_count[c], 1u);
 }
-// single workgroup: exclusive scan of the cell counts -> cell_start[0..ncells]; cell_fill (cursor) = copy of cell_start
+// exclusive scan of the cell counts -> cell_start[0..ncells]; cell_fill (cursor) = copy of cell_start.  One workgroup per tile of 4 096
+// counters: tile sums, then every tile adds the sums of the tiles before it (<= 64 values) to its own in-tile scan.
+__device__ inline uint4 knn_load_counts(const unsigned* __restrict__ cell_count, int base, int ncells) {
+    uint4 v = *(const uint4*)(cell_count + base);     // whole tiles are allocated; entries beyond ncells are not initialised: masked here
+    if (base + 0 > ncells) v.x = 0u;
+    if (base + 1 > ncells) v.y = 0u;
+    if (base + 2 > ncells) v.z = 0u;
+    if (base + 3 > ncells) v.w = 0u;
+    return v;
+}
+__global__ __launch_bounds__(1024) void knn_scan_sums_kernel(KnnGrid* __restrict__ gp, const unsigned* __restrict__ cell_count) {
+    KnnBuild* const kb = (KnnBuild*)gp;
+    __shared__ unsigned s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncells = gp->ncells;
+    const int base = (int)blockIdx.x * KNN_SCAN_TILE + 4 * tid;
+    unsigned sum = 0u;
+    if ((int)blockIdx.x * KNN_SCAN_TILE <= ncells) { const uint4 v = knn_load_counts(cell_count, base, ncells); sum = (v.x + v.y) + (v.z + v.w); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += (unsigned)__shfl_xor((int)sum, off, 64);
+    if (lane == 0) s_w[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned t = 0u;
+        for (int w = 0; w < 16; ++w) t += s_w[w];
+        kb->tile_sum[blockIdx.x] = t;
+    }
+}
 __global__ __launch_bounds__(1024) void knn_scan_kernel(const KnnGrid* __restrict__ gp, const unsigned* __restrict__ cell_count,
                                                         unsigned* __restrict__ cell_start, unsigned* __restrict__ cell_fill) {
-    __shared__ unsigned s_part[1024];
-    const int tid = threadIdx.x;
+    const KnnBuild* const kb = (const KnnBuild*)gp;
+    __shared__ unsigned s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ncells = gp->ncells;
-    const int per = (ncells + 1023) / 1024;
-    const int lo = tid * per, hi = (lo + per) < ncells ? (lo + per) : ncells;
-    unsigned sum = 0;
-    for (int c = lo; c < hi; ++c) sum += cell_count[c];
-    s_part[tid] = sum;
+    if ((int)blockIdx.x * KNN_SCAN_TILE > ncells) return;       // workgroup-uniform
+    unsigned before = 0u;                                       // counters of the tiles in front of this one
+    for (int b = lane; b < (int)blockIdx.x; b += 64) before += kb->tile_sum[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += (unsigned)__shfl_xor((int)before, off, 64);
+    const int base = (int)blockIdx.x * KNN_SCAN_TILE + 4 * tid;
+    const uint4 v = knn_load_counts(cell_count, base, ncells);
+    const unsigned mine = (v.x + v.y) + (v.z + v.w);
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
-        const unsigned v = tid >= off ? s_part[tid - off] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    unsigned run = before + incl - mine;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) if (w < wave) run += s_w[w];
+    const unsigned r0 = run, r1 = r0 + v.x, r2 = r1 + v.y, r3 = r2 + v.z;
+    if (base + 3 <= ncells) {
+        *(uint4*)(cell_start + base) = make_uint4(r0, r1, r2, r3);
+        *(uint4*)(cell_fill + base) = make_uint4(r0, r1, r2, r3);
+    } else {
+        if (base + 0 <= ncells) { cell_start[base + 0] = r0; cell_fill[base + 0] = r0; }
+        if (base + 1 <= ncells) { cell_start[base + 1] = r1; cell_fill[base + 1] = r1; }
+        if (base + 2 <= ncells) { cell_start[base + 2] = r2; cell_fill[base + 2] = r2; }
     }
-    unsigned run = s_part[tid] - sum;
-    for (int c = lo; c < hi; ++c) {
-        const unsigned cnt = cell_count[c];
-        cell_start[c] = run; cell_fill[c] = run;
-        run += cnt;
-    }
-    if (tid == 1023) cell_start[ncells] = s_part[1023];
 }
 __global__ __launch_bounds__(256) void knn_fill_kernel(int n, const float4* __restrict__ pts, const int* __restrict__ cell_of,
                                                        unsigned* __restrict__ cell_fill, float4* __restrict__ sorted) {
@@ -514,6 +599,19 @@ __global__ __launch_bounds__(256) void knn_fill_kernel(int n, const float4* __re
     float4 p = pts[i];
     p.w = __int_as_float(i);
     sorted[atomicAdd(&cell_fill[cell_of[i]], 1u)] = p;
+}
+
+// the multi-launch build of the uniform grid over `pts` (see KnnBuild): gp must hold KNN_PARAM_SLOTS records, the counter arrays KNN_CELL_SLOTS
+inline void enqueue_knn_grid_build(hipStream_t stream, int n, const float4* pts, float h_area, float h_vol, KnnGrid* gp, int* cell_of,
+                                   unsigned* cell_count, unsigned* cell_start, unsigned* cell_fill, float4* sorted) {
+    int parts = (n + 2047) / 2048;
+    parts = parts < 1 ? 1 : (parts > KNN_BOX_WGS ? KNN_BOX_WGS : parts);
+    hipLaunchKernelGGL(knn_box_kernel, dim3(parts), dim3(256), 0, stream, n, pts, gp);
+    hipLaunchKernelGGL(knn_grid_params_kernel, dim3(KNN_PARAM_WGS), dim3(1024), 0, stream, n, parts, h_area, h_vol, gp, cell_count);
+    hipLaunchKernelGGL(knn_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, pts, gp, cell_of, cell_count);
+    hipLaunchKernelGGL(knn_scan_sums_kernel, dim3(KNN_SCAN_TILES), dim3(1024), 0, stream, gp, cell_count);
+    hipLaunchKernelGGL(knn_scan_kernel, dim3(KNN_SCAN_TILES), dim3(1024), 0, stream, gp, cell_count, cell_start, cell_fill);
+    hipLaunchKernelGGL(knn_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, pts, cell_of, cell_fill, sorted);
 }
 
 // Tracker-sized clouds (<= KNN_FUSED_MAX_N points: 8-12 k per frame): the four launches above as ONE single-workgroup kernel — bounding box,
@@ -567,28 +665,14 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
         if (lane == 0) { s_lo[d][wave] = lo[d]; s_hi[d][wave] = hi[d]; }
     }
     __syncthreads();
-    if (tid == 0) {   // identical arithmetic to knn_grid_params_kernel
+    if (tid == 0) {
         float L[3], E[3];
         for (int d = 0; d < 3; ++d) {
             float l = s_lo[d][0], u = s_hi[d][0];
             for (int w = 1; w < 16; ++w) { l = fminf(l, s_lo[d][w]); u = fmaxf(u, s_hi[d][w]); }
             L[d] = l; E[d] = fmaxf(u - l, 0.f);
         }
-        const float emax = fmaxf(fmaxf(E[0], E[1]), fmaxf(E[2], 1e-6f));
-        const float area = E[0] * E[1] + E[1] * E[2] + E[0] * E[2];
-        const float vol = fmaxf(E[0], 1e-3f * emax) * fmaxf(E[1], 1e-3f * emax) * fmaxf(E[2], 1e-3f * emax);
-        float h = fmaxf(h_area * sqrtf(area / (float)n), h_vol * cbrtf(vol / (float)n));
-        h = fmaxf(h, emax * (1.f / 1024.f));
-        int nx, ny, nz;
-        for (;;) {
-            nx = (int)(E[0] / h) + 1; ny = (int)(E[1] / h) + 1; nz = (int)(E[2] / h) + 1;
-            if ((long long)nx * ny * nz <= KNN_MAX_CELLS) break;
-            h *= 1.25f;
-        }
-        KnnGrid g;
-        g.ox = L[0]; g.oy = L[1]; g.oz = L[2]; g.h = h; g.inv_h = 1.f / h;
-        g.nx = nx; g.ny = ny; g.nz = nz; g.ncells = nx * ny * nz;
-        for (int i = 0; i < 5; ++i) g.ring_hist[i] = 0u;
+        const KnnGrid g = knn_grid_from_box(L, E, n, h_area, h_vol);
         s_g = g;
         *gp = g;
     }
@@ -1070,10 +1154,8 @@ __global__ __launch_bounds__(256) void cov_fromqs_kernel(int n, int reg_method, 
 // ---------------------------------------------------------------------------------------------- hash grid build
 // sort key = coarse-cell key << 3 | octant: a coarse cell's points come out contiguous, ordered by fine cell, in track order within one
 __global__ __launch_bounds__(256) void grid_keys_kernel(int n_track, const int* __restrict__ track, const float4* __restrict__ pts,
-                                                        float inv_hf, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals,
-                                                        unsigned* __restrict__ n_cells) {
+                                                        float inv_hf, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s == 0) { n_cells[0] = 0u; n_cells[1] = 0u; }     // [0] counted runs (read back by the host), [1] ordinal allocator of grid_cells_kernel
     if (s >= n_track) return;
     const int i = track[s];
     const float4 p = pts[i];
@@ -1081,31 +1163,84 @@ __global__ __launch_bounds__(256) void grid_keys_kernel(int n_track, const int* 
     keys[s] = cell_key(fx >> 1, fy >> 1, fz >> 1) << 3 | (unsigned long long)((fx & 1) | (fy & 1) << 1 | (fz & 1) << 2);
     vals[s] = (unsigned)i;
 }
-// occupied coarse cells (runs of the sorted keys): one atomic per workgroup; the host reads the total back to size the table by CELLS
-__global__ __launch_bounds__(256) void grid_count_cells_kernel(int n, const unsigned long long* __restrict__ skeys, unsigned* __restrict__ n_cells) {
-    __shared__ unsigned s_w[4];
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    const bool first = s < n && (s == 0 || (skeys[s - 1] >> 3) != (skeys[s] >> 3));
-    const unsigned long long b = __ballot(first);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(b);
-    __syncthreads();
-    if (threadIdx.x == 0) { const unsigned c = s_w[0] + s_w[1] + s_w[2] + s_w[3]; if (c) atomicAdd(n_cells, c); }
+// Occupied coarse cells = runs of the sorted keys.  Cell ordinals are the RANKS of the run heads (rounds 3-4a handed them out with one
+// same-address atomic per cell: 17 k serialised atomics = 150 us of a 1e6-point build): heads per slab of 256 or 2 048 sorted keys, one
+// single-workgroup scan over the slabs (its total is what the host reads back to size the table by CELLS), rank inside the slab by ballots.
+// sorted keys per workgroup = 256 x NJ (element j * 256 + t of the slab for thread t): NJ = 8 for maps, 1 below GRID_SMALL_N points (a frame-sized
+// target would otherwise be five workgroups walking eight insertions each)
+constexpr int GRID_SMALL_N = 65536;
+__device__ inline bool grid_run_head(const unsigned long long* __restrict__ skeys, int s, int n) {
+    return s < n && (s == 0 || (skeys[s - 1] >> 3) != (skeys[s] >> 3));
 }
-// sorted (key, original index) -> sorted float4 records; the first element of each COARSE run takes the next cell ordinal, inserts
-// {coarse key -> ordinal} in the table and clears the cell's eight {begin, count} pairs
+template <int NJ>
+__global__ __launch_bounds__(256) void grid_heads_kernel(int n, const unsigned long long* __restrict__ skeys, unsigned* __restrict__ slab_heads) {
+    __shared__ unsigned s_w[4];
+    const int tid = threadIdx.x, base = (int)blockIdx.x * (256 * NJ);
+    unsigned c = 0u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) c += (unsigned)__popcll(__ballot(grid_run_head(skeys, base + j * 256 + tid, n)));
+    if ((tid & 63) == 0) s_w[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) slab_heads[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+// exclusive scan of the slab counts in place (one workgroup; <= 2^26 / 2048 = 32 768 slabs); n_cells[0] = total = occupied cells
+__global__ __launch_bounds__(1024) void grid_heads_scan_kernel(int n_slabs, unsigned* __restrict__ slab_heads, unsigned* __restrict__ n_cells) {
+    __shared__ unsigned s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n_slabs + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < n_slabs ? lo + per : n_slabs;
+    unsigned sum = 0u;
+    for (int b = lo; b < hi; ++b) sum += slab_heads[b];
+    unsigned incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned u = (unsigned)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned run = incl - sum, total = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const unsigned v = s_w[w]; if (w < wave) run += v; total += v; }
+    for (int b = lo; b < hi; ++b) { const unsigned c = slab_heads[b]; slab_heads[b] = run; run += c; }
+    if (tid == 0) n_cells[0] = total;
+}
+// sorted (key, original index) -> sorted float4 records; the first element of each COARSE run inserts {coarse key -> its rank} in the
+// table and clears the cell's eight {begin, count} pairs
+template <int NJ>
 __global__ __launch_bounds__(256) void grid_cells_kernel(int n, const unsigned long long* __restrict__ skeys, const unsigned* __restrict__ svals,
                                                          const float4* __restrict__ pts, float4* __restrict__ sorted, unsigned mask,
                                                          unsigned long long* __restrict__ tkeys, unsigned* __restrict__ tords,
-                                                         uint2* __restrict__ cells, unsigned* __restrict__ n_cells) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n) return;
-    const unsigned id = svals[s];
-    float4 p = pts[id];
-    p.w = __int_as_float((int)id);
-    sorted[s] = p;
-    const unsigned long long key = skeys[s] >> 3;
-    if (s == 0 || (skeys[s - 1] >> 3) != key) {
-        const unsigned ord = atomicAdd(n_cells + 1, 1u);
+                                                         uint2* __restrict__ cells, const unsigned* __restrict__ slab_base) {
+    __shared__ unsigned s_cnt[NJ][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, base = (int)blockIdx.x * (256 * NJ);
+    unsigned id[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int s = base + j * 256 + tid; id[j] = svals[s < n ? s : n - 1]; }
+    float4 p[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) p[j] = pts[id[j]];
+    unsigned long long heads[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        heads[j] = __ballot(grid_run_head(skeys, base + j * 256 + tid, n));
+        if (lane == 0) s_cnt[j][wave] = (unsigned)__popcll(heads[j]);
+    }
+    __syncthreads();
+    unsigned before = slab_base[blockIdx.x];     // heads in front of (j, wave) in slab order
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int s = base + j * 256 + tid;
+        unsigned mine = before;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const unsigned v = s_cnt[j][w]; if (w < wave) mine += v; before += v; }
+        if (s >= n) continue;
+        float4 q = p[j];
+        q.w = __int_as_float((int)id[j]);
+        sorted[s] = q;
+        if (!(heads[j] >> lane & 1ull)) continue;
+        const unsigned ord = mine + (unsigned)__popcll(heads[j] & ((1ull << lane) - 1ull));
+        const unsigned long long key = skeys[s] >> 3;
         unsigned slot = (hash_key(key) << 2) & mask;   // first slot of the key's 4-slot bucket (grid_nn reads whole buckets)
         for (;;) {
             const unsigned long long prev = atomicCAS(&tkeys[slot], EMPTY_KEY, key);
@@ -2039,7 +2174,7 @@ struct PinnedBuf {                // page-locked host staging: async copies with
 struct IndexLevel {               // one level of the target index (build_level)
     GridView view{};
     DevBuf<unsigned long long> tkeys;
-    DevBuf<unsigned> tords, n_cells;
+    DevBuf<unsigned> tords, n_cells, slab_heads;   // n_cells[0] = occupied coarse cells (grid_heads_scan_kernel)
     DevBuf<uint2> cells;
     DevBuf<float4> sorted;
     unsigned n_cells_host = 0;
@@ -2220,22 +2355,17 @@ int calc_cov(gsicp_gicp* g, Cloud& c) {
         if (g->k > 64) { g_last_error = "correspondence randomness (k) > 64 is not supported"; return -2; }
         const float maxd2 = g->max_knn >= (double)FLT_MAX ? FLT_MAX : (float)(g->max_knn * g->max_knn);
         gsicp::ProfileScope ps(gsicp::ST_GICP_COV, g->stream);
-        if (g->nbr_idx.ensure((size_t)n * 64) || g->nbr_d2.ensure((size_t)n * 64) || g->knn_params.ensure(1) ||
-            g->knn_cell_of.ensure((size_t)n) || g->knn_count.ensure(KNN_MAX_CELLS + 1) || g->knn_start.ensure(KNN_MAX_CELLS + 1) ||
-            g->knn_fill.ensure(KNN_MAX_CELLS + 1) || g->knn_sorted.ensure((size_t)n)) { g_last_error = "hipMalloc failed"; return -1; }
+        if (g->nbr_idx.ensure((size_t)n * 64) || g->nbr_d2.ensure((size_t)n * 64) || g->knn_params.ensure(KNN_PARAM_SLOTS) ||
+            g->knn_cell_of.ensure((size_t)n) || g->knn_count.ensure(KNN_CELL_SLOTS) || g->knn_start.ensure(KNN_CELL_SLOTS) ||
+            g->knn_fill.ensure(KNN_CELL_SLOTS) || g->knn_sorted.ensure((size_t)n)) { g_last_error = "hipMalloc failed"; return -1; }
         static const bool knn_stats_on = std::getenv("GSICP_KNN_STATS") != nullptr;
         static const float h_area = [] { const char* e = std::getenv("GSICP_KNN_H"); const float v = e ? (float)std::atof(e) : 0.f; return v > 0.f ? v : KNN_H_AREA; }();
         if (n <= KNN_FUSED_MAX_N) {
             hipLaunchKernelGGL(knn_build_fused_kernel, dim3(1), dim3(1024), 0, g->stream, n, c.pts.p, h_area, h_area * (KNN_H_VOL / KNN_H_AREA),
                                g->knn_params.p, g->knn_cell_of.p, g->knn_count.p, g->knn_start.p, g->knn_fill.p, g->knn_sorted.p);
         } else {
-            hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, g->stream, n, c.pts.p, h_area, h_area * (KNN_H_VOL / KNN_H_AREA),
-                               g->knn_params.p, g->knn_count.p);
-            hipLaunchKernelGGL(knn_count_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, c.pts.p, g->knn_params.p, g->knn_cell_of.p,
-                               g->knn_count.p);
-            hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, g->stream, g->knn_params.p, g->knn_count.p, g->knn_start.p, g->knn_fill.p);
-            hipLaunchKernelGGL(knn_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, g->stream, n, c.pts.p, g->knn_cell_of.p, g->knn_fill.p,
-                               g->knn_sorted.p);
+            enqueue_knn_grid_build(g->stream, n, c.pts.p, h_area, h_area * (KNN_H_VOL / KNN_H_AREA), g->knn_params.p, g->knn_cell_of.p, g->knn_count.p,
+                                   g->knn_start.p, g->knn_fill.p, g->knn_sorted.p);
         }
         hipLaunchKernelGGL(knn_grid_kernel, dim3((n + 3) / 4), dim3(256), 0, g->stream, n, g->k, c.pts.p, g->knn_params.p, g->knn_start.p,
                            g->knn_sorted.p, g->nbr_idx.p, g->nbr_d2.p,
@@ -2255,6 +2385,7 @@ int calc_cov(gsicp_gicp* g, Cloud& c) {
 int build_level(gsicp_gicp* g, int lvl, double radius) {
     Cloud& t = g->tgt;
     const int n = t.n_track;
+    const int slab = n < GRID_SMALL_N ? 256 : 2048, n_slabs = (n + slab - 1) / slab;
     IndexLevel& L = g->lv[lvl];
     GridView& G = L.view;
     std::memset(&G, 0, sizeof(G));
@@ -2266,15 +2397,17 @@ int build_level(gsicp_gicp* g, int lvl, double radius) {
     size_t temp_bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
                                     (unsigned*)nullptr, (size_t)n, 0, 63, g->stream);
-    if (g->gkeys.ensure(n) || g->gskeys.ensure(n) || g->gvals.ensure(n) || g->gsvals.ensure(n) || L.n_cells.ensure(2) ||
+    if (g->gkeys.ensure(n) || g->gskeys.ensure(n) || g->gvals.ensure(n) || g->gsvals.ensure(n) || L.n_cells.ensure(2) || L.slab_heads.ensure((size_t)n_slabs) ||
         g->sort_temp.ensure(temp_bytes ? temp_bytes : 1)) { g_last_error = "hipMalloc failed"; return -1; }
     const dim3 grid((n + 255) / 256), block(256);
-    hipLaunchKernelGGL(grid_keys_kernel, grid, block, 0, g->stream, n, t.track.p, t.pts.p, G.inv_hf, g->gkeys.p, g->gvals.p, L.n_cells.p);
+    hipLaunchKernelGGL(grid_keys_kernel, grid, block, 0, g->stream, n, t.track.p, t.pts.p, G.inv_hf, g->gkeys.p, g->gvals.p);
     GC(rocprim::radix_sort_pairs(g->sort_temp.p, temp_bytes, g->gkeys.p, g->gskeys.p, g->gvals.p, g->gsvals.p, (size_t)n, 0, 63, g->stream));
+    if (slab == 256) hipLaunchKernelGGL(grid_heads_kernel<1>, dim3(n_slabs), block, 0, g->stream, n, g->gskeys.p, L.slab_heads.p);
+    else hipLaunchKernelGGL(grid_heads_kernel<8>, dim3(n_slabs), block, 0, g->stream, n, g->gskeys.p, L.slab_heads.p);
+    hipLaunchKernelGGL(grid_heads_scan_kernel, dim3(1), dim3(1024), 0, g->stream, n_slabs, L.slab_heads.p, L.n_cells.p);
     size_t n_cells = (size_t)n;       // upper bound
     L.cells_known = false;
     if (n >= (1 << 15)) {
-        hipLaunchKernelGGL(grid_count_cells_kernel, grid, block, 0, g->stream, n, g->gskeys.p, L.n_cells.p);
         GC(hipMemcpyAsync(&g->mailbox->scratch_u32, L.n_cells.p, sizeof(unsigned), hipMemcpyDeviceToHost, g->stream));
         if (int rc_ = drain(g)) return rc_;
         n_cells = g->mailbox->scratch_u32;
@@ -2290,8 +2423,10 @@ int build_level(gsicp_gicp* g, int lvl, double radius) {
     G.mask = (unsigned)(cap - 1);
     if (L.tkeys.ensure(cap) || L.tords.ensure(cap) || L.cells.ensure((size_t)8 * n_cells)) { g_last_error = "hipMalloc failed"; return -1; }
     GC(hipMemsetAsync(L.tkeys.p, 0xFF, cap * 8, g->stream));
-    hipLaunchKernelGGL(grid_cells_kernel, grid, block, 0, g->stream, n, g->gskeys.p, g->gsvals.p, t.pts.p, L.sorted.p, G.mask, L.tkeys.p, L.tords.p,
-                       L.cells.p, L.n_cells.p);
+    if (slab == 256) hipLaunchKernelGGL(grid_cells_kernel<1>, dim3(n_slabs), block, 0, g->stream, n, g->gskeys.p, g->gsvals.p, t.pts.p, L.sorted.p, G.mask, L.tkeys.p, L.tords.p,
+                       L.cells.p, L.slab_heads.p);
+    else hipLaunchKernelGGL(grid_cells_kernel<8>, dim3(n_slabs), block, 0, g->stream, n, g->gskeys.p, g->gsvals.p, t.pts.p, L.sorted.p, G.mask, L.tkeys.p, L.tords.p,
+                       L.cells.p, L.slab_heads.p);
     hipLaunchKernelGGL(grid_octants_kernel, grid, block, 0, g->stream, n, g->gskeys.p, G.mask, L.tkeys.p, L.tords.p, L.cells.p);
     GC(hipGetLastError());
     G.keys = L.tkeys.p; G.ords = L.tords.p; G.cells = L.cells.p;
@@ -2340,14 +2475,14 @@ int build_grid(gsicp_gicp* g) {
     }
     // coarse dense grid over the same points for the exact-distance export (nn1_grid_kernel)
     g->tg_valid = false;
-    const dim3 grid((n + 255) / 256), block(256);
-    if (!(g->tg_params.ensure(1) || g->tg_cell_of.ensure((size_t)n) || g->tg_count.ensure(KNN_MAX_CELLS + 1) ||
-          g->tg_start.ensure(KNN_MAX_CELLS + 1) || g->tg_fill.ensure(KNN_MAX_CELLS + 1) || g->tg_sorted.ensure((size_t)n))) {
-        hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, g->stream, n, (const float4*)g->lv[0].sorted.p, KNN_H_AREA, KNN_H_VOL,
-                           g->tg_params.p, g->tg_count.p);
-        hipLaunchKernelGGL(knn_count_kernel, grid, block, 0, g->stream, n, (const float4*)g->lv[0].sorted.p, g->tg_params.p, g->tg_cell_of.p, g->tg_count.p);
-        hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, g->stream, g->tg_params.p, g->tg_count.p, g->tg_start.p, g->tg_fill.p);
-        hipLaunchKernelGGL(knn_fill_kernel, grid, block, 0, g->stream, n, (const float4*)g->lv[0].sorted.p, g->tg_cell_of.p, g->tg_fill.p, g->tg_sorted.p);
+    if (!(g->tg_params.ensure(KNN_PARAM_SLOTS) || g->tg_cell_of.ensure((size_t)n) || g->tg_count.ensure(KNN_CELL_SLOTS) ||
+          g->tg_start.ensure(KNN_CELL_SLOTS) || g->tg_fill.ensure(KNN_CELL_SLOTS) || g->tg_sorted.ensure((size_t)n))) {
+        if (n <= KNN_FUSED_MAX_N)      // a frame-sized target (the first frames of a run): the single-workgroup build, one launch instead of six
+            hipLaunchKernelGGL(knn_build_fused_kernel, dim3(1), dim3(1024), 0, g->stream, n, (const float4*)g->lv[0].sorted.p, KNN_H_AREA, KNN_H_VOL,
+                               g->tg_params.p, g->tg_cell_of.p, g->tg_count.p, g->tg_start.p, g->tg_fill.p, g->tg_sorted.p);
+        else
+            enqueue_knn_grid_build(g->stream, n, (const float4*)g->lv[0].sorted.p, KNN_H_AREA, KNN_H_VOL, g->tg_params.p, g->tg_cell_of.p, g->tg_count.p,
+                                   g->tg_start.p, g->tg_fill.p, g->tg_sorted.p);
         GC(hipGetLastError());
         g->tg_valid = true;
     }
@@ -2771,7 +2906,7 @@ int gsicp_gicp_target_index_stats(gsicp_gicp* g, double out[12]) {
         if (!L.view.use_grid) continue;
         unsigned cells = 0;
         GC(hipStreamSynchronize(g->stream));
-        GC(hipMemcpy(&cells, L.n_cells.p + 1, sizeof(cells), hipMemcpyDeviceToHost));   // ordinals handed out = occupied coarse cells
+        GC(hipMemcpy(&cells, L.n_cells.p, sizeof(cells), hipMemcpyDeviceToHost));       // run heads of the sorted keys = occupied coarse cells
         double* o = out + 2 + 5 * l;
         o[0] = (double)L.view.mask + 1.0;                                   // table slots
         o[1] = o[0] * 12.0 + (double)L.n_cells_host * 64.0;                 // keys + ordinals + cell records (as allocated)
@@ -2824,16 +2959,13 @@ int gsicp_knn_dist2(int P, const float* points, float* out, void* stream_v) {
     GC(hipGetDevice(&dev));
     Knn3Scratch& k = per_device[dev];
     if (!k.done) GC(hipEventCreateWithFlags(&k.done, hipEventDisableTiming));
-    const bool grow = (size_t)P > k.pts.cap || (size_t)P > k.sorted.cap || (size_t)P > k.cell_of.cap || k.count.cap < (size_t)KNN_MAX_CELLS + 1 || k.params.cap < 1;
+    const bool grow = (size_t)P > k.pts.cap || (size_t)P > k.sorted.cap || (size_t)P > k.cell_of.cap || k.count.cap < (size_t)KNN_CELL_SLOTS || k.params.cap < (size_t)KNN_PARAM_SLOTS;
     if (k.used && grow) GC(hipDeviceSynchronize());                                     // nothing queued may still read what is about to be freed
     else if (k.used && k.last_stream != stream) GC(hipStreamWaitEvent(stream, k.done, 0));   // another stream's call owns the buffers until its kernels are done
-    if (k.pts.ensure((size_t)P) || k.sorted.ensure((size_t)P) || k.cell_of.ensure((size_t)P) || k.count.ensure(KNN_MAX_CELLS + 1) ||
-        k.start.ensure(KNN_MAX_CELLS + 1) || k.fill.ensure(KNN_MAX_CELLS + 1) || k.params.ensure(1)) { g_last_error = "hipMalloc failed"; return -1; }
+    if (k.pts.ensure((size_t)P) || k.sorted.ensure((size_t)P) || k.cell_of.ensure((size_t)P) || k.count.ensure(KNN_CELL_SLOTS) ||
+        k.start.ensure(KNN_CELL_SLOTS) || k.fill.ensure(KNN_CELL_SLOTS) || k.params.ensure(KNN_PARAM_SLOTS)) { g_last_error = "hipMalloc failed"; return -1; }
     hipLaunchKernelGGL(knn3_pack_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, points, k.pts.p);
-    hipLaunchKernelGGL(knn_grid_params_kernel, dim3(1), dim3(1024), 0, stream, P, k.pts.p, KNN_H_AREA, KNN_H_VOL, k.params.p, k.count.p);
-    hipLaunchKernelGGL(knn_count_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, k.pts.p, k.params.p, k.cell_of.p, k.count.p);
-    hipLaunchKernelGGL(knn_scan_kernel, dim3(1), dim3(1024), 0, stream, k.params.p, k.count.p, k.start.p, k.fill.p);
-    hipLaunchKernelGGL(knn_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, k.pts.p, k.cell_of.p, k.fill.p, k.sorted.p);
+    enqueue_knn_grid_build(stream, P, k.pts.p, KNN_H_AREA, KNN_H_VOL, k.params.p, k.cell_of.p, k.count.p, k.start.p, k.fill.p, k.sorted.p);
     hipLaunchKernelGGL(knn3_grid_kernel, dim3((P + 3) / 4), dim3(256), 0, stream, P, k.pts.p, k.params.p, k.start.p, k.sorted.p, out);
     GC(hipGetLastError());
     GC(hipEventRecord(k.done, stream));
