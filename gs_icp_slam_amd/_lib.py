@@ -103,6 +103,7 @@ SIGNATURES = {
     "gsicp_gicp_last_align_stats": (c_int, [c_void_p, c_void_p]),
     "gsicp_gicp_get_final_hessian": (c_int, [c_void_p, c_void_p]),
     "gsicp_gicp_debug_abort_next_align": (c_int, [c_void_p]),
+    "gsicp_debug_wave_sort": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_gicp_barrier_retries": (c_int, [c_void_p]),
 }
 

@@ -756,37 +756,88 @@ __global__ __launch_bounds__(1024) void knn_build_fused_kernel(int n, const floa
     }
 }
 
+typedef unsigned gi_uint2_t __attribute__((ext_vector_type(2)));
 struct TopK { float my_d; int my_i; float tau_d; int tau_i; };
-// (d, id) pairs are totally ordered (ids are unique; idle lanes carry (FLT_MAX, INT_MAX), the largest pair)
-__device__ inline void lex_cswap(float& d, int& i, const float od, const int oi, const bool keep_min) {
-    const bool other_less = lex_less(od, oi, d, i);
-    if (other_less == keep_min) { d = od; i = oi; }
-}
-// ascending bitonic sort of one pair per lane across the wave: 21 compare-exchange steps, no scalar round trips
-__device__ inline void wave_sort_pairs(float& d, int& i, const int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const float od = __shfl_xor(d, j, 64);
-            const int oi = __shfl_xor(i, j, 64);
-            const bool up = (lane & k) == 0 || k == 64;            // direction of this lane's block
-            lex_cswap(d, i, od, oi, ((lane & j) == 0) == up);
-        }
+// (d, id) pairs are totally ordered (ids are unique; idle lanes carry (FLT_MAX, INT_MAX), the largest pair).  For d >= 0 (squared distances;
+// candidates that are not < FLT_MAX — NaN, overflow — are turned into the idle pair where they are made) the order of the pairs IS the order
+// of the 64-bit integers (bits of d) << 32 | id: one v_cmp_lt_u64 instead of three compares and two mask operations.
+typedef unsigned long long pair_key_t;
+__device__ __forceinline__ pair_key_t pair_key(float d, int i) { return ((pair_key_t)__float_as_uint(d) << 32) | (pair_key_t)(unsigned)i; }
+__device__ __forceinline__ float pair_d(pair_key_t k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ int pair_i(pair_key_t k) { return (int)(unsigned)k; }
+__device__ __forceinline__ bool pair_less(float d, int i, float d2, int i2) { return pair_key(d, i) < pair_key(d2, i2); }
+__device__ __forceinline__ void idle_unless_finite(float& d, int& id) { if (!(d < FLT_MAX)) { d = FLT_MAX; id = 0x7fffffff; } }
+
+// value of lane (l ^ J) without the LDS crossbar: quad permutes (1, 2), two bank-masked row shifts (4), a row rotate (8), gfx950's
+// v_permlane16_swap / v_permlane32_swap (16, 32).  Round 4b: the sorting network below used __shfl_xor = ds_bpermute_b32 + s_waitcnt, 42 LDS
+// round trips per sort, and its compare-exchanges compiled into exec-masked branches (355 ds_bpermute / 243 s_and_saveexec in the kernel).
+template <int J>
+__device__ __forceinline__ unsigned lane_xor(unsigned v, int lane) {
+    const int iv = (int)v;
+    // (old = 0 with bound_ctrl: every lane has a valid source in these patterns, and the compiler then needs no copy of `old`)
+    if constexpr (J == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, iv, 0x12C, 0xF, 0xF, true);                            // row_ror 12: lane l <- (l + 4) mod 16, right for banks 0, 2
+        return (unsigned)__builtin_amdgcn_update_dpp(t, iv, 0x124, 0xF, 0xA, false);                        // banks 1, 3: row_ror 4, lane l <- l - 4
+    } else if constexpr (J == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, iv, 0x128, 0xF, 0xF, true);   // row_ror 8
+    else if constexpr (J == 15) return (unsigned)__builtin_amdgcn_update_dpp(0, iv, 0x140, 0xF, 0xF, true);    // row_mirror
+    else if constexpr (J == 16) {
+        const gi_uint2_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false);    // x: rows (0, 0, 2, 2) of v, y: rows (1, 1, 3, 3)
+        return (lane & 16) ? r.x : r.y;
+    } else {
+        static_assert(J == 32, "lane_xor: unsupported pattern");
+        const gi_uint2_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false);    // x: lower half of v twice, y: upper half twice
+        return (lane & 32) ? r.x : r.y;
     }
+}
+template <int J>
+__device__ __forceinline__ pair_key_t lane_xor_key(pair_key_t k, int lane) {
+    return (pair_key_t)lane_xor<J>((unsigned)(k >> 32), lane) << 32 | (pair_key_t)lane_xor<J>((unsigned)k, lane);
+}
+// one compare-exchange of a bitonic network: partner = lane ^ J; blocks of K lanes alternate direction (K = 64: ascending everywhere)
+template <int K, int J>
+__device__ __forceinline__ void cx_step(pair_key_t& k, int lane) {
+    const bool up = K >= 64 || (lane & K) == 0;
+    const bool keep_min = ((lane & J) == 0) == up;
+    if constexpr (J >= 16) {
+        // the swap instructions hand BOTH partners to both lanes of a pair (a: the key of the lane with bit J clear, b: of the lane with it
+        // set), so the step is a min / max of (a, b) — no second copy of the key, no select to rebuild "the other lane's key"
+        gi_uint2_t hi, lo;
+        if constexpr (J == 16) { hi = __builtin_amdgcn_permlane16_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+                                 lo = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false); }
+        else { hi = __builtin_amdgcn_permlane32_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+               lo = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false); }
+        const pair_key_t a = (pair_key_t)hi.x << 32 | lo.x, b = (pair_key_t)hi.y << 32 | lo.y;
+        k = ((a < b) == keep_min) ? a : b;
+    } else {
+        const pair_key_t o = lane_xor_key<J>(k, lane);
+        k = ((o < k) == keep_min) ? o : k;
+    }
+}
+template <int K, int J>
+__device__ __forceinline__ void cx_steps(pair_key_t& k, int lane) {     // J, J / 2, .. 1 at block size K
+    cx_step<K, J>(k, lane);
+    if constexpr (J > 1) cx_steps<K, J / 2>(k, lane);
+}
+// ascending bitonic sort of one pair per lane across the wave: 21 compare-exchange steps, no scalar round trips, no LDS
+__device__ __forceinline__ void wave_sort_keys(pair_key_t& k, int lane) {
+    cx_steps<2, 1>(k, lane); cx_steps<4, 2>(k, lane); cx_steps<8, 4>(k, lane);
+    cx_steps<16, 8>(k, lane); cx_steps<32, 16>(k, lane); cx_steps<64, 32>(k, lane);
 }
 // the list (ascending over the lanes) and 64 candidates -> the 64 smallest of both, ascending: sort the candidates, take the lane-wise
 // minimum against the reversed list (a bitonic sequence holding exactly the 64 smallest), finish with the six merge steps
 __device__ inline void topk_merge64(TopK& t, float d, int id, const int kk, const int lane) {
-    wave_sort_pairs(d, id, lane);
-    const float rd = __shfl(d, 63 - lane, 64);
-    const int ri = __shfl(id, 63 - lane, 64);
-    if (lex_less(rd, ri, t.my_d, t.my_i)) { t.my_d = rd; t.my_i = ri; }
-#pragma unroll
-    for (int j = 32; j > 0; j >>= 1) {
-        const float od = __shfl_xor(t.my_d, j, 64);
-        const int oi = __shfl_xor(t.my_i, j, 64);
-        lex_cswap(t.my_d, t.my_i, od, oi, (lane & j) == 0);
+    pair_key_t c = pair_key(d, id);
+    wave_sort_keys(c, lane);
+    if (__builtin_amdgcn_readfirstlane(t.my_i) == 0x7fffffff) {     // the list is still empty (ascending: lane 0 idle = every lane idle): the
+        t.my_d = pair_d(c); t.my_i = pair_i(c);                      // sorted candidates ARE the list — the first batch of every query
+    } else {
+        c = lane_xor_key<15>(lane_xor_key<16>(lane_xor_key<32>(c, lane), lane), lane);     // lane 63 - l
+        pair_key_t m = pair_key(t.my_d, t.my_i);
+        m = c < m ? c : m;
+        cx_steps<64, 32>(m, lane);
+        t.my_d = pair_d(m); t.my_i = pair_i(m);
     }
     t.tau_d = readlane_f(t.my_d, kk - 1);
     t.tau_i = __builtin_amdgcn_readlane(t.my_i, kk - 1);
@@ -794,28 +845,30 @@ __device__ inline void topk_merge64(TopK& t, float d, int id, const int kk, cons
 // Offer one candidate per lane (d = FLT_MAX / id = INT_MAX for idle lanes) to the cross-lane sorted list (ascending over the lanes; lanes
 // >= kk hold the next larger pairs or the idle pair and are never read).  Few candidates below the current k-th pair are inserted one by one
 // (a scalar round trip each, ~25 instructions); many — the first batches of a query, while the list is still filling — go through the
-// sorting network instead (~270 instructions whatever their number).
-constexpr int TOPK_SORT_FROM = 10;
+// sorting network instead (~200 instructions whatever their number).
+constexpr int TOPK_SORT_FROM = 8;
 __device__ inline void topk_offer(TopK& t, float d, int id, int kk, unsigned long long kmask, int lane) {
+    idle_unless_finite(d, id);
     if (kk == 1) {      // nearest neighbour only (the exact-distance export): a lexicographic wave minimum, no list to maintain
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float od = __shfl_xor(d, off, 64);
-            const int oi = __shfl_xor(id, off, 64);
-            if (lex_less(od, oi, d, id)) { d = od; id = oi; }
-        }
-        if (lex_less(d, id, t.tau_d, t.tau_i)) { t.tau_d = d; t.tau_i = id; t.my_d = d; t.my_i = id; }   // every lane holds the same pair
+        pair_key_t k = pair_key(d, id);
+        { const pair_key_t o = lane_xor_key<32>(k, lane); k = o < k ? o : k; }
+        { const pair_key_t o = lane_xor_key<16>(k, lane); k = o < k ? o : k; }
+        { const pair_key_t o = lane_xor_key<8>(k, lane); k = o < k ? o : k; }
+        { const pair_key_t o = lane_xor_key<4>(k, lane); k = o < k ? o : k; }
+        { const pair_key_t o = lane_xor_key<2>(k, lane); k = o < k ? o : k; }
+        { const pair_key_t o = lane_xor_key<1>(k, lane); k = o < k ? o : k; }
+        if (k < pair_key(t.tau_d, t.tau_i)) { t.tau_d = t.my_d = pair_d(k); t.tau_i = t.my_i = pair_i(k); }   // every lane holds the same pair
         return;
     }
-    unsigned long long m = __ballot(lex_less(d, id, t.tau_d, t.tau_i));
+    unsigned long long m = __ballot(pair_less(d, id, t.tau_d, t.tau_i));
     if (__popcll(m) >= TOPK_SORT_FROM) { topk_merge64(t, d, id, kk, lane); return; }
     while (m) {
         const int b = __ffsll((long long)m) - 1;
         m &= m - 1;
         const float cd = readlane_f(d, b);
         const int ci = __builtin_amdgcn_readlane(id, b);
-        if (!lex_less(cd, ci, t.tau_d, t.tau_i)) continue;   // the list moved on since the ballot
-        const unsigned long long le = __ballot(!lex_less(cd, ci, t.my_d, t.my_i)) & kmask;   // entries ranked before the candidate
+        if (!pair_less(cd, ci, t.tau_d, t.tau_i)) continue;   // the list moved on since the ballot
+        const unsigned long long le = __ballot(!pair_less(cd, ci, t.my_d, t.my_i)) & kmask;   // entries ranked before the candidate
         const int pos = __popcll(le);
         const float up_d = __int_as_float(wave_shr1(__float_as_int(t.my_d)));
         const int up_i = wave_shr1(t.my_i);
@@ -824,6 +877,19 @@ __device__ inline void topk_offer(TopK& t, float d, int id, int kk, unsigned lon
         t.tau_d = readlane_f(t.my_d, kk - 1);
         t.tau_i = __builtin_amdgcn_readlane(t.my_i, kk - 1);
     }
+}
+
+// test hook (gsicp_debug_wave_sort): the wave-wide sorting network and the lane-exchange patterns it is made of, on one wave
+__global__ __launch_bounds__(64) void debug_wave_sort_kernel(const float* __restrict__ d, const int* __restrict__ id, float* __restrict__ od,
+                                                             int* __restrict__ oi, int* __restrict__ ox) {
+    const int lane = threadIdx.x;
+    pair_key_t k = pair_key(d[lane], id[lane]);
+    wave_sort_keys(k, lane);
+    od[lane] = pair_d(k); oi[lane] = pair_i(k);
+    const unsigned me = (unsigned)lane * 3u + 1u;      // any lane-dependent value: ox[j][lane] must equal the value of lane (lane ^ J)
+    ox[0 * 64 + lane] = (int)lane_xor<1>(me, lane); ox[1 * 64 + lane] = (int)lane_xor<2>(me, lane); ox[2 * 64 + lane] = (int)lane_xor<4>(me, lane);
+    ox[3 * 64 + lane] = (int)lane_xor<8>(me, lane); ox[4 * 64 + lane] = (int)lane_xor<15>(me, lane); ox[5 * 64 + lane] = (int)lane_xor<16>(me, lane);
+    ox[6 * 64 + lane] = (int)lane_xor<32>(me, lane);
 }
 
 // scan one contiguous range of the cell-sorted array, four batches per trip (four independent loads in flight: the whole-cloud fallback
@@ -909,6 +975,7 @@ __device__ inline int knn_search(const float4 Q, int kk, unsigned long long kmas
         const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r >= g.ny ? g.ny - 1 : cy + r;
         const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r >= g.nz ? g.nz - 1 : cz + r;
         const int side = 2 * r + 1, rows = side * side;
+        const float inv_side = 1.0f / (float)side;     // w / side below as a float product: exact for w < 169, side <= 13 ((w + 0.5) / side is never within 0.03 of an integer)
         // pass 0: every row of the window (outer rows: the whole segment; inner rows of r >= 2: the left end cell, x = cx - r);
         // pass 1 (r >= 2): the right end cell (x = cx + r) of the inner rows
         for (int pass = 0; pass < (r >= 2 ? 2 : 1); ++pass) {
@@ -916,7 +983,8 @@ __device__ inline int knn_search(const float4 Q, int kk, unsigned long long kmas
                 const int w = w0 + lane;
                 unsigned cs = 0, cnt = 0;
                 if (w < rows) {
-                    const int dy = w % side - r, dz = w / side - r;
+                    const int wz = (int)(((float)w + 0.5f) * inv_side);
+                    const int dy = (w - wz * side) - r, dz = wz - r;
                     const int y = cy + dy, z = cz + dz;
                     const bool inner = r >= 2 && dy > -r && dy < r && dz > -r && dz < r;
                     if (y >= 0 && y < g.ny && z >= 0 && z < g.nz && (pass == 0 || inner)) {
@@ -2926,6 +2994,20 @@ int gsicp_gicp_last_align_stats(gsicp_gicp* g, double out[6]) {
     return 0;
 }
 int gsicp_gicp_debug_abort_next_align(gsicp_gicp* g) { g->inject_abort = true; return 0; }
+int gsicp_debug_wave_sort(const float* d, const int* id, float* out_d, int* out_id, int* out_xor) {
+    if (!d || !id || !out_d || !out_id || !out_xor) { g_last_error = "gsicp_debug_wave_sort: null pointer"; return -2; }
+    DevBuf<float> dd, od;
+    DevBuf<int> di, oi, ox;
+    if (dd.ensure(64) || od.ensure(64) || di.ensure(64) || oi.ensure(64) || ox.ensure(7 * 64)) { g_last_error = "hipMalloc failed"; return -1; }
+    GC(hipMemcpy(dd.p, d, 64 * sizeof(float), hipMemcpyHostToDevice));
+    GC(hipMemcpy(di.p, id, 64 * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(debug_wave_sort_kernel, dim3(1), dim3(64), 0, nullptr, dd.p, di.p, od.p, oi.p, ox.p);
+    GC(hipGetLastError());
+    GC(hipMemcpy(out_d, od.p, 64 * sizeof(float), hipMemcpyDeviceToHost));
+    GC(hipMemcpy(out_id, oi.p, 64 * sizeof(int), hipMemcpyDeviceToHost));
+    GC(hipMemcpy(out_xor, ox.p, 7 * 64 * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
 int gsicp_gicp_barrier_retries(gsicp_gicp* g) { return g->barrier_retries; }
 int gsicp_gicp_get_final_hessian(gsicp_gicp* g, double out[36]) { std::memcpy(out, g->host_result.H_final, sizeof(double) * 36); return 0; }
 

@@ -235,6 +235,9 @@ int gsicp_gicp_last_align_stats(gsicp_gicp*, double out[6]);
  * as ONE workgroup, which needs no grid barrier.  gsicp_gicp_barrier_retries() counts such re-runs; gsicp_gicp_debug_abort_next_align()
  * is a test hook that makes the next align's first barrier abort, so that the recovery path can be exercised deterministically. */
 int gsicp_gicp_debug_abort_next_align(gsicp_gicp* g);
+/* Test hook: sorts 64 (squared distance >= 0, id >= 0) pairs with the wave-wide network the k-NN kernels use (ascending by distance, then
+ * id) and returns, for J in {1, 2, 4, 8, 15, 16, 32}, what lane l reads from lane l ^ J when every lane holds 3 l + 1 (out_xor[7][64]). */
+int gsicp_debug_wave_sort(const float* d, const int* id, float* out_d, int* out_id, int* out_xor);
 int gsicp_gicp_barrier_retries(gsicp_gicp* g);
 int gsicp_gicp_get_final_hessian(gsicp_gicp*, double out[36]);
 

@@ -73,3 +73,34 @@ def test_dist2_from_two_streams_back_to_back():
     torch.cuda.synchronize()
     for c, (_t, o) in zip(clouds, outs):
         np.testing.assert_allclose(o.cpu().numpy(), oracle.knn_dist2(c), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_wave_sorting_network_and_lane_exchanges():
+    """The k-NN kernels keep their candidate lists with a 64-lane bitonic network made of DPP / permlane exchanges on packed
+    (distance bits << 32 | id) keys.  Known answers: every exchange pattern returns the value of lane l ^ J, and the network sorts any
+    64 pairs — random, heavy ties (broken by id), idle pairs (FLT_MAX, INT_MAX), already sorted, reversed — exactly as a lexicographic sort."""
+    import ctypes
+    from gs_icp_slam_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    fmax, imax = np.float32(np.finfo(np.float32).max), np.int32(2**31 - 1)
+    cases = []
+    cases.append((rng.random(64, dtype=np.float32) * 10, rng.permutation(64).astype(np.int32)))
+    cases.append((rng.integers(0, 3, 64).astype(np.float32), rng.permutation(1000)[:64].astype(np.int32)))          # three distinct distances
+    cases.append((np.zeros(64, np.float32), rng.permutation(64).astype(np.int32)[::-1].copy()))                     # all tied: order by id
+    d = rng.random(64, dtype=np.float32); i = rng.permutation(64).astype(np.int32); d[20:] = fmax; i[20:] = imax      # mostly idle lanes
+    cases.append((d, i))
+    cases.append((np.arange(64, dtype=np.float32), np.arange(64, dtype=np.int32)))
+    cases.append((np.arange(64, dtype=np.float32)[::-1].copy(), np.arange(64, dtype=np.int32)))
+    cases.append((np.float32(1e-30) * rng.random(64, dtype=np.float32), rng.permutation(2**20)[:64].astype(np.int32)))   # denormal-range distances
+    for d, i in cases:
+        od, oi, ox = np.empty(64, np.float32), np.empty(64, np.int32), np.empty((7, 64), np.int32)
+        rc = lib.gsicp_debug_wave_sort(d.ctypes.data_as(ctypes.c_void_p), i.ctypes.data_as(ctypes.c_void_p), od.ctypes.data_as(ctypes.c_void_p),
+                                       oi.ctypes.data_as(ctypes.c_void_p), ox.ctypes.data_as(ctypes.c_void_p))
+        _lib.check(rc, "gsicp_debug_wave_sort")
+        lanes = np.arange(64)
+        for row, J in enumerate((1, 2, 4, 8, 15, 16, 32)):
+            assert np.array_equal(ox[row], 3 * (lanes ^ J) + 1), f"exchange pattern {J}"
+        order = np.lexsort((i, d))
+        assert np.array_equal(od, d[order]) and np.array_equal(oi, i[order])
