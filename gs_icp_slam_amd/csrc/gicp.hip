@@ -784,11 +784,11 @@ __device__ __forceinline__ unsigned lane_xor(unsigned v, int lane) {
     else if constexpr (J == 15) return (unsigned)__builtin_amdgcn_update_dpp(0, iv, 0x140, 0xF, 0xF, true);    // row_mirror
     else if constexpr (J == 16) {
         const gi_uint2_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false);    // x: rows (0, 0, 2, 2) of v, y: rows (1, 1, 3, 3)
-        return (lane & 16) ? r.x : r.y;
+        return __builtin_amdgcn_inverse_ballot_w64(0xFFFF0000FFFF0000ull) ? r.x : r.y;
     } else {
         static_assert(J == 32, "lane_xor: unsupported pattern");
         const gi_uint2_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false);    // x: lower half of v twice, y: upper half twice
-        return (lane & 32) ? r.x : r.y;
+        return __builtin_amdgcn_inverse_ballot_w64(0xFFFFFFFF00000000ull) ? r.x : r.y;
     }
 }
 template <int J>
@@ -796,10 +796,20 @@ __device__ __forceinline__ pair_key_t lane_xor_key(pair_key_t k, int lane) {
     return (pair_key_t)lane_xor<J>((unsigned)(k >> 32), lane) << 32 | (pair_key_t)lane_xor<J>((unsigned)k, lane);
 }
 // one compare-exchange of a bitonic network: partner = lane ^ J; blocks of K lanes alternate direction (K = 64: ascending everywhere)
+// lanes that keep the smaller key in the step (K, J): a compile-time wave mask, handed to the selects as a scalar constant
+// (computed from the lane id, the 21 masks of a sort cost ~120 vector instructions per wave and more scalar registers than there are)
+template <int K, int J>
+constexpr unsigned long long keep_min_mask() {
+    unsigned long long m = 0ull;
+    for (int l = 0; l < 64; ++l) {
+        const bool up = K >= 64 || (l & K) == 0;
+        if (((l & J) == 0) == up) m |= 1ull << l;
+    }
+    return m;
+}
 template <int K, int J>
 __device__ __forceinline__ void cx_step(pair_key_t& k, int lane) {
-    const bool up = K >= 64 || (lane & K) == 0;
-    const bool keep_min = ((lane & J) == 0) == up;
+    const bool keep_min = __builtin_amdgcn_inverse_ballot_w64(keep_min_mask<K, J>());
     if constexpr (J >= 16) {
         // the swap instructions hand BOTH partners to both lanes of a pair (a: the key of the lane with bit J clear, b: of the lane with it
         // set), so the step is a min / max of (a, b) — no second copy of the key, no select to rebuild "the other lane's key"
