@@ -11,6 +11,7 @@ BENCH="python $ROOT/bench.py --steps 30 --warmup 5 --repeats 3 --no-cpu-baseline
 cd /tmp
 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 python $ROOT/bench.py --no-legs --no-cpu-baseline > $OUT/bench_second_run.json 2>> $OUT/bench.err
+python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_cmd.json 2>> $OUT/bench.err     # the driver's command (round 3's BENCH record)
 python $ROOT/bench.py --res tum --no-cpu-baseline --no-legs > $OUT/bench_tum.json 2>> $OUT/bench.err
 python $ROOT/bench.py --tracker pair --pair survey --no-cpu-baseline --no-legs > $OUT/bench_pair_survey.json 2>> $OUT/bench.err
 python $ROOT/bench.py --tracker pair --pair basin --no-cpu-baseline --no-legs > $OUT/bench_pair_basin.json 2>> $OUT/bench.err

@@ -87,7 +87,7 @@ def main():
     for name in ("bench", "bench_tum", "bench_basin", "bench_eager", "bench_under_rocprof", "reference_run_replica", "reference_run_tum_shaped",
                  "reference_run_unlimit400", "reference_run_limit30_300", "reference_run_tum_layout60", "bench_gpus2_gloo_one_gpu",
                  "mfma_cov_experiment", "bench_mapper_only", "bench_tracker_only", "bench_force_collectives", "rccl_graph_probe",
-                 "bench_pair_survey", "bench_pair_basin", "tracker_vs_map", "reference_run_fused_unlimit400", "reference_run_fused_limit30_300",
+                 "bench_pair_survey", "bench_pair_basin", "bench_driver_cmd", "tracker_vs_map", "reference_run_fused_unlimit400", "reference_run_fused_limit30_300",
                  "reference_run_unlimit1500", "reference_run_fused_unlimit1500"):
         j = last_json_line(os.path.join(src, name + ".json"))
         if j is not None:
