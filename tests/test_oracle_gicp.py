@@ -119,3 +119,69 @@ def test_knn_oracle_is_invariant_to_point_order():
     perm = rng.permutation(len(pts))
     a, b = oracle.knn_dist2(pts), oracle.knn_dist2(pts[perm])
     np.testing.assert_allclose(b, a[perm], rtol=1e-6, atol=0)
+
+
+def _sym(c6):
+    c = np.zeros((len(c6), 3, 3))
+    c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2] = c6.T
+    c[:, 1, 0], c[:, 2, 0], c[:, 2, 1] = c[:, 0, 1], c[:, 0, 2], c[:, 1, 2]
+    return c
+
+
+def test_converged_pose_is_a_stationary_point_of_the_published_gicp_objective():
+    """Independent of the oracle's Jacobians, its LM damping and its linear solve: at the pose the oracle converges to (tiny epsilons), with the
+    correspondences and Mahalanobis matrices of that pose held fixed as fast_gicp does within an iteration, the published objective
+    sum_i d_i^T (C_B,i + R C_A,i R^T)^-1 d_i, d_i = b_i - T a_i, written out here in numpy, has a vanishing gradient (central differences over
+    the six twist coordinates) and does not decrease under small random perturbations — on NOISY clouds with anisotropic covariances, where a
+    wrong weighting or a wrong residual sign would still recover a noise-free known motion but not sit on this stationary point."""
+    rng = np.random.default_rng(7)
+    n = 2500
+    tgt = np.concatenate([np.c_[rng.uniform(-1, 1, (n, 2)), np.zeros(n)], np.c_[rng.uniform(-1, 1, n), np.zeros(n), rng.uniform(0, 1, n)],
+                          np.c_[np.zeros(n), rng.uniform(-1, 1, n), rng.uniform(0, 1, n)]]) + 0.004 * rng.standard_normal((3 * n, 3))
+    motion = synth.se3((0.5, -0.7, 0.3), (0.008, -0.01, 0.012))
+    pick = rng.permutation(3 * n)[:3000]
+    src = ((tgt[pick] + 0.004 * rng.standard_normal((3000, 3)) - motion[:3, 3]) @ motion[:3, :3]).astype(np.float32)
+    tgt = tgt.astype(np.float32)
+    gate = 0.08
+    reg = oracle.OracleGICP()
+    reg.set_max_correspondence_distance(gate)
+    reg.set_max_knn_distance(99999.0)
+    reg.set_max_iterations(200)
+    reg.set_rotation_epsilon(1e-10)
+    reg.set_transformation_epsilon(1e-10)
+    reg.set_input_target(tgt)
+    reg.calculate_target_covariance_with_filter()
+    reg.set_input_source(src)
+    reg.calculate_source_covariance()
+    T = np.asarray(reg.align(np.eye(4)), np.float64)
+    idx, d2 = reg.get_source_correspondence()
+    CA, CB = _sym(reg.get_source_covariances()), _sym(reg.get_target_covariances())
+    used = np.flatnonzero((idx >= 0) & (d2 < gate * gate * 0.98))          # clear of the gate's edge (the pose returned is rounded to float32)
+    assert len(used) > 2000
+    a, b = src[used].astype(np.float64), tgt[idx[used]].astype(np.float64)
+    R = T[:3, :3]
+    M = np.linalg.inv(CB[idx[used]] + R @ CA[used] @ R.T)
+
+    def cost(xi):
+        w, v = xi[:3], xi[3:]
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        dR = np.eye(3) if th == 0 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+        d = b - ((a @ R.T + T[:3, 3]) @ dR.T + v)
+        return float(np.einsum("ni,nij,nj->", d, M, d))
+
+    def grad(at):
+        g = np.zeros(6)
+        for k in range(6):
+            e = np.zeros(6); e[k] = 1e-6
+            g[k] = (cost(at + e) - cost(at - e)) / 2e-6
+        return g
+
+    g0 = grad(np.zeros(6))
+    g_off = grad(np.array([1e-3, -1e-3, 1e-3, 1e-3, 1e-3, -1e-3]))          # the scale of the gradient a millimetre / millirad away
+    assert np.linalg.norm(g0) < 1e-5 * np.linalg.norm(g_off), (g0, g_off)     # measured 3.6e-7; weighting by C_B alone gives 0.15
+    c0 = cost(np.zeros(6))
+    for _ in range(20):
+        assert cost(2e-4 * rng.standard_normal(6)) >= c0 * (1 - 1e-9)
+    ang, mm = pose_err(T, motion)
+    assert ang < 0.05 and mm < 1.0, (ang, mm)
