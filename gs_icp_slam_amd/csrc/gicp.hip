@@ -614,7 +614,7 @@ inline void enqueue_knn_grid_build(hipStream_t stream, int n, const float4* pts,
     hipLaunchKernelGGL(knn_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, pts, cell_of, cell_fill, sorted);
 }
 
-// Tracker-sized clouds (<= KNN_FUSED_MAX_N points: 8-12 k per frame): the four launches above as ONE single-workgroup kernel — bounding box,
+// Tracker-sized clouds (<= KNN_FUSED_MAX_N points: 8-12 k per frame): the launches above as ONE single-workgroup kernel — bounding box,
 // grid parameters, counting sort with the cell counters in LDS (global memory when the grid has more than KNN_LDS_CELLS cells), exclusive
 // scan, fill.  Same parameters, same cell assignment, same cell_start table as the multi-launch path (the order of the points inside a
 // cell is arbitrary in both; the search result does not depend on it).  Three kernel boundaries (~4 us each plus their launch gaps) less

@@ -522,7 +522,7 @@ def test_map_sized_target_with_points_beyond_the_gate():
 
 
 def test_knn_covariances_of_a_map_sized_cloud():
-    """`calculate_target_covariance_with_filter` above the single-workgroup grid build (> 32 768 points: the four-launch counting sort) on a
+    """`calculate_target_covariance_with_filter` above the single-workgroup grid build (> 32 768 points: the six-launch chip-wide counting sort) on a
     1e5-point multi-keyframe cloud: exported scales / covariances equal the oracle's kd-tree k-NN to summation-order tolerance."""
     import pygicp
     cloud = synth.tracker_map_cloud(100_000, n_keyframes=6, seed=9)
