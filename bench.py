@@ -110,6 +110,137 @@ def _measure_pmc_traffic(kernel_substr, timeout=120.0):
     return out, None
 
 
+def trained_map_leg(dev, steps=100, reps=3, n_views=8, cache=None):
+    """legs.mapper_trained_map: the mapper iteration on a TRAINED map — the map tools/slam_demo.py builds on the 240-frame synthetic
+    sequence (>= 1 500 Adam steps, keyframe growth, pruning: ~209 k Gaussians of which 80-97 % are visible per view, D = 1.2-1.4 M duplicates, tile
+    lists of 390 mean / 870 max — the mapper's real workload [REF mp_Mapper.py:200-223], 5x the duplicates of the untrained S-map surfels of the
+    headline) —, one hipGraph replay per iteration cycling `n_views` of the run's own keyframe poses (targets: render of a perturbed copy from each pose, so
+    gradients are non-zero).  The map is built once per box (`cache`, ~30 s: 240 ray-cast frames + the loop) by a child process.  Reports ms per
+    iteration, the kernels' hipEvent times, D / P_vis / longest list per view and the SURVEY 8(d) roofline entry of R7 at that D."""
+    import subprocess
+    import torch
+    from gs_icp_slam_amd import _lib, synth
+    from gs_icp_slam_amd.graph import MapperIterationGraph
+    from gs_icp_slam_amd.optim import FusedAdam
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    cache = cache or os.environ.get("GSICP_TRAINED_MAP", "/tmp/gsicp_trained_map.npz")
+    t_build = 0.0
+    if not os.path.exists(cache):
+        t0 = time.perf_counter()
+        tmp = cache + f".{os.getpid()}.npz"
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "slam_demo.py"), "240", "--iters", "6", "--post-iters", "200", "--no-asserts", "--save-map", tmp],
+                       check=True, cwd=ROOT, stdout=subprocess.DEVNULL, timeout=900, env=dict(os.environ, GSICP_BENCH_CHILD="1"))
+        os.replace(tmp, cache)
+        t_build = time.perf_counter() - t0
+    z = np.load(cache)
+    g = {k: np.ascontiguousarray(z[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    P = g["means3D"].shape[0]
+    poses = z["keyframe_poses"]
+    cfg = synth.REPLICA
+    W, H = cfg["W"], cfg["H"]
+    pick = sorted({int(round(i * (len(poses) - 1) / max(1, n_views - 1))) for i in range(n_views)})
+    raw = {"means3D": torch.from_numpy(g["means3D"]), "scales": torch.log(torch.from_numpy(g["scales"])), "rotations": torch.from_numpy(g["rotations"]),
+           "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-6, 1 - 1e-6)), "shs": torch.from_numpy(g["shs"])}
+    params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in raw.items()}
+    rng = np.random.default_rng(5)
+    with torch.no_grad():     # targets: the same map with colours and positions nudged (gradients of a map that is still learning)
+        t2 = {"means3D": params["means3D"] + torch.from_numpy(rng.normal(0, 2e-3, (P, 3)).astype(np.float32)).to(dev),
+              "shs": params["shs"] + torch.from_numpy(rng.normal(0, 0.05, tuple(params["shs"].shape)).astype(np.float32)).to(dev),
+              "opacities": torch.from_numpy(g["opacities"]).to(dev), "scales": torch.from_numpy(g["scales"]).to(dev), "rotations": params["rotations"].detach()}
+    lib = _lib.load()
+    import ctypes
+    views = []
+    for k in pick:
+        cam = synth.make_camera(W, H, cfg["fx"], cfg["fy"], poses[k])
+        rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=torch.zeros(3, device=dev),
+                                           scale_modifier=1.0, viewmatrix=torch.from_numpy(cam["viewmatrix"]).to(dev), projmatrix=torch.from_numpy(cam["projmatrix"]).to(dev),
+                                           sh_degree=0, campos=torch.from_numpy(cam["campos"]).to(dev), prefiltered=False, debug=False)
+        with torch.no_grad():
+            gd, gc, _, _ = GaussianRasterizer(rs)(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"], opacities=t2["opacities"],
+                                                  scales=t2["scales"], rotations=t2["rotations"])
+        # D, P_vis and the tile lists of the map itself from this pose (the product's own ranges, read from the forward's image scratch)
+        m3 = params["means3D"].detach().requires_grad_(True)
+        d_, c_, radii, _u = GaussianRasterizer(rs)(means3D=m3, means2D=torch.zeros_like(m3), shs=params["shs"].detach(), opacities=t2["opacities"],
+                                                   scales=t2["scales"], rotations=t2["rotations"])
+        saved = c_.grad_fn.saved_tensors
+        img = saved[9]
+        lay = (ctypes.c_size_t * 12)()
+        n_dup = int(c_.grad_fn.num_rendered)
+        lib.gsicp_raster_layout(P, n_dup, W, H, lay)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        ranges = img[lay[6]: lay[6] + T * 8].cpu().numpy().view(np.uint32).reshape(T, 2).astype(np.int64)
+        ln = ranges[:, 1] - ranges[:, 0]
+        views.append(dict(rs=rs, gt_color=gc.clone(), gt_depth=gd.clone(), keyframe=int(k), duplicates=n_dup, visible=int((radii > 0).sum()),
+                          longest_list=int(ln.max()), mean_list=round(float(ln.mean()), 1)))
+        del d_, c_, m3, saved, img
+    capacity = int(1.5 * max(v["duplicates"] for v in views)) + 4096
+    opt = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in LRS.items()], lr=0.0, eps=1e-15, capturable=True)
+    cam0 = synth.make_camera(W, H, cfg["fx"], cfg["fy"], poses[pick[0]])
+    mg = MapperIterationGraph(params, opt, H, W, cam0["tanfovx"], cam0["tanfovy"], sh_degree=0, capacity=capacity, lambda_dssim=0.2, warmup=2)
+    v0 = views[0]
+    mg.set_view(v0["rs"].viewmatrix, v0["rs"].projmatrix, v0["rs"].campos, v0["gt_color"], v0["gt_depth"])
+    mg.capture()
+    it = [0]
+
+    def iteration():
+        v = views[it[0] % len(views)]
+        it[0] += 1
+        mg.set_view(v["rs"].viewmatrix, v["rs"].projmatrix, v["rs"].campos, v["gt_color"], v["gt_depth"])
+        mg.step()
+    for _ in range(2 * len(views)):
+        iteration()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            iteration()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / steps)
+    if mg.overflowed() or mg.skipped_steps() > 0:
+        raise RuntimeError("trained-map leg: duplicate-list capacity overflowed")
+    # per-kernel hipEvent times: the same kernels launched eagerly (one bracket per kernel), over the same view cycle
+    rasts = [GaussianRasterizer(v["rs"]._replace(capacity=capacity, raw_params=True)) for v in views]
+    opt_e = FusedAdam([{"params": [params[k]], "lr": lr} for k, lr in LRS.items()], lr=0.0, eps=1e-15)
+    from gs_icp_slam_amd.loss import mapper_loss_and_grads
+
+    def eager(i):
+        v, r = views[i % len(views)], rasts[i % len(views)]
+        m2 = torch.zeros_like(params["means3D"], requires_grad=True)
+        depth, color, _r, _u2 = r(means3D=params["means3D"], means2D=m2, shs=params["shs"], opacities=params["opacities"], scales=params["scales"],
+                                  rotations=params["rotations"])
+        parts, gc_, gd_ = mapper_loss_and_grads(color, depth, v["gt_color"], v["gt_depth"], lambda_dssim=0.2)
+        torch.autograd.backward((color, depth), (gc_, gd_))
+        opt_e.step()
+        opt_e.zero_grad(set_to_none=True)
+    _lib.profile_enable(True)
+    eager(0)
+    torch.cuda.synchronize()
+    _lib.profile_read()
+    n_e = 2 * len(views)
+    for i in range(n_e):
+        eager(i)
+    torch.cuda.synchronize()
+    stage = {k: round(1e3 * ms / n_e, 2) for k, (ms, c) in _lib.profile_read().items() if c > 0 and not k.startswith("gicp")}
+    _lib.profile_enable(False)
+    D = sum(v["duplicates"] for v in views) / len(views)
+    Pv = sum(v["visible"] for v in views) / len(views)
+    b_r7 = 44.0 * D + 40.0 * W * H + 44.0 * Pv
+    us_r7 = stage.get("blend_backward", float("nan"))
+    ach = b_r7 / (us_r7 * 1e-6) / 1e9
+    ms_it = statistics.median(ts) * 1e3
+    mg.release()
+    return {"ms_per_iteration": round(ms_it, 4), "iterations_per_s": round(1e3 / ms_it, 1), "block_ms": [round(1e3 * t, 4) for t in ts],
+            "gaussians": P, "keyframe_poses_in_the_map": int(len(poses)), "mapper_iterations_that_trained_it": int(z["mapper_iterations"]),
+            "views": [{k: v[k] for k in ("keyframe", "duplicates", "visible", "longest_list", "mean_list")} for v in views],
+            "duplicates_mean": int(D), "visible_mean": int(Pv), "stage_us": stage, "map_build_s": round(t_build, 1),
+            "roofline_trained": {"bound": "hbm", "kernel": "blend_backward_tile_kernel (R7)", "kernel_us": us_r7, "algorithmic_bytes": int(b_r7),
+                                 "byte_model": "SURVEY 8(d): 44 D + 40 W H + 44 P_vis", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(ach / HBM_PEAK_GBS, 5)},
+            "what": "one hipGraph replay per iteration on the map tools/slam_demo.py trains (240 frames, 6 iterations per frame + 200), cycling keyframe poses of that run; "
+                    "stage_us = hipEvent brackets in eager iterations over the same cycle"}
+
+
 def tracker_vs_map_leg(sizes=(8280, 100_000, 1_000_000), frames=60, fid=155, back=1):
     """The tracker in its STEADY-STATE configuration [REF mp_Tracker.py:282-288; scene/gaussian_model.py:207-215]: the target is the map's
     trackable Gaussians (K of them, out of 2K rows: half fail the opacity / trackable selection), handed over at a tracking keyframe either
@@ -252,7 +383,7 @@ def main():
     ap.add_argument("--lockstep", action="store_true", help="join the tracker frame and the mapper iteration after EVERY step (round 1's timing loop) instead of "
                     "letting the two halves run their --steps steps at their own pace inside the timed block")
     ap.add_argument("--no-graph", action="store_true", help="drive the mapper iteration eagerly from Python instead of replaying the captured HIP graph")
-    ap.add_argument("--only", choices=["tracker", "mapper"], default=None, help="diagnostics: run only one half (the JSON line is then NOT the contract metric)")
+    ap.add_argument("--only", choices=["tracker", "mapper", "trained"], default=None, help="diagnostics: run only one half (the JSON line is then NOT the contract metric)")
     ap.add_argument("--mp-mode", choices=["tiles", "keyframes"], default="tiles",
                     help="N > 1 GPUs: `tiles` (default) = ONE view per step, its screen tiles sharded over the ranks (same optimiser trajectory as 1 GPU: "
                          "strong scaling); `keyframes` = every rank renders its OWN view, one dense gradient all-reduce, N views per optimiser step "
@@ -344,6 +475,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.only == "trained":     # diagnostic: legs.mapper_trained_map alone (what tools/capture_profiles.sh runs under rocprofv3)
+        leg = trained_map_leg(dev, steps=args.steps, reps=max(1, min(args.repeats, 3)), n_views=args.views)
+        print(json.dumps({"metric": "DIAGNOSTIC: mapper iteration on the trained map (legs.mapper_trained_map)", "value": leg["iterations_per_s"], "unit": "iterations/s",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": leg["ms_per_iteration"], "higher_is_better": True,
+                          "dtype": "f32", "data": "synthetic", "legs": {"mapper_trained_map": leg}}))
+        return 0
     cfg = synth.REPLICA if args.res == "replica" else synth.TUM
     W, H = cfg["W"], cfg["H"]
     P = args.gaussians
@@ -1053,6 +1190,27 @@ def main():
                                          "what": "torch activations + synchronous GaussianRasterizer + torch l1/ssim + loss.backward() + torch.optim.Adam "
                                                  "(the statements of unmodified mp_Mapper.py:219-248)"}
         del rp, topt
+        # -- the mapper iteration where D is REAL: the map the fused loop trains (5x the duplicates of the S-map surfels)
+        if args.res == "replica" and os.environ.get("GSICP_BENCH_TRAINED_LEG", "1") != "0":
+            try:
+                legs["mapper_trained_map"] = trained_map_leg(dev, steps=100, reps=3, n_views=args.views)
+            except Exception as e:   # noqa: BLE001 — a leg must not take the contract line with it
+                legs["mapper_trained_map"] = {"status": "failed", "why": f"{type(e).__name__}: {e}"[:400]}
+        # -- BASELINE configs[3]'s proxy: the same steady-state step at TUM's shape (640x480, 12 416-point noisy frames, gate 0.03, opacity threshold
+        #    0.09 [REF tum.sh:135-142]) — a child run of this script, its contract line kept as the leg
+        if args.res == "replica" and os.environ.get("GSICP_BENCH_CHILD") != "1" and os.environ.get("GSICP_BENCH_TUM_LEG", "1") != "0":
+            import subprocess
+            try:
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--res", "tum", "--no-legs", "--no-cpu-baseline", "--steps", str(args.steps),
+                                     "--warmup", str(args.warmup), "--repeats", "3"], capture_output=True, text=True, timeout=300,
+                                    env=dict(os.environ, GSICP_BENCH_CHILD="1"))
+                line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                tj = json.loads(line[-1])
+                legs["step_tum"] = {k: tj.get(k) for k in ("value", "unit", "ms_per_step", "block_ms_per_step_p10_p50_p90", "pose_error_deg_mm", "stage_us_per_step")}
+                legs["step_tum"].update(workload=tj["config"]["workload"], duplicates_per_view=tj["config"]["duplicates_per_view"],
+                                        tracker_target_gaussians=tj["config"]["tracker_target_gaussians"])
+            except Exception as e:   # noqa: BLE001
+                legs["step_tum"] = {"status": "failed", "why": f"{type(e).__name__}: {e}"[:400]}
 
     # ---------------- CPU baseline: OpenMP GICP oracle (port), rank 0 only ----------------
     cpu = None
@@ -1101,6 +1259,7 @@ def main():
     # System FPS [REF mp_Tracker.py:333] and ATE (the reference's mean statistic [REF mp_Tracker.py:334, 479] and a true RMSE) of the unmodified
     # gs_icp_slam_unlimit.py on a 400-frame synthetic Replica-layout sequence, PSNR / SSIM of its end-of-run pass [REF mp_Mapper.py:335-422]
     ref_run = ref_run_fused = None
+    noisy_runs = {}
     if rank == 0 and world == 1 and args.only is None and not args.no_reference_leg and not args.no_legs and os.environ.get("GSICP_BENCH_CHILD") != "1":
         import subprocess
         torch.cuda.synchronize()
@@ -1123,6 +1282,20 @@ def main():
                 ref_run_fused = json.loads(line[-1]) if line else {"status": "failed", "why": (pr.stderr or pr.stdout)[-400:]}
             except Exception as e:   # noqa: BLE001
                 ref_run_fused = {"status": "failed", "why": f"{type(e).__name__}: {e}"}
+        # the same pair on NOISY depth (sensor model sigma(z) = 1.2 mm + 1.9 mm (z - 0.4)^2, 15 % holes) with fast hand-held motion: the bar of VERDICT r4
+        # item 1 — the fused system (default pacing: refglue.DEFAULT_ITERS_PER_FRAME) must keep the untouched system's ATE
+        for fused_ in (False, True):
+            if os.environ.get("GSICP_BENCH_NOISY_LEG", "1") == "0" or (fused_ and ref_run_fused is None):
+                continue
+            try:
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_slam.py"), "--synthetic", "300", "--noise", "--speed", "2", "--jitter", "0.003",
+                                     "--cache", "/tmp/gsicp_synth_cache", "--timeout", "240"] + (["--fused"] if fused_ else []), capture_output=True, text=True, timeout=420,
+                                    env=dict(os.environ, GSICP_ATE_DETAIL="1"))
+                line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+                rj = json.loads(line[-1]) if line else {"status": "failed", "why": (pr.stderr or pr.stdout)[-400:]}
+            except Exception as e:   # noqa: BLE001
+                rj = {"status": "failed", "why": f"{type(e).__name__}: {e}"}
+            noisy_runs["fused" if fused_ else "untouched"] = rj
 
     # ---------------- multi-GPU bookkeeping ----------------
     ranks_seen = None
@@ -1179,6 +1352,11 @@ def main():
             # (400-frame synthetic Replica-layout sequence, gs_icp_slam_unlimit.py, replica.sh's flags); the whole record is legs.reference_system_run
             "system_fps": rr.get("system_fps"), "ate_cm": rr.get("ate_rmse_cm"), "ate_true_rmse_cm": rr.get("ate_true_rmse_cm"), "psnr": rr.get("psnr"),
             "ssim": rr.get("ssim"), "processes_that_loaded_it": rr.get("processes_that_loaded_it"),
+            # the same system on noisy depth + fast motion (300 frames), untouched and with SURVEY 8(f)'s rows applied at the default pacing: the reference's
+            # printed statistic (mean aligned error) and the true RMSE
+            "ate_cm_noisy": noisy_runs.get("untouched", {}).get("ate_rmse_cm"), "ate_cm_noisy_fused": noisy_runs.get("fused", {}).get("ate_rmse_cm"),
+            "ate_true_rmse_cm_noisy": noisy_runs.get("untouched", {}).get("ate_true_rmse_cm"),
+            "ate_true_rmse_cm_noisy_fused": noisy_runs.get("fused", {}).get("ate_true_rmse_cm"),
             "config": {"workload": workload,
                        "tracker_workload": tkey, "tracker_motion": motions[tkey], "lm_iterations": it,
                        "tracker_target_gaussians": (trk.n_target if steady else None),
@@ -1216,7 +1394,8 @@ def main():
             "legs": legs, "roofline": roofline, "roofline_longest_kernel": roofline_align, "cpu_baseline": cpu,
         }
         if ref_run is not None:
-            out["legs"] = dict(out["legs"] or {}, reference_system_run=ref_run, reference_system_run_fused=ref_run_fused)
+            out["legs"] = dict(out["legs"] or {}, reference_system_run=ref_run, reference_system_run_fused=ref_run_fused,
+                               reference_system_run_noisy=noisy_runs.get("untouched"), reference_system_run_noisy_fused=noisy_runs.get("fused"))
         print(json.dumps(out))
     if worker is not None:
         jobs.put(None)

@@ -47,7 +47,10 @@ class MapperIterationGraph:
 
     def __init__(self, params, optimizer, image_height, image_width, tanfovx, tanfovy, sh_degree, capacity, bg=None, lambda_dssim=0.2,
                  depth_weight=0.1, d_max=10.0, activations=None, rasterizer_factory=None, warmup=2, live_count=None,
-                 depth_mode=0):
+                 depth_mode=0, grad_hook=None):
+        # grad_hook(params): optional, runs between the backward and the optimiser step INSIDE the captured iteration (static tensors only) —
+        # e.g. refglue's experiment knob that zeroes the geometry gradients of Gaussians the tracker aligns against.
+        self._grad_hook = grad_hook
         # activations=None (default): the rasteriser takes the RAW parameters and applies sigmoid / exp / normalize and their chain rule inside
         # its preprocess kernels (GaussianRasterizationSettings.raw_params) — two launches and 64 B per Gaussian of traffic less per iteration;
         # pass default_activations / torch_activations to run them as separate operators instead.
@@ -151,6 +154,8 @@ class MapperIterationGraph:
             parts = self.rasterizer.summed_loss()
         self.screenspace_grad = self._means2D.grad     # (P,3) viewspace gradient of this iteration (densification statistics)
         self._means2D.grad = None
+        if self._grad_hook is not None:
+            self._grad_hook(self.params)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return parts, radii, used

@@ -98,6 +98,7 @@ def patch_gaussian_model(cls):
 
 # ------------------------------------------------------------------------------------------------------------------ mp_Mapper.py
 _STAMPS = []
+_GPU_MS = []          # device time of the iterations (hipEvent pairs around set_view + the graph replay), whatever the pacing does to the cadence
 
 
 def _stamp(mapper):
@@ -113,8 +114,11 @@ def _stamp(mapper):
         def report():
             if len(_STAMPS) > 2:
                 d = sorted(b - a for a, b in zip(_STAMPS[:-1], _STAMPS[1:]))
+                g = sorted(_GPU_MS) or [float("nan")]
                 print(f"GSICP_FUSED_MAPPER iterations {len(_STAMPS)} median_ms {1e3 * d[len(d) // 2]:.4f} mean_ms {1e3 * sum(d) / len(d):.4f} "
-                      f"p90_ms {1e3 * d[int(0.9 * (len(d) - 1))]:.4f} captures {mapper.__dict__.get('_gsicp_captures', 0)} gaussians {mapper.gaussians._store.n}", flush=True)
+                      f"p90_ms {1e3 * d[int(0.9 * (len(d) - 1))]:.4f} captures {mapper.__dict__.get('_gsicp_captures', 0)} gaussians {mapper.gaussians._store.n} "
+                      f"gpu_median_ms {g[len(g) // 2]:.4f} gpu_p90_ms {g[int(0.9 * (len(g) - 1))]:.4f} paced_waits {mapper.gaussians.__dict__.get('_gsicp_paced', 0)} "
+                      f"iters_per_frame {os.environ.get('GSICP_FUSED_ITERS_PER_FRAME', str(DEFAULT_ITERS_PER_FRAME))}", flush=True)
         atexit.register(report)
     _STAMPS.append(time.perf_counter())
 
@@ -135,43 +139,96 @@ def fused_mapping_iteration(mapper, viewpoint_cam, gt_image, gt_depth_image):
                   "scales": store.params["scaling"], "rotations": store.params["rotation"]}
         if store.n_rest != 0:
             raise RuntimeError("fused mapping iteration: sh_degree > 0 needs the f_dc / f_rest concatenation inside the graph (not built: the reference runs sh_degree 0)")
+        # experiment knob (measured in profiles/r05_fused_pacing_sweep.json; NOT the reference's optimiser): free-run, but the
+        # Gaussians the tracker aligns against (the trackable rows) keep their position ("xyz") or position + shape ("geom") — their gradients are
+        # zeroed before Adam, so with zero moments they never move
+        freeze = os.environ.get("GSICP_FUSED_FREEZE_TRACKABLE", "")
+        hook = None
+        if freeze in ("xyz", "geom"):
+            keep = store._sets[0][("aux", "trackable_mask")]          # static full-capacity int32 0 / 1 (stable store)
+            names = ("means3D",) if freeze == "xyz" else ("means3D", "scales", "rotations")
+
+            def hook(p, keep=keep, names=names):
+                w = (1 - keep).to(torch.float32).unsqueeze(-1)
+                for nm in names:
+                    if p[nm].grad is not None:
+                        p[nm].grad.mul_(w)
         mg = MapperIterationGraph(params, gm.optimizer, H, W, math.tan(float(viewpoint_cam.FoVx[0]) * 0.5), math.tan(float(viewpoint_cam.FoVy[0]) * 0.5),
                                   sh_degree=gm.active_sh_degree, capacity=int(os.environ.get("GSICP_FUSED_LIST_CAPACITY", str(1 << 23))),
-                                  bg=mapper.background, lambda_dssim=mapper.lambda_dssim, warmup=1, live_count=store.live_count)
+                                  bg=mapper.background, lambda_dssim=mapper.lambda_dssim, warmup=1, live_count=store.live_count, grad_hook=hook)
         mg.set_view(viewpoint_cam.world_view_transform, viewpoint_cam.full_proj_transform, viewpoint_cam.camera_center, gt_image.contiguous(),
                     gt_depth_image.contiguous())
         mg.capture()                            # applies no optimiser update (the warm-up is rolled back)
         graphs[(H, W)] = mg
         mapper.__dict__["_gsicp_captures"] = mapper.__dict__.get("_gsicp_captures", 0) + 1
-    if mapper.train_iter % 200 == 0:            # the reference prunes BEFORE the step of these iterations [REF mp_Mapper.py:244-245]
+    if mapper.train_iter % 200 == 0:
+        # [REF mp_Mapper.py:243-248] prunes between loss.backward() and optimizer.step(); prune_points re-creates every Parameter, the fresh ones carry
+        # no .grad, so torch's Adam applies NOTHING on these iterations (1 in 200): the iteration's only lasting effect is the prune.  Same here.
         gm.prune_large_and_transparent(0.005, mapper.prune_th)
-    mg.set_view(viewpoint_cam.world_view_transform, viewpoint_cam.full_proj_transform, viewpoint_cam.camera_center, gt_image.contiguous(),
-                gt_depth_image.contiguous())
+        return mg.loss_parts[0]
+    _pace(mapper, gm)
     # Bounded run-ahead: a graph launch returns at once, so this loop could queue thousands of iterations ahead of the GPU — and the TRACKER process's
     # small kernels would wait behind them (measured without the bound: tracker 17 ms per frame, System FPS 66 instead of 167).  The reference's own
     # iteration is throttled by its synchronous forward; here at most `GSICP_FUSED_INFLIGHT` (2) replays are in flight.
-    # diagnostic (GSICP_FUSED_MIN_PERIOD_MS): hold the mapper to a minimum period per iteration, e.g. the untouched loop's 16.8 ms — separates
-    # "the fused iteration computes something else" from "a mapper that iterates 30x more often changes the map the tracker aligns against"
+    ring = gm.__dict__.setdefault("_gsicp_ring", [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                                  for _ in range(max(1, int(os.environ.get("GSICP_FUSED_INFLIGHT", "2"))))])
+    done = gm.__dict__.get("_gsicp_steps", 0)
+    begin, end = ring[done % len(ring)]
+    if done >= len(ring):
+        end.synchronize()
+        if len(_GPU_MS) < 100000:
+            _GPU_MS.append(begin.elapsed_time(end))
+    begin.record()
+    mg.set_view(viewpoint_cam.world_view_transform, viewpoint_cam.full_proj_transform, viewpoint_cam.camera_center, gt_image.contiguous(),
+                gt_depth_image.contiguous())
+    loss = mg.step()
+    end.record()
+    gm.__dict__["_gsicp_steps"] = done + 1
+    if done % 10 == 9 and mg.ensure_capacity():
+        # duplicate lists outgrown: at most ten replays rendered nothing and had their optimiser steps skipped ON THE DEVICE (nothing drifted); the lists
+        # are enlarged and the iteration re-captured.  The skipped steps are NOT repeated on the current view: the loop simply goes on.
+        mapper.__dict__["_gsicp_captures"] = mapper.__dict__.get("_gsicp_captures", 0) + 1
+    return loss
+
+
+# Default iteration budget of the in-system fused mapper, in Adam steps per TRACKED FRAME.  The reference's mapper free-runs [REF mp_Mapper.py:150-262]
+# and its speed decides how far the map has been optimised when the tracker next re-targets on it [REF mp_Tracker.py:282-288]: on the box this was
+# measured on, the untouched loop fits 0.3-2 iterations into a tracked frame, the fused one 7-50.  On noisy depth that is not neutral — ATE grows
+# with the iteration count (profiles/r05_fused_pacing_sweep.json) — so the DEFAULT keeps the fused system at the reference's iterations-per-frame
+# scale and leaves the GPU time it frees to the tracker; `GSICP_FUSED_ITERS_PER_FRAME=0` free-runs.
+DEFAULT_ITERS_PER_FRAME = 2.0
+
+
+def _pace(mapper, gm):
+    """Pacing policy of the fused mapper: hold the loop to `k` optimiser steps per frame the tracker has consumed (the shared frame counter
+    [REF gs_icp_slam.py:95; mp_Tracker.py:117]).  Every call of fused_mapping_iteration still performs exactly ONE iteration — the loop's own
+    bookkeeping (new keyframes trained once first, train_iter, the prune cadence) is untouched; pacing only delays it.  The wait ends at once when
+    the tracker raises a keyframe flag or the end of the dataset (it blocks on the mapper there [REF mp_Tracker.py:285-286]) and is bounded
+    (`GSICP_FUSED_MAX_WAIT_MS`) so a stalled frame counter cannot hang the mapper.  `GSICP_FUSED_MIN_PERIOD_MS` (a wall-clock period) is kept
+    as a second, diagnostic knob."""
+    import time
     period = float(os.environ.get("GSICP_FUSED_MIN_PERIOD_MS", "0"))
     if period > 0:
-        import time
         t_prev = gm.__dict__.get("_gsicp_t_prev")
         if t_prev is not None:
             wait = t_prev + 1e-3 * period - time.perf_counter()
             if wait > 0:
                 time.sleep(wait)
         gm.__dict__["_gsicp_t_prev"] = time.perf_counter()
-    ring = gm.__dict__.setdefault("_gsicp_ring", [torch.cuda.Event() for _ in range(max(1, int(os.environ.get("GSICP_FUSED_INFLIGHT", "2"))))])
-    slot = mapper.train_iter % len(ring)
-    if mapper.train_iter >= len(ring):
-        ring[slot].synchronize()
-    loss = mg.step()
-    ring[slot].record()
-    if mapper.train_iter % 50 == 49:            # duplicate lists outgrown: steps were skipped on the device; enlarge, re-capture, repeat them
-        lost = mg.ensure_capacity()
-        for _ in range(lost):
-            mg.step()
-    return loss
+    k = float(os.environ.get("GSICP_FUSED_ITERS_PER_FRAME", str(DEFAULT_ITERS_PER_FRAME)))
+    frames = getattr(mapper, "iter_shared", None)
+    flags = [getattr(mapper, n, None) for n in ("end_of_dataset", "is_tracking_keyframe_shared", "is_mapping_keyframe_shared")]
+    if k <= 0 or frames is None or any(f is None for f in flags):
+        return
+    done = gm.__dict__.get("_gsicp_steps", 0)
+    burst = float(os.environ.get("GSICP_FUSED_BURST", "8"))          # the first keyframe's iterations, before any frame has been counted
+    deadline = time.perf_counter() + 1e-3 * float(os.environ.get("GSICP_FUSED_MAX_WAIT_MS", "250"))
+    waited = False
+    while done >= burst + k * (int(frames[0]) + 1) and not any(int(f[0]) for f in flags) and time.perf_counter() < deadline:
+        time.sleep(5e-5)
+        waited = True
+    if waited:
+        gm.__dict__["_gsicp_paced"] = gm.__dict__.get("_gsicp_paced", 0) + 1
 
 
 # ------------------------------------------------------------------------------------------------------------------ scene/shared_objs.py
