@@ -952,7 +952,7 @@ def main():
         b_bwd = b_r7 + 184.0 * P                                                # + R8/R9
         b_fwd = 128.0 * P + D_local * (64.0 + 24.0 * n_pass) + 24.0 * WHr + 8.0 * Tr
         fwd_stages = ["preprocess", "emit", "split_hist", "split_colscan", "tile_scan_lpt", "split_scatter", "tile_sort", "blend_forward"]
-        bwd_stages = ["blend_backward", "preprocess_backward"]
+        bwd_stages = ["blend_backward", "entry_run_sum", "preprocess_backward"]
         us_r7 = per_launch_us.get("blend_backward", float("nan"))
         us_bwd = sum(per_launch_us.get(k, 0.0) for k in bwd_stages)
         us_fwd = sum(per_launch_us.get(k, 0.0) for k in fwd_stages)

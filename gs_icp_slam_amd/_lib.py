@@ -37,6 +37,7 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "gsicp_raster_mark_visible": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_raster_layout": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "gsicp_raster_set_legacy_backward": (c_int, [c_int]),
     "gsicp_knn_dist2": (c_int, [c_int, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_loss_scratch_bytes": (c_size_t, [c_int, c_int]),
     "gsicp_mapper_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p,

@@ -55,7 +55,7 @@ std::atomic<int> g_prof_enabled{0};
 // one-workgroup reduce); adam = adam_tensor_kernel (+ the one-thread step bump)
 const char* const g_stage_names[ST_COUNT] = {"preprocess", "tile_scan_lpt", "emit", "split_hist", "split_colscan", "split_scatter",
                                              "tile_sort", "blend_forward", "blend_backward", "preprocess_backward", "gicp_knn_cov",
-                                             "gicp_grid_build", "gicp_align", "gicp_exact_nn", "loss_pass1", "loss_pass2", "adam"};
+                                             "gicp_grid_build", "gicp_align", "gicp_exact_nn", "loss_pass1", "loss_pass2", "adam", "entry_run_sum"};
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -909,6 +909,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
         pa.tile_mod = tile_mod; pa.tile_rem = tile_rem;
         pa.rec = rec; pa.clamped = (unsigned char*)(geom + GL.clamped);
         pa.tiles_touched = tiles_touched; pa.slot_base = slot_base; pa.total_counter = total_counter;
+        pa.vis_list = (uint32_t*)(geom + GL.vis_list); pa.vis_counter = total_counter + 1;
         pa.radii = radii;
         { ProfileScope ps(ST_PREPROCESS, stream); launch_preprocess(pa, stream); }
         if (async) {
@@ -1083,13 +1084,19 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     pb.slot_base = (const uint32_t*)(geom_buffer + GL.slot_base);
     pb.tiles_touched = (const uint32_t*)(geom_buffer + GL.tiles_touched);
     pb.total_counter = total_counter; pb.capacity = (uint32_t)(num_rendered > 0 ? num_rendered : 0);
+    pb.entry_gauss = (const uint32_t*)(binning_buffer + BL.entry_gauss);
+    pb.vis_list = (const uint32_t*)(geom_buffer + GL.vis_list); pb.vis_counter = total_counter + 1;
+    pb.entry_sum_rw = entry_sum;
     pb.dL_dmean2D = dL_dmeans2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
     pb.dL_ddepths = dL_ddepths;
     pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = dL_dsh; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;
+    { ProfileScope ps(ST_RUN_SUM, stream); launch_entry_run_sum(pb, stream); }
     { ProfileScope ps(ST_PREPROCESS_BWD, stream); launch_preprocess_backward(pb, stream); }
     GS_CHECK(hipGetLastError());
     return 0;
 }
+
+int gsicp_raster_set_legacy_backward(int legacy) { return set_prebwd_legacy(legacy); }
 
 int gsicp_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                               unsigned char* present, void* stream) {

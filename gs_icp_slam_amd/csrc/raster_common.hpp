@@ -51,7 +51,7 @@ __host__ __device__ inline int tile_chunk_slots(int gx, int gy, int tile_mod) {
 }
 
 // Section offsets inside the three torch-owned scratch buffers.
-struct GeomLayout { size_t records, clamped, slot_base, tiles_touched, total; };
+struct GeomLayout { size_t records, clamped, slot_base, tiles_touched, vis_list, total; };
 struct BinLayout { size_t point_list, tile_keys, list_gauss, entry_gauss, entry_bits, emit_tile, emit_depth, scatter_keys, scatter_vals, block_hist, total; };
 constexpr int SPLIT_BLOCKS_MAX = 128;   // workgroups of the tile multi-split (each owns a contiguous chunk of emission slots)
 struct ImgLayout { size_t ranges, final_T, n_contrib, order, tile_count, total; };
@@ -64,6 +64,7 @@ inline GeomLayout geom_layout(int P) {
     L.clamped = o; o = align_up(o + Pp);
     L.slot_base = o; o = align_up(o + Pp * 4);        // first emission slot of each Gaussian (its slots are contiguous)
     L.tiles_touched = o; o = align_up(o + Pp * 4);    // number of emission slots (tiles of this rank it touches)
+    L.vis_list = o; o = align_up(o + Pp * 4);         // ids of the Gaussians with radii > 0 (work list of the backward's per-Gaussian pass)
     L.total = o;
     return L;
 }
@@ -112,6 +113,8 @@ struct PreprocessArgs {
     uint32_t* tiles_touched;
     uint32_t* slot_base;
     uint32_t* total_counter;   // [1] emission-slot allocator
+    uint32_t* vis_list;        // optional: ids of the Gaussians with radii > 0, compacted ...
+    uint32_t* vis_counter;     // ... and their number (zeroed with total_counter)
     int* radii;
 };
 static_assert(sizeof(SplatRec) == 48, "SplatRec must stay 48 bytes");
@@ -131,6 +134,9 @@ struct PreprocessBwdArgs {
     const uint32_t *slot_base, *tiles_touched;
     const uint32_t* total_counter;  // device R; above `capacity` the forward rendered nothing (async path overflow)
     uint32_t capacity;
+    const uint32_t* entry_gauss;    // emission slot -> Gaussian id (the run-sum pass finds the run boundaries in it)
+    const uint32_t *vis_list, *vis_counter;   // the forward's work list (ids with radii > 0) and its length
+    float* entry_sum_rw;            // = entry_sum: the run-sum pass leaves a run's total in the record of its LAST slot
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolors, *dL_ddepths;   // (P,3) (P,4) (P) (P,3) (P): written here
     float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
@@ -138,7 +144,7 @@ struct PreprocessBwdArgs {
 // ---- per-stage hipEvent profiler (implemented in raster.hip, shared with gicp.hip)
 // one stage per KERNEL on the rasteriser side (a bracket over several launches would also time the host gaps between them)
 enum Stage { ST_PREPROCESS = 0, ST_RANGES, ST_EMIT, ST_SPLIT_HIST, ST_SPLIT_COLSCAN, ST_SPLIT_SCATTER, ST_TILE_SORT, ST_BLEND_FWD,
-             ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_GICP_COV, ST_GICP_GRID, ST_GICP_ALIGN, ST_GICP_MISS, ST_LOSS_PASS1, ST_LOSS_PASS2, ST_ADAM, ST_COUNT };
+             ST_BLEND_BWD, ST_PREPROCESS_BWD, ST_GICP_COV, ST_GICP_GRID, ST_GICP_ALIGN, ST_GICP_MISS, ST_LOSS_PASS1, ST_LOSS_PASS2, ST_ADAM, ST_RUN_SUM, ST_COUNT };
 bool profile_on();
 void profile_begin(int stage, hipStream_t s);
 void profile_end(int stage, hipStream_t s);
@@ -151,6 +157,8 @@ struct ProfileScope {
 // implemented in raster_preprocess.hip (compiled with -ffp-contract=off so integer-feeding floats are reproducible)
 void launch_preprocess(const PreprocessArgs& a, hipStream_t s);
 void launch_preprocess_backward(const PreprocessBwdArgs& a, hipStream_t s);
+void launch_entry_run_sum(const PreprocessBwdArgs& a, hipStream_t s);
+int set_prebwd_legacy(int legacy);   // returns the previous setting
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
 
 // Tile rectangle of a splat (shared by preprocess and the duplicate kernel; integer outputs must agree).

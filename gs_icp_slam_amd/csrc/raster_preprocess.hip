@@ -11,6 +11,8 @@
 // blocks (4 waves); the work is 56 B read + ~66 B written per Gaussian and embarrassingly parallel, so the
 // kernel is HBM/launch bound.  Camera matrices are wave-uniform and live in SGPRs.
 #include "raster_common.hpp"
+#include <atomic>
+#include <cstdlib>
 
 namespace gsicp {
 
@@ -265,6 +267,26 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
         a.tiles_touched[idx] = mine;
         a.slot_base[idx] = s_base + wave_off + incl - mine;
     }
+    // Work list of the backward's per-Gaussian pass: the ids of the Gaussians that survived the culls (radii > 0), compacted the same way (ballot
+    // rank inside the wave, one atomic per workgroup).  Its ORDER across workgroups is whatever the atomics gave; nothing depends on it (every
+    // Gaussian's gradients are computed independently and written at its own index).
+    if (a.vis_list) {
+        __shared__ uint32_t s_vwave[4];
+        __shared__ uint32_t s_vbase;
+        const bool vis = in_range && a.radii[idx] > 0;
+        const unsigned long long vm = __ballot(vis);
+        const uint32_t vrank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+        if (lane == 0) s_vwave[wave] = (uint32_t)__popcll(vm);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = s_vwave[0] + s_vwave[1] + s_vwave[2] + s_vwave[3];
+            s_vbase = tot ? atomicAdd(a.vis_counter, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t voff = 0;
+        for (int w = 0; w < wave; ++w) voff += s_vwave[w];
+        if (vis) a.vis_list[s_vbase + voff + vrank] = (uint32_t)idx;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -340,59 +362,15 @@ __device__ inline void sh_backward(int deg, int M, const float* mean, const floa
     dm[2] += (-dir[0] * dir[2] * dd[0] - dir[1] * dir[2] * dd[1] + (sum2 - dir[2] * dir[2]) * dd[2]) * inv;
 }
 
-__global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.P) return;
+// Per-Gaussian algebra of the backward (R8 / R9) for Gaussian i.  gs = moment sums of h = G dL/dalpha over every pixel this Gaussian blends
+// (zeros for an invisible one); r_early / p_early / sc_early / q_early = its splat record and parameters, loaded by the caller next to the sums.
+__device__ __forceinline__ void prebwd_finish(const PreprocessBwdArgs& a, const int i, const bool visible, float* gs, const SplatRec& r_early,
+                                              const float* p_early, const float* sc_early, const float* q_early) {
     float dm[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dsc[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool visible = a.radii[i] > 0 && (a.live_rows == nullptr || i < *a.live_rows);
     const bool use_sh = (a.colors_precomp == nullptr) && (a.dL_dsh != nullptr);
     float sc_act[3] = {1.f, 1.f, 1.f}, q_act[4] = {0.f, 0.f, 0.f, 1.f}, q_norm_v = 1.f;   // activated scales / quaternion and the raw norm (raw_params)
-    // screen-space gradient sums of this Gaussian: its emission slots are one contiguous run of entry_sum
-    float gs[NGRAD];
-#pragma unroll
-    for (int c = 0; c < NGRAD; ++c) gs[c] = 0.f;
-    // Everything a visible Gaussian needs later is requested NOW, together with the first records of its run: the kernel is one residency
-    // wave of threads, so its duration is the length of one thread's chain of dependent memory latencies (radii -> run bounds -> records ->
-    // splat record -> parameters -> SH); issuing the independent ones side by side shortens that chain by two hops.
-    SplatRec r_early;
-    r_early.px = r_early.py = r_early.depth = r_early.hx = r_early.ca = r_early.cb = r_early.cc = r_early.opacity = 0.f;
-    r_early.r = r_early.g = r_early.b = r_early.hy = 0.f;
-    float p_early[3] = {0.f, 0.f, 0.f}, sc_early[3] = {1.f, 1.f, 1.f}, q_early[4] = {0.f, 0.f, 0.f, 1.f};
-    if (visible) {
-        r_early = a.rec[i];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) p_early[k] = a.means3D[3 * i + k];
-        if (!a.cov3D_precomp) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) sc_early[k] = a.scales[3 * i + k];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) q_early[k] = a.rotations[4 * i + k];
-        }
-    }
-    {
-        const uint32_t n_slots = (!visible || *a.total_counter > a.capacity) ? 0u : a.tiles_touched[i];
-        const float4* es = (const float4*)a.entry_sum + 3 * (size_t)a.slot_base[i];
-        // four records (twelve 16-byte loads) in flight per round: the Gaussian with the longest run sets the pace of its wave;
-        // the additions stay in slot order, so the sums are bit-identical to the one-at-a-time loop
-        for (uint32_t u0 = 0; u0 < n_slots; u0 += 4) {
-            float4 q[4][3];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t u = u0 + k < n_slots ? u0 + k : u0;
-                q[k][0] = es[3 * u]; q[k][1] = es[3 * u + 1]; q[k][2] = es[3 * u + 2];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (u0 + k < n_slots) {
-                    gs[0] += q[k][0].x; gs[1] += q[k][0].y; gs[2] += q[k][0].z; gs[3] += q[k][0].w;
-                    gs[4] += q[k][1].x; gs[5] += q[k][1].y; gs[6] += q[k][1].z; gs[7] += q[k][1].w;
-                    gs[8] += q[k][2].x; gs[9] += q[k][2].y;
-                }
-            }
-        }
-    }
     // gs = moment sums of h = G dL/dalpha over every pixel this Gaussian blends: [h dx, h dy, h dx dx, h dx dy, h dy dy, h, ...]
     // (blend_backward_tile_kernel); the per-Gaussian constants turn them into the screen-space gradients
     if (visible) {
@@ -560,6 +538,192 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     }
 }
 
+__device__ __forceinline__ void prebwd_load(const PreprocessBwdArgs& a, const int i, SplatRec& r, float* p, float* sc, float* q) {
+    r = a.rec[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] = a.means3D[3 * i + k];
+    if (!a.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sc[k] = a.scales[3 * i + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = a.rotations[4 * i + k];
+    }
+}
+
+// LEGACY per-Gaussian pass (rounds 3-4; GSICP_PREBWD_LEGACY=1, kept as the A/B partner and the reference of tests/test_raster_gpu.py): one thread
+// per Gaussian over all P, each visible thread walks its own run of 48-byte records, left to right.
+__global__ __launch_bounds__(256) void preprocess_backward_legacy_kernel(PreprocessBwdArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    const bool visible = a.radii[i] > 0 && (a.live_rows == nullptr || i < *a.live_rows);
+    float gs[NGRAD];
+#pragma unroll
+    for (int c = 0; c < NGRAD; ++c) gs[c] = 0.f;
+    SplatRec r_early;
+    r_early.px = r_early.py = r_early.depth = r_early.hx = r_early.ca = r_early.cb = r_early.cc = r_early.opacity = 0.f;
+    r_early.r = r_early.g = r_early.b = r_early.hy = 0.f;
+    float p_early[3] = {0.f, 0.f, 0.f}, sc_early[3] = {1.f, 1.f, 1.f}, q_early[4] = {0.f, 0.f, 0.f, 1.f};
+    if (visible) prebwd_load(a, i, r_early, p_early, sc_early, q_early);
+    {
+        const uint32_t n_slots = (!visible || *a.total_counter > a.capacity) ? 0u : a.tiles_touched[i];
+        const float4* es = (const float4*)a.entry_sum + 3 * (size_t)a.slot_base[i];
+        for (uint32_t u0 = 0; u0 < n_slots; u0 += 4) {
+            float4 q[4][3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t u = u0 + k < n_slots ? u0 + k : u0;
+                q[k][0] = es[3 * u]; q[k][1] = es[3 * u + 1]; q[k][2] = es[3 * u + 2];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (u0 + k < n_slots) {
+                    gs[0] += q[k][0].x; gs[1] += q[k][0].y; gs[2] += q[k][0].z; gs[3] += q[k][0].w;
+                    gs[4] += q[k][1].x; gs[5] += q[k][1].y; gs[6] += q[k][1].z; gs[7] += q[k][1].w;
+                    gs[8] += q[k][2].x; gs[9] += q[k][2].y;
+                }
+            }
+        }
+    }
+    prebwd_finish(a, i, visible, gs, r_early, p_early, sc_early, q_early);
+}
+
+// ---- Round 5: the per-Gaussian pass in two launches.
+// (1) entry_run_sum_kernel — the SUMMATION of a Gaussian's run of records as a flat, fully coalesced pass over the emission slots: one lane per
+//     48-byte record, one wave per window of 64 consecutive slots, run boundaries from entry_gauss (slot -> Gaussian id).  Inside a window the ten sums
+//     are a segmented Hillis-Steele scan across the lanes (step d adds the value d records EARLIER IN THE SAME RUN): the additions a run's total is
+//     made of depend only on the position of a record inside its run, never on where the run sits in the window — so the result is bit-reproducible
+//     although the slot allocator (one atomic per workgroup) places runs differently from launch to launch.  A run that starts in a window and
+//     leaves it is summed by THAT wave in chunks of 64 records aligned to the run's start (the same scan per chunk — a run of <= 64 records gets
+//     the same bits on either path; chunk totals are added in order); lanes of a run that started in an earlier window idle.  The total replaces
+//     the record of the run's LAST slot.  No Gaussian's run sets the pace of anything: the longest run of a trained map (342 records) costs its wave
+//     six chunk rounds, where the legacy walk kept a lane busy for 86 dependent rounds.
+// (2) preprocess_backward_kernel — the per-Gaussian algebra over the forward's COMPACTED list of visible Gaussians (thread t takes list entry t:
+//     every lane of the leading waves works; on the S-map 82 % of the Gaussians are culled and the legacy kernel ran its 120-register body with
+//     a fifth of the lanes), reading ONE record per Gaussian; thread t also writes the zeros of Gaussian t when that one is invisible.
+__global__ __launch_bounds__(256) void entry_run_sum_kernel(const uint32_t* __restrict__ total_counter, const uint32_t capacity,
+                                                            const uint32_t* __restrict__ entry_gauss, const uint32_t* __restrict__ tiles_touched,
+                                                            float* __restrict__ entry_sum) {
+    const uint32_t total = *total_counter;
+    const uint32_t R = total > capacity ? 0u : total;
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t n_windows = (R + 63u) / 64u;
+    const uint32_t n_waves = gridDim.x * 4u;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    float4* es = (float4*)entry_sum;
+    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_windows; w += n_waves) {
+        const uint32_t u = w * 64u + (uint32_t)lane;
+        const bool valid = u < R;
+        const uint32_t g = valid ? entry_gauss[u] : NONE;
+        const uint32_t g_prev = (valid && u > 0u) ? entry_gauss[u - 1u] : NONE;
+        const uint32_t g_next = (u + 1u < R) ? entry_gauss[u + 1u] : NONE;
+        const bool head = valid && g != g_prev, tail = valid && g != g_next;
+        int hl = head ? lane : -1;               // lane of the head of the run this lane belongs to (-1: the run started in an earlier window)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(hl, off, 64);
+            if (lane >= off) hl = o > hl ? o : hl;
+        }
+        const int k = hl >= 0 ? lane - hl : -1;  // position of this lane's record inside its run
+        float v[NGRAD];
+#pragma unroll
+        for (int c = 0; c < NGRAD; ++c) v[c] = 0.f;
+        if (valid && hl >= 0) {
+            const float4 q0 = es[3 * (size_t)u], q1 = es[3 * (size_t)u + 1], q2 = es[3 * (size_t)u + 2];
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w; v[8] = q2.x; v[9] = q2.y;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+            for (int c = 0; c < NGRAD; ++c) {
+                const float o = __shfl_up(v[c], off, 64);
+                if (k >= off) v[c] += o;
+            }
+        }
+        if (tail && hl >= 0) {
+            es[3 * (size_t)u] = make_float4(v[0], v[1], v[2], v[3]);
+            es[3 * (size_t)u + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            es[3 * (size_t)u + 2] = make_float4(v[8], v[9], 0.f, 0.f);
+        }
+        // the run that starts in this window and leaves it
+        const int hl63 = __shfl(hl, 63, 64);
+        const int open63 = __shfl((int)(valid && !tail), 63, 64);
+        if (open63 != 0 && hl63 >= 0) {
+            const uint32_t s0 = w * 64u + (uint32_t)hl63;
+            const uint32_t gsp = (uint32_t)__shfl((int)g, 63, 64);
+            const uint32_t n = tiles_touched[gsp];
+            float acc[NGRAD];
+#pragma unroll
+            for (int c = 0; c < NGRAD; ++c) acc[c] = 0.f;
+            for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+                const uint32_t pos = c0 + (uint32_t)lane;
+                float x[NGRAD];
+#pragma unroll
+                for (int c = 0; c < NGRAD; ++c) x[c] = 0.f;
+                if (pos < n) {
+                    const size_t uu = (size_t)s0 + pos;
+                    const float4 q0 = es[3 * uu], q1 = es[3 * uu + 1], q2 = es[3 * uu + 2];
+                    x[0] = q0.x; x[1] = q0.y; x[2] = q0.z; x[3] = q0.w; x[4] = q1.x; x[5] = q1.y; x[6] = q1.z; x[7] = q1.w; x[8] = q2.x; x[9] = q2.y;
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+                    for (int c = 0; c < NGRAD; ++c) {
+                        const float o = __shfl_up(x[c], off, 64);
+                        if (lane >= off) x[c] += o;
+                    }
+                }
+                const int last = (n - c0) >= 64u ? 63 : (int)(n - c0) - 1;
+#pragma unroll
+                for (int c = 0; c < NGRAD; ++c) {
+                    const float t = __shfl(x[c], last, 64);
+                    acc[c] = c0 == 0u ? t : acc[c] + t;
+                }
+            }
+            if (lane == 0) {
+                const size_t ut = (size_t)s0 + n - 1u;
+                es[3 * ut] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                es[3 * ut + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+                es[3 * ut + 2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.P) return;
+    SplatRec r0;
+    r0.px = r0.py = r0.depth = r0.hx = r0.ca = r0.cb = r0.cc = r0.opacity = 0.f;
+    r0.r = r0.g = r0.b = r0.hy = 0.f;
+    {   // Gaussian t, if it is not visible: its zeros (the algebra of an invisible Gaussian IS the zero fill)
+        const bool visible_t = a.radii[t] > 0 && (a.live_rows == nullptr || t < *a.live_rows);
+        if (!visible_t) {
+            float gs[NGRAD];
+#pragma unroll
+            for (int c = 0; c < NGRAD; ++c) gs[c] = 0.f;
+            const float p0[3] = {0.f, 0.f, 0.f}, s1[3] = {1.f, 1.f, 1.f}, q1[4] = {0.f, 0.f, 0.f, 1.f};
+            prebwd_finish(a, t, false, gs, r0, p0, s1, q1);
+        }
+    }
+    const uint32_t n_vis = *a.vis_counter;
+    if ((uint32_t)t >= n_vis) return;
+    const int i = (int)a.vis_list[t];
+    if (a.live_rows != nullptr && i >= *a.live_rows) return;      // cannot happen (rows behind the live count are culled in the forward); cheap
+    SplatRec r_early = r0;
+    float p_early[3] = {0.f, 0.f, 0.f}, sc_early[3] = {1.f, 1.f, 1.f}, q_early[4] = {0.f, 0.f, 0.f, 1.f};
+    prebwd_load(a, i, r_early, p_early, sc_early, q_early);
+    float gs[NGRAD];
+#pragma unroll
+    for (int c = 0; c < NGRAD; ++c) gs[c] = 0.f;
+    const uint32_t n_slots = (*a.total_counter > a.capacity) ? 0u : a.tiles_touched[i];
+    if (n_slots != 0u) {
+        const float4* es = (const float4*)a.entry_sum + 3 * ((size_t)a.slot_base[i] + n_slots - 1u);     // the run's total (entry_run_sum_kernel)
+        const float4 q0 = es[0], q1 = es[1], q2 = es[2];
+        gs[0] = q0.x; gs[1] = q0.y; gs[2] = q0.z; gs[3] = q0.w; gs[4] = q1.x; gs[5] = q1.y; gs[6] = q1.z; gs[7] = q1.w; gs[8] = q2.x; gs[9] = q2.y;
+    }
+    prebwd_finish(a, i, true, gs, r_early, p_early, sc_early, q_early);
+}
+
 #pragma clang fp contract(off)
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* means3D, const float* view, unsigned char* present) {
@@ -575,9 +739,23 @@ void launch_preprocess(const PreprocessArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
     hipLaunchKernelGGL(preprocess_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
+static std::atomic<int>& prebwd_legacy_flag() {
+    static std::atomic<int> v([] { const char* e = getenv("GSICP_PREBWD_LEGACY"); return (e && e[0] == '1') ? 1 : 0; }());
+    return v;
+}
+static bool prebwd_legacy() { return prebwd_legacy_flag().load() != 0; }
+int set_prebwd_legacy(int legacy) { return prebwd_legacy_flag().exchange(legacy ? 1 : 0); }
+void launch_entry_run_sum(const PreprocessBwdArgs& a, hipStream_t s) {
+    if (a.P <= 0 || a.capacity == 0u || prebwd_legacy()) return;
+    // grid-stride over the windows of 64 slots that exist on the device (R <= capacity): enough workgroups to fill the chip, no more
+    unsigned blocks = (unsigned)(((size_t)a.capacity + 255) / 256);
+    if (blocks > 4096u) blocks = 4096u;
+    hipLaunchKernelGGL(entry_run_sum_kernel, dim3(blocks), dim3(256), 0, s, a.total_counter, a.capacity, a.entry_gauss, a.tiles_touched, a.entry_sum_rw);
+}
 void launch_preprocess_backward(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    if (prebwd_legacy()) hipLaunchKernelGGL(preprocess_backward_legacy_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(preprocess_backward_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s) {
     if (P <= 0) return;

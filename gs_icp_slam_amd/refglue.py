@@ -261,9 +261,19 @@ def patch_tracker(cls):
     if getattr(cls, "_gsicp_fused", False):
         return cls
     import numpy as np
+    plain_init = cls.__init__
+
+    def __init__(self, slam, *args, **kw):
+        # the shared frame counter [REF gs_icp_slam.py:95]: mp_Tracker.py keeps and advances it [REF mp_Tracker.py:35, 117], mp_Tracker_unlimit.py does
+        # neither — the fused mapper's pacing policy reads it (refglue._pace), so the patched front-end advances it in both variants
+        plain_init(self, slam, *args, **kw)
+        if not hasattr(self, "iter_shared") and hasattr(slam, "iter_shared"):
+            self.iter_shared = slam.iter_shared
 
     def downsample_and_make_pointcloud2(self, depth_img, rgb_img):
         from .frontend import DepthFrontEnd
+        if getattr(self, "iter_shared", None) is not None:
+            self.iter_shared[0] = int(getattr(self, "iteration_images", 0))
         fe = self.__dict__.get("_gsicp_frontend")
         if fe is None:
             fe = DepthFrontEnd(self.H, self.W, self.fx, self.fy, self.cx, self.cy, self.downsample_rate, self.depth_scale, self.depth_trunc)
@@ -276,6 +286,7 @@ def patch_tracker(cls):
         pc = fe.make_pointcloud(d_dev, torch.from_numpy(np.ascontiguousarray(rgb_img)).cuda())
         return pc.points.cpu().numpy(), pc.colors.cpu().numpy(), pc.z_values.cpu().numpy(), pc.trackable_idx.cpu().numpy().astype(np.int64)
 
+    cls.__init__ = __init__
     cls.downsample_and_make_pointcloud2 = downsample_and_make_pointcloud2
     cls._gsicp_fused = True
     return cls

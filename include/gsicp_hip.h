@@ -135,6 +135,12 @@ int gsicp_raster_mark_visible(int P, const float* means3D, const float* viewmatr
  * its low 28 bits (entry_gauss[slot] is the Gaussian id) and 4 strip bits on top. */
 int gsicp_raster_layout(int P, int num_rendered, int width, int height, size_t out[12]);
 
+/* Test / A-B hook: which per-Gaussian pass gsicp_raster_backward launches.  0 (default) = round 5's two launches (flat run summation over the
+ * emission slots + the algebra over the forward's compacted list of visible Gaussians); 1 = the legacy single kernel of rounds 3-4 (one thread per
+ * Gaussian walking its own run).  Process-wide; also set by GSICP_PREBWD_LEGACY=1 at load.  Returns the previous value.  Both compute the
+ * same gradients; the order in which a Gaussian's per-tile records are added differs (tests/test_raster_gpu.py compares them). */
+int gsicp_raster_set_legacy_backward(int legacy);
+
 /* --------------------------------------------------------------------------------------------------------
  * 2. simple_knn — replaces simple_knn._C.distCUDA2 [REF scene/gaussian_model.py:20 (import site)].
  *    out[i] = mean squared distance from point i to its 3 nearest other points (f32).  Asynchronous.

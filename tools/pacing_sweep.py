@@ -18,6 +18,7 @@ SEQUENCES = {
     "replica_noisy_fast": ["--synthetic", "300", "--noise", "--speed", "2", "--jitter", "0.003"],
     "tum_noisy": ["--synthetic", "200", "--shape", "tum", "--noise"],
     "replica_clean": ["--synthetic", "300"],
+    "replica_noisy_fast_30fps": ["--synthetic", "300", "--noise", "--speed", "2", "--jitter", "0.003", "--limit30"],
 }
 
 
@@ -48,10 +49,16 @@ def main():
     ap.add_argument("--cache", default="/tmp/gsicp_cache")
     ap.add_argument("--quick", action="store_true", help="one run per configuration, fewer budgets")
     ap.add_argument("--budget-s", type=float, default=900.0, help="stop starting new runs after this many seconds")
+    ap.add_argument("--plan", default="v1", help="v1: budgets 1/2/4/8 + free-run + the freeze experiment; v2: the confirmation runs after v1")
     a = ap.parse_args()
     k = lambda v: {"GSICP_FUSED_ITERS_PER_FRAME": str(v)}      # noqa: E731
+    geom = dict(k(0), GSICP_FUSED_FREEZE_TRACKABLE="geom")
     plan = []
-    for seq in ("replica_noisy_fast", "tum_noisy"):
+    if a.plan == "v2":
+        plan = [("replica_noisy_fast", True, k(2)), ("replica_noisy_fast", True, k(4)), ("replica_noisy_fast", True, geom), ("replica_noisy_fast", True, geom),
+                ("replica_noisy_fast", False, {}), ("replica_noisy_fast_30fps", True, geom), ("replica_noisy_fast_30fps", True, k(2)),
+                ("tum_noisy", True, geom), ("tum_noisy", True, geom), ("tum_noisy", True, k(2)), ("replica_clean", True, geom)]
+    for seq in (() if a.plan == "v2" else ("replica_noisy_fast", "tum_noisy")):
         plan.append((seq, False, {}))
         for v in ((1, 2, 4) if (a.quick or seq == "tum_noisy") else (1, 2, 4, 8)):
             plan.append((seq, True, k(v)))
@@ -60,7 +67,8 @@ def main():
             plan.append((seq, False, {}))               # second untouched run: run-to-run spread of the bar itself
             plan.append((seq, True, dict(k(0), GSICP_FUSED_FREEZE_TRACKABLE="xyz")))
             plan.append((seq, True, dict(k(0), GSICP_FUSED_FREEZE_TRACKABLE="geom")))
-    plan.append(("replica_clean", True, k(2)))
+    if a.plan != "v2":
+        plan.append(("replica_clean", True, k(2)))
     t0 = time.time()
     runs = []
     for seq, fused, env in plan:
