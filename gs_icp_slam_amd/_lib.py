@@ -53,6 +53,9 @@ SIGNATURES = {
     "gsicp_rows_pack": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p]),
     "gsicp_rows_unpack": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_set_view": (c_int, [c_int, c_int] + [c_void_p] * 11),
+    "gsicp_mapper_select_view": (c_int, [c_void_p] * 10),
+    "gsicp_mapper_loss_indirect": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_activations_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_activations_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_void_p, c_void_p, c_void_p]),
@@ -62,6 +65,8 @@ SIGNATURES = {
                                            c_void_p, c_void_p]),
     "gsicp_adam_step_guarded": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                         c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsicp_adam_step_masked": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
+                                       c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_gicp_create": (c_void_p, []),
     "gsicp_gicp_destroy": (None, [c_void_p]),
     "gsicp_gicp_set_max_correspondence_distance": (c_int, [c_void_p, c_double]),

@@ -10,7 +10,10 @@
 // five moment maps (x, y, xx, yy, xy) in pass 1 and to the three derivative maps in pass 2.  Everything is HBM-streaming: pass 1 reads 2 and writes 3 floats per
 // pixel-channel, pass 2 reads 5 and writes 1.  Sums are reduced per workgroup and finished in a fixed order (no float atomics:
 // results are bit-reproducible) by one workgroup of pass 2 — or by a one-workgroup kernel when only the loss value is asked for.
+#include <atomic>
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <cstdint>
 #include <cstdlib>
 #include <string>
@@ -66,7 +69,8 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
                                                          const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
                                                          Win win, float d_max, float dS_scale /* = -lambda / (3HW) */,
                                                          float* __restrict__ abc /* (3, 3, H, W): A, B, C per channel */,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, const float* const* __restrict__ gt_slots) {
+    if (gt_slots) { gt_image = gt_slots[0]; gt_depth = gt_slots[1]; }   // keyframe selected on the device (gsicp_mapper_select_view): two scalar loads
     // LDS overlay: the horizontal pass runs in two sub-phases — the three maps that need x (mu_x, E[xx], E[xy]) first; then x is dead and
     // mu_y is written over it — so four map buffers instead of five: 39 KB instead of 45 KB per workgroup, four workgroups per CU instead
     // of three (the kernel is bound by how many workgroups a CU holds).  Same arithmetic in the same order: bit-identical results.
@@ -241,7 +245,9 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
                                                          const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
                                                          Win win, float d_max, float l1_scale /* (1 - lambda) / (3HW) */,
                                                          float depth_scale /* w_d / (HW d_max) */, const float* __restrict__ abc,
-                                                         float* __restrict__ dL_dimage, float* __restrict__ dL_ddepth, LossReduceArgs red) {
+                                                         float* __restrict__ dL_dimage, float* __restrict__ dL_ddepth, LossReduceArgs red,
+                                                         const float* const* __restrict__ gt_slots) {
+    if (gt_slots) { gt_image = gt_slots[0]; gt_depth = gt_slots[1]; }
     // LDS overlay: the horizontally filtered map m is written where the INPUT map m - 1 lay (already consumed; map 0 gets a buffer of its
     // own) — 28 KB instead of 40 KB per workgroup, five workgroups per CU instead of four (these kernels are bound by how many
     // workgroups a CU can hold, not by bandwidth or arithmetic), at the price of a barrier per map instead of one for all three.
@@ -345,7 +351,9 @@ __global__ __launch_bounds__(256) void loss_fused_kernel(const float* __restrict
                                                          const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
                                                          Win win, float d_max, float dS_scale /* -lambda / (3HW) */, float l1_scale /* (1 - lambda) / (3HW) */,
                                                          float depth_scale /* w_d / (HW d_max) */, float* __restrict__ dL_dimage,
-                                                         float* __restrict__ dL_ddepth, float* __restrict__ partial, int tile_mod, int tile_rem) {
+                                                         float* __restrict__ dL_ddepth, float* __restrict__ partial, int tile_mod, int tile_rem,
+                                                         const float* const* __restrict__ gt_slots) {
+    if (gt_slots) { gt_image = gt_slots[0]; gt_depth = gt_slots[1]; }
     // x and y staging as ONE object: the three derivative maps (FMID x FMS each) later overlay BOTH, and only members of one array are
     // guaranteed contiguous (separate __shared__ variables may be laid out in any order — ADVICE r3)
     __shared__ __attribute__((aligned(16))) float s_xy[2][FIN][FXS];
@@ -609,6 +617,19 @@ __global__ __launch_bounds__(256) void set_view_kernel(const float* __restrict__
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4_depth; i += stride) d_gt_depth[i] = gt_depth[i];
 }
 
+// Round 5: the keyframe's images stay where they are.  The captured loss kernels read the two ground-truth pointers from a DEVICE slot pair
+// (gsicp_mapper_loss_indirect); selecting a keyframe writes 35 floats and two pointers — no 13 MB copy (6.8 us and 20 MB of traffic per iteration).
+__global__ __launch_bounds__(64) void select_view_kernel(const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+                                                         const float* gt_image, const float* gt_depth, float* __restrict__ d_view,
+                                                         float* __restrict__ d_proj, float* __restrict__ d_campos, const float** __restrict__ d_slots) {
+    const int t = threadIdx.x;
+    if (t < 16) d_view[t] = view[t];
+    else if (t < 32) d_proj[t - 16] = proj[t - 16];
+    else if (t < 35) d_campos[t - 32] = campos[t - 32];
+    else if (t == 35) d_slots[0] = gt_image;
+    else if (t == 36) d_slots[1] = gt_depth;
+}
+
 // ------------------------------------------------------------------------------------------------ Adam
 constexpr int ADAM_MAX_GROUPS = 8;
 struct AdamTable {
@@ -620,6 +641,7 @@ struct AdamTable {
     float step_size[ADAM_MAX_GROUPS];  // lr / (1 - beta1^t)
     int src[ADAM_MAX_GROUPS];          // index of the group in the caller's arrays (empty tensors are squeezed out)
     int row_width[ADAM_MAX_GROUPS];    // elements per map row (live-row mode), 0 = whole tensor
+    int frozen[ADAM_MAX_GROUPS];       // 1: rows with row_freeze[row] != 0 of this tensor are left alone (parameter and both moments)
     int n;
 };
 
@@ -643,13 +665,11 @@ __device__ inline AdamPMV adam_update(float p, float m, float v, float g, float 
 // rasteriser forward rendered nothing because its duplicate lists outgrew their capacity — and the step must not happen: parameters,
 // both moments and the step count stay as they are, and the bump kernel counts the skipped step in a sticky device counter.
 template <bool CAPTURABLE>
-__global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const double* __restrict__ lr_dev, const int* __restrict__ step_dev,
-                                                          float beta1, float beta2, float eps, float inv_bc2_sqrt_host,
-                                                          const unsigned* __restrict__ guard_count, unsigned guard_limit,
-                                                          const int* __restrict__ live_rows) {
-    __shared__ double s_bc1;
-    __shared__ float s_inv_bc2_sqrt;
-    if (CAPTURABLE && guard_count && *guard_count > guard_limit) return;   // wave-uniform (one scalar load)
+__device__ __forceinline__ void adam_tensor_body(const AdamTable& t, const double* __restrict__ lr_dev, const int* step_dev, float beta1, float beta2,
+                                                 float eps, float inv_bc2_sqrt_host, const int* __restrict__ live_rows, double* s_bc1_p,
+                                                 float* s_inv_bc2_sqrt_p, const int* __restrict__ row_freeze) {
+    double& s_bc1 = *s_bc1_p;
+    float& s_inv_bc2_sqrt = *s_inv_bc2_sqrt_p;
     if (CAPTURABLE) {
         if (threadIdx.x == 0) {   // two double pow() per BLOCK, not per thread
             const int step = *step_dev + 1;
@@ -675,20 +695,56 @@ __global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const dou
     const bool aligned = ((((uintptr_t)P) | ((uintptr_t)G) | ((uintptr_t)M) | ((uintptr_t)V)) & 15) == 0;
     const long long nvec = aligned ? numel / 4 : 0;
     const long long stride = (long long)gridDim.x * 256;
+    // ROW FREEZE (round 5; refglue's default policy): a tensor flagged in t.frozen skips the rows whose row_freeze word is non-zero — parameter
+    // and both moments stay as they are, exactly as if the row were no parameter at all.
+    const unsigned rw = (row_freeze && t.frozen[gidx] && t.row_width[gidx] > 0) ? (unsigned)t.row_width[gidx] : 0u;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
         float4 p = ((float4*)P)[i], m = ((float4*)M)[i], v = ((float4*)V)[i];
         const float4 g = ((const float4*)G)[i];
-        const AdamPMV a0 = adam_update(p.x, m.x, v.x, g.x, beta1, beta2, eps, inv_bc2_sqrt, step_size);
-        const AdamPMV a1 = adam_update(p.y, m.y, v.y, g.y, beta1, beta2, eps, inv_bc2_sqrt, step_size);
-        const AdamPMV a2 = adam_update(p.z, m.z, v.z, g.z, beta1, beta2, eps, inv_bc2_sqrt, step_size);
-        const AdamPMV a3 = adam_update(p.w, m.w, v.w, g.w, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+        AdamPMV a0 = adam_update(p.x, m.x, v.x, g.x, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+        AdamPMV a1 = adam_update(p.y, m.y, v.y, g.y, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+        AdamPMV a2 = adam_update(p.z, m.z, v.z, g.z, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+        AdamPMV a3 = adam_update(p.w, m.w, v.w, g.w, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+        if (rw) {
+            const unsigned e = 4u * (unsigned)i;
+            if (row_freeze[e / rw] != 0) { a0.p = p.x; a0.m = m.x; a0.v = v.x; }
+            if (row_freeze[(e + 1u) / rw] != 0) { a1.p = p.y; a1.m = m.y; a1.v = v.y; }
+            if (row_freeze[(e + 2u) / rw] != 0) { a2.p = p.z; a2.m = m.z; a2.v = v.z; }
+            if (row_freeze[(e + 3u) / rw] != 0) { a3.p = p.w; a3.m = m.w; a3.v = v.w; }
+        }
         ((float4*)M)[i] = make_float4(a0.m, a1.m, a2.m, a3.m);
         ((float4*)V)[i] = make_float4(a0.v, a1.v, a2.v, a3.v);
         ((float4*)P)[i] = make_float4(a0.p, a1.p, a2.p, a3.p);
     }
     for (long long j = 4 * nvec + (long long)blockIdx.x * 256 + threadIdx.x; j < numel; j += stride) {
+        if (rw && row_freeze[(unsigned)j / rw] != 0) continue;
         const AdamPMV a0 = adam_update(P[j], M[j], V[j], G[j], beta1, beta2, eps, inv_bc2_sqrt, step_size);
         M[j] = a0.m; V[j] = a0.v; P[j] = a0.p;
+    }
+}
+// STEP BUMP (capturable path, round 5): `done` is a zeroed device word; every workgroup counts itself in when it has finished, and the one that
+// completes the count advances the step counter (or, under a tripped guard, the skipped-steps counter) and re-zeroes the word.  Every workgroup
+// reads the step count at its START, the bump happens after ALL of them have finished: no workgroup can see the advanced value — and the
+// one-thread adam_bump_step_kernel (3.9 us of launch floor per iteration) is gone.
+template <bool CAPTURABLE>
+__global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const double* __restrict__ lr_dev, const int* step_dev,
+                                                          float beta1, float beta2, float eps, float inv_bc2_sqrt_host,
+                                                          const unsigned* __restrict__ guard_count, unsigned guard_limit,
+                                                          const int* __restrict__ live_rows, int* step_rw, unsigned* done, unsigned* skipped_dev,
+                                                          const int* __restrict__ row_freeze) {
+    __shared__ double s_bc1;
+    __shared__ float s_inv_bc2_sqrt;
+    const bool skip = CAPTURABLE && guard_count && *guard_count > guard_limit;   // grid-uniform (one scalar load)
+    if (!skip) adam_tensor_body<CAPTURABLE>(t, lr_dev, step_dev, beta1, beta2, eps, inv_bc2_sqrt_host, live_rows, &s_bc1, &s_inv_bc2_sqrt, row_freeze);
+    if (CAPTURABLE && done) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1u) {
+                *done = 0u;
+                if (skip) { if (skipped_dev) *skipped_dev += 1u; } else *step_rw += 1;
+            }
+        }
     }
 }
 __global__ void adam_bump_step_kernel(int* step_dev, const unsigned* __restrict__ guard_count, unsigned guard_limit, unsigned* skipped_dev) {
@@ -861,10 +917,10 @@ size_t gsicp_mapper_loss_scratch_bytes(int width, int height) {
 
 static int mapper_loss_impl(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
                             float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
-                            char* scratch, int tile_mod, int tile_rem, void* stream_v) {
+                            char* scratch, int tile_mod, int tile_rem, void* stream_v, const float* const* gt_slots = nullptr) {
     hipStream_t stream = (hipStream_t)stream_v;
     if (tile_mod < 1 || tile_rem < 0 || tile_rem >= tile_mod) { g_last_error = "gsicp_mapper_loss_sharded: bad tile_mod / tile_rem"; return -2; }
-    if (width <= 0 || height <= 0 || !image || !depth || !gt_image || !gt_depth || !loss_out || !scratch) {
+    if (width <= 0 || height <= 0 || !image || !depth || (!gt_slots && (!gt_image || !gt_depth)) || !loss_out || !scratch) {
         g_last_error = "gsicp_mapper_loss: bad arguments"; return -2;
     }
     Win win;
@@ -897,7 +953,7 @@ static int mapper_loss_impl(const float* image, const float* depth, const float*
         { ProfileScope ps(ST_LOSS_PASS1, stream);
           hipLaunchKernelGGL(loss_fused_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                              -lambda_dssim / n_img, (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), dL_dimage, dL_ddepth, partial,
-                             tile_mod, tile_rem); }
+                             tile_mod, tile_rem, gt_slots); }
         { ProfileScope ps(ST_LOSS_PASS2, stream);
           hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, red_n); }
         if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss_sharded: kernel launch failed"; return -1; }
@@ -905,12 +961,12 @@ static int mapper_loss_impl(const float* image, const float* depth, const float*
     }
     { ProfileScope ps(ST_LOSS_PASS1, stream);
       hipLaunchKernelGGL(loss_pass1_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
-                         -lambda_dssim / n_img, abc, partial);
+                         -lambda_dssim / n_img, abc, partial, gt_slots);
       if (!with_grads) hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, red); }
     if (with_grads) {   // one workgroup of pass 2 finishes the loss value (no launch of its own)
         ProfileScope ps(ST_LOSS_PASS2, stream);
         hipLaunchKernelGGL(loss_pass2_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
-                           (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth, red);
+                           (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth, red, gt_slots);
     }
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss: kernel launch failed"; return -1; }
     return 0;
@@ -927,6 +983,14 @@ int gsicp_mapper_loss_sharded(const float* image, const float* depth, const floa
                               float* dL_dimage, float* dL_ddepth, char* scratch, void* stream) {
     return mapper_loss_impl(image, depth, gt_image, gt_depth, width, height, lambda_dssim, depth_weight, d_max, loss_out, dL_dimage, dL_ddepth,
                             scratch, tile_mod, tile_rem, stream);
+}
+
+int gsicp_mapper_loss_indirect(const float* image, const float* depth, const float* const* gt_slots, int width, int height, float lambda_dssim,
+                               float depth_weight, float d_max, int tile_mod, int tile_rem, float* loss_out, float* dL_dimage, float* dL_ddepth,
+                               char* scratch, void* stream) {
+    if (!gt_slots) { g_last_error = "gsicp_mapper_loss_indirect: gt_slots is NULL"; return -2; }
+    return mapper_loss_impl(image, depth, nullptr, nullptr, width, height, lambda_dssim, depth_weight, d_max, loss_out, dL_dimage, dL_ddepth, scratch,
+                            tile_mod < 1 ? 1 : tile_mod, tile_rem, stream, gt_slots);
 }
 
 size_t gsicp_store_compact_scratch_bytes(int n) { return ((size_t)(n > 0 ? (n + 255) / 256 : 1) + 1) * sizeof(unsigned); }
@@ -1047,6 +1111,17 @@ int gsicp_mapper_set_view(int width, int height, const float* viewmatrix, const 
     return 0;
 }
 
+int gsicp_mapper_select_view(const float* viewmatrix, const float* projmatrix, const float* campos, const float* gt_image, const float* gt_depth,
+                             float* dst_viewmatrix, float* dst_projmatrix, float* dst_campos, const float** dst_gt_slots, void* stream) {
+    if (!viewmatrix || !projmatrix || !campos || !gt_image || !gt_depth || !dst_viewmatrix || !dst_projmatrix || !dst_campos || !dst_gt_slots) {
+        g_last_error = "gsicp_mapper_select_view: bad arguments"; return -2;
+    }
+    hipLaunchKernelGGL(select_view_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, viewmatrix, projmatrix, campos, gt_image, gt_depth, dst_viewmatrix,
+                       dst_projmatrix, dst_campos, dst_gt_slots);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_select_view: kernel launch failed"; return -1; }
+    return 0;
+}
+
 int gsicp_mapper_activations_forward(int P, const float* opacity_raw, const float* scaling_raw, const float* rotation_raw, float* opacity,
                                      float* scaling, float* rotation, const int* live_rows_dev, void* stream) {
     if (P < 0 || (P > 0 && (!opacity_raw || !scaling_raw || !rotation_raw || !opacity || !scaling || !rotation))) {
@@ -1071,6 +1146,24 @@ int gsicp_mapper_activations_backward(int P, const float* opacity, const float* 
     return 0;
 }
 
+// GSICP_ADAM_BUMP_KERNEL=1: keep the separate one-thread bump launch of rounds 2-4 (A/B)
+static std::atomic<int> g_adam_bump_kernel([] { const char* e = getenv("GSICP_ADAM_BUMP_KERNEL"); return (e && e[0] == '1') ? 1 : 0; }());
+static unsigned* adam_done_word(const int* step_dev, hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<const int*, unsigned*> words;     // keyed by the step counter: one optimiser = one counter = one word
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = words.find(step_dev);
+    if (it != words.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    unsigned* w = nullptr;
+    if (hipMalloc((void**)&w, 256) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(w, 0, 256) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w); return nullptr; }
+    if (words.size() > 4096) words.clear();           // step counters of long-gone optimisers (the words themselves are 256 B each: left allocated)
+    words[step_dev] = w;
+    return w;
+}
+
 static long long adam_table(AdamTable& t, int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
                             float* const* exp_avg_sq, const long long* numel, const float* lr, double bc1) {
     long long total = 0;
@@ -1083,11 +1176,12 @@ static long long adam_table(AdamTable& t, int n_groups, float* const* params, co
         t.step_size[t.n] = lr ? (float)((double)lr[k] / bc1) : 0.f;
         t.src[t.n] = k;
         t.row_width[t.n] = 0;
+        t.frozen[t.n] = 0;
         ++t.n;
     }
     for (int k = t.n; k < ADAM_MAX_GROUPS; ++k) {
         t.p[k] = nullptr; t.g[k] = nullptr; t.m[k] = nullptr; t.v[k] = nullptr; t.end[k] = total; t.step_size[k] = 0.f; t.src[k] = 0;
-        t.row_width[k] = 0;
+        t.row_width[k] = 0; t.frozen[k] = 0;
     }
     return total;
 }
@@ -1110,7 +1204,8 @@ int gsicp_adam_step(int n_groups, float* const* params, const float* const* grad
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr, bc1);
     if (total == 0) return 0;
     hipLaunchKernelGGL(adam_tensor_kernel<false>, adam_grid(t), dim3(256), 0, stream, t, (const double*)nullptr, (const int*)nullptr, beta1, beta2, eps,
-                       (float)(1.0 / std::sqrt(bc2)), (const unsigned*)nullptr, 0u, (const int*)nullptr);
+                       (float)(1.0 / std::sqrt(bc2)), (const unsigned*)nullptr, 0u, (const int*)nullptr, (int*)nullptr, (unsigned*)nullptr,
+                       (unsigned*)nullptr, (const int*)nullptr);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step: kernel launch failed"; return -1; }
     return 0;
 }
@@ -1119,20 +1214,37 @@ int gsicp_adam_step_guarded(int n_groups, float* const* params, const float* con
                             float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
                             float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
                             unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, void* stream_v) {
+    return gsicp_adam_step_masked(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr_dev, beta1, beta2, eps, step_dev, bump_step, guard_count,
+                                  guard_limit, skipped_dev, live_rows_dev, row_width, nullptr, nullptr, stream_v);
+}
+
+int gsicp_adam_step_masked(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                           float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
+                           float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
+                           unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, const int* row_freeze_dev,
+                           const int* group_frozen, void* stream_v) {
     hipStream_t stream = (hipStream_t)stream_v;
+    if (row_freeze_dev && (!row_width || !group_frozen)) { g_last_error = "gsicp_adam_step_masked: row_freeze needs row_width and group_frozen"; return -2; }
     if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || !lr_dev || !step_dev) {
         g_last_error = "gsicp_adam_step_capturable: 1..8 tensors, device lr array and device step counter"; return -2;
     }
     AdamTable t;
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, nullptr, 1.0);
-    if (live_rows_dev && row_width)
+    if ((live_rows_dev || row_freeze_dev) && row_width)
         for (int k = 0; k < t.n; ++k) t.row_width[k] = row_width[t.src[k]];
+    if (row_freeze_dev)
+        for (int k = 0; k < t.n; ++k) t.frozen[k] = group_frozen[t.src[k]] ? 1 : 0;
+    // the word the workgroups of the bumping launch count themselves into (see adam_tensor_kernel): one per (device, step counter), zeroed once.
+    // It cannot be allocated while a stream is being captured; a capture always follows eager warm-up steps, which allocate it.  Without it
+    // (or with nothing to update) the one-thread bump kernel runs, as in rounds 2-4.
+    unsigned* done = (bump_step && total > 0 && !g_adam_bump_kernel.load()) ? adam_done_word(step_dev, stream) : nullptr;
     {
         ProfileScope ps(ST_ADAM, stream);
         if (total > 0)
             hipLaunchKernelGGL(adam_tensor_kernel<true>, adam_grid(t), dim3(256), 0, stream, t, lr_dev, (const int*)step_dev, beta1, beta2, eps, 0.f,
-                               guard_count, guard_limit, (live_rows_dev && row_width) ? live_rows_dev : (const int*)nullptr);
-        if (bump_step)
+                               guard_count, guard_limit, (live_rows_dev && row_width) ? live_rows_dev : (const int*)nullptr, step_dev, done, skipped_dev,
+                               row_freeze_dev);
+        if (bump_step && !done)
             hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, stream, step_dev, guard_count, guard_limit, skipped_dev);
     }
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step_capturable: kernel launch failed"; return -1; }

@@ -245,8 +245,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
     }  // in_range
     // Emission-slot allocation: each Gaussian gets a private contiguous run of `mine` slots.  The runs need no global
     // order (only contiguity), so one block-aggregated atomic per workgroup replaces a device-wide prefix scan.
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_base;
+    // Round 5: the same atomic also allocates the workgroup's share of the backward's WORK LIST — the ids of the Gaussians that survived the culls
+    // (radii > 0), compacted by ballot rank.  The two counters are adjacent 32-bit words ([0] = slots, [1] = visible Gaussians) of one 8-byte-aligned
+    // 64-bit word: ONE 64-bit atomicAdd returns both bases (a second atomic doubled the kernel's dependent chain: +7 us, measured).  The list's
+    // order across workgroups is whatever the atomics gave; nothing depends on it (every Gaussian's gradients are computed independently).
+    __shared__ uint32_t s_wave[4], s_vwave[4];
+    __shared__ unsigned long long s_base64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = mine;
 #pragma unroll
@@ -254,39 +258,31 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
         const uint32_t o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
+    const bool vis = a.vis_list != nullptr && in_range && a.radii[idx] > 0;
+    const unsigned long long vm = __ballot(vis);
+    const uint32_t vrank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
     if (lane == 63) s_wave[wave] = incl;
+    if (lane == 0) s_vwave[wave] = (uint32_t)__popcll(vm);
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        s_base = tot ? atomicAdd(a.total_counter, tot) : 0u;
+        const uint32_t vtot = s_vwave[0] + s_vwave[1] + s_vwave[2] + s_vwave[3];
+        unsigned long long base = 0ull;
+        if (tot | vtot) {
+            if (a.vis_list) base = atomicAdd((unsigned long long*)a.total_counter, (unsigned long long)tot | ((unsigned long long)vtot << 32));
+            else base = (unsigned long long)atomicAdd(a.total_counter, tot);
+        }
+        s_base64 = base;
     }
     __syncthreads();
-    uint32_t wave_off = 0;
-    for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+    const uint32_t s_base = (uint32_t)s_base64, s_vbase = (uint32_t)(s_base64 >> 32);
+    uint32_t wave_off = 0, voff = 0;
+    for (int w = 0; w < wave; ++w) { wave_off += s_wave[w]; voff += s_vwave[w]; }
     if (in_range) {
         a.tiles_touched[idx] = mine;
         a.slot_base[idx] = s_base + wave_off + incl - mine;
     }
-    // Work list of the backward's per-Gaussian pass: the ids of the Gaussians that survived the culls (radii > 0), compacted the same way (ballot
-    // rank inside the wave, one atomic per workgroup).  Its ORDER across workgroups is whatever the atomics gave; nothing depends on it (every
-    // Gaussian's gradients are computed independently and written at its own index).
-    if (a.vis_list) {
-        __shared__ uint32_t s_vwave[4];
-        __shared__ uint32_t s_vbase;
-        const bool vis = in_range && a.radii[idx] > 0;
-        const unsigned long long vm = __ballot(vis);
-        const uint32_t vrank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
-        if (lane == 0) s_vwave[wave] = (uint32_t)__popcll(vm);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t tot = s_vwave[0] + s_vwave[1] + s_vwave[2] + s_vwave[3];
-            s_vbase = tot ? atomicAdd(a.vis_counter, tot) : 0u;
-        }
-        __syncthreads();
-        uint32_t voff = 0;
-        for (int w = 0; w < wave; ++w) voff += s_vwave[w];
-        if (vis) a.vis_list[s_vbase + voff + vrank] = (uint32_t)idx;
-    }
+    if (vis) a.vis_list[s_vbase + voff + vrank] = (uint32_t)idx;
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -588,29 +584,32 @@ __global__ __launch_bounds__(256) void preprocess_backward_legacy_kernel(Preproc
 }
 
 // ---- Round 5: the per-Gaussian pass in two launches.
-// (1) entry_run_sum_kernel — the SUMMATION of a Gaussian's run of records as a flat, fully coalesced pass over the emission slots: one lane per
-//     48-byte record, one wave per window of 64 consecutive slots, run boundaries from entry_gauss (slot -> Gaussian id).  Inside a window the ten sums
-//     are a segmented Hillis-Steele scan across the lanes (step d adds the value d records EARLIER IN THE SAME RUN): the additions a run's total is
-//     made of depend only on the position of a record inside its run, never on where the run sits in the window — so the result is bit-reproducible
-//     although the slot allocator (one atomic per workgroup) places runs differently from launch to launch.  A run that starts in a window and
-//     leaves it is summed by THAT wave in chunks of 64 records aligned to the run's start (the same scan per chunk — a run of <= 64 records gets
-//     the same bits on either path; chunk totals are added in order); lanes of a run that started in an earlier window idle.  The total replaces
-//     the record of the run's LAST slot.  No Gaussian's run sets the pace of anything: the longest run of a trained map (342 records) costs its wave
-//     six chunk rounds, where the legacy walk kept a lane busy for 86 dependent rounds.
+// (1) entry_run_sum_kernel — the SUMMATION of a Gaussian's run of records as a flat, coalesced pass over the emission slots: one wave per window
+//     of 64 consecutive slots, one lane per 48-byte record, run boundaries from entry_gauss (slot -> Gaussian id).  The wave stages its 64 records in
+//     a wave-private LDS slab; the lane that holds a run's LAST record then adds the run's records from the slab first to last — the same left
+//     fold, in slot order, the legacy kernel performed: the totals are BIT-IDENTICAL to rounds 3-4 (and independent of where the slot allocator
+//     placed the run).  A run that starts in a window and leaves it is folded by THAT wave, 64 records per trip through the same slab, the
+//     accumulator carried across trips; lanes of a run that started in an earlier window idle.  The total replaces the record of the run's last
+//     slot.  What the legacy walk paid per Gaussian — a chain of dependent global loads as long as its longest run per wave (342 records on a
+//     trained map: 86 rounds) — is now one coalesced load per record plus LDS reads.  (A first version summed with a segmented Hillis-Steele
+//     scan across the lanes: 130 ds_bpermute per window bound it to the LDS crossbar, 33 us at D = 1.3 M; and its tree order moved one
+//     ill-conditioned Gaussian of the S-map across the parity bound.)
 // (2) preprocess_backward_kernel — the per-Gaussian algebra over the forward's COMPACTED list of visible Gaussians (thread t takes list entry t:
 //     every lane of the leading waves works; on the S-map 82 % of the Gaussians are culled and the legacy kernel ran its 120-register body with
 //     a fifth of the lanes), reading ONE record per Gaussian; thread t also writes the zeros of Gaussian t when that one is invisible.
 __global__ __launch_bounds__(256) void entry_run_sum_kernel(const uint32_t* __restrict__ total_counter, const uint32_t capacity,
                                                             const uint32_t* __restrict__ entry_gauss, const uint32_t* __restrict__ tiles_touched,
                                                             float* __restrict__ entry_sum) {
+    __shared__ __attribute__((aligned(16))) float4 s_slab[4][64 * 3];
     const uint32_t total = *total_counter;
     const uint32_t R = total > capacity ? 0u : total;
-    const int lane = (int)(threadIdx.x & 63);
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
     const uint32_t n_windows = (R + 63u) / 64u;
     const uint32_t n_waves = gridDim.x * 4u;
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     float4* es = (float4*)entry_sum;
-    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_windows; w += n_waves) {
+    float4* slab = s_slab[wave];
+    for (uint32_t w = blockIdx.x * 4u + (uint32_t)wave; w < n_windows; w += n_waves) {
         const uint32_t u = w * 64u + (uint32_t)lane;
         const bool valid = u < R;
         const uint32_t g = valid ? entry_gauss[u] : NONE;
@@ -623,28 +622,23 @@ __global__ __launch_bounds__(256) void entry_run_sum_kernel(const uint32_t* __re
             const int o = __shfl_up(hl, off, 64);
             if (lane >= off) hl = o > hl ? o : hl;
         }
-        const int k = hl >= 0 ? lane - hl : -1;  // position of this lane's record inside its run
-        float v[NGRAD];
-#pragma unroll
-        for (int c = 0; c < NGRAD; ++c) v[c] = 0.f;
         if (valid && hl >= 0) {
-            const float4 q0 = es[3 * (size_t)u], q1 = es[3 * (size_t)u + 1], q2 = es[3 * (size_t)u + 2];
-            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w; v[8] = q2.x; v[9] = q2.y;
+            slab[3 * lane] = es[3 * (size_t)u]; slab[3 * lane + 1] = es[3 * (size_t)u + 1]; slab[3 * lane + 2] = es[3 * (size_t)u + 2];
         }
+        __builtin_amdgcn_wave_barrier();         // a wave's LDS operations execute in program order; this only stops the compiler from reordering them
+        if (tail && hl >= 0) {                   // a complete run inside the window: left fold of slab[hl .. lane]
+            float v[NGRAD];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-            for (int c = 0; c < NGRAD; ++c) {
-                const float o = __shfl_up(v[c], off, 64);
-                if (k >= off) v[c] += o;
+            for (int c = 0; c < NGRAD; ++c) v[c] = 0.f;
+            for (int j = hl; j <= lane; ++j) {
+                const float4 q0 = slab[3 * j], q1 = slab[3 * j + 1], q2 = slab[3 * j + 2];
+                v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w; v[8] += q2.x; v[9] += q2.y;
             }
-        }
-        if (tail && hl >= 0) {
             es[3 * (size_t)u] = make_float4(v[0], v[1], v[2], v[3]);
             es[3 * (size_t)u + 1] = make_float4(v[4], v[5], v[6], v[7]);
             es[3 * (size_t)u + 2] = make_float4(v[8], v[9], 0.f, 0.f);
         }
-        // the run that starts in this window and leaves it
+        // the run that starts in this window and leaves it: 64 records per trip through the slab, lane 0 folds
         const int hl63 = __shfl(hl, 63, 64);
         const int open63 = __shfl((int)(valid && !tail), 63, 64);
         if (open63 != 0 && hl63 >= 0) {
@@ -656,27 +650,19 @@ __global__ __launch_bounds__(256) void entry_run_sum_kernel(const uint32_t* __re
             for (int c = 0; c < NGRAD; ++c) acc[c] = 0.f;
             for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
                 const uint32_t pos = c0 + (uint32_t)lane;
-                float x[NGRAD];
-#pragma unroll
-                for (int c = 0; c < NGRAD; ++c) x[c] = 0.f;
+                __builtin_amdgcn_wave_barrier();
                 if (pos < n) {
                     const size_t uu = (size_t)s0 + pos;
-                    const float4 q0 = es[3 * uu], q1 = es[3 * uu + 1], q2 = es[3 * uu + 2];
-                    x[0] = q0.x; x[1] = q0.y; x[2] = q0.z; x[3] = q0.w; x[4] = q1.x; x[5] = q1.y; x[6] = q1.z; x[7] = q1.w; x[8] = q2.x; x[9] = q2.y;
+                    slab[3 * lane] = es[3 * uu]; slab[3 * lane + 1] = es[3 * uu + 1]; slab[3 * lane + 2] = es[3 * uu + 2];
                 }
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-                    for (int c = 0; c < NGRAD; ++c) {
-                        const float o = __shfl_up(x[c], off, 64);
-                        if (lane >= off) x[c] += o;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    const int cnt = (n - c0) >= 64u ? 64 : (int)(n - c0);
+                    for (int j = 0; j < cnt; ++j) {
+                        const float4 q0 = slab[3 * j], q1 = slab[3 * j + 1], q2 = slab[3 * j + 2];
+                        acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w; acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;
+                        acc[8] += q2.x; acc[9] += q2.y;
                     }
-                }
-                const int last = (n - c0) >= 64u ? 63 : (int)(n - c0) - 1;
-#pragma unroll
-                for (int c = 0; c < NGRAD; ++c) {
-                    const float t = __shfl(x[c], last, 64);
-                    acc[c] = c0 == 0u ? t : acc[c] + t;
                 }
             }
             if (lane == 0) {
@@ -686,6 +672,7 @@ __global__ __launch_bounds__(256) void entry_run_sum_kernel(const uint32_t* __re
                 es[3 * ut + 2] = make_float4(acc[8], acc[9], 0.f, 0.f);
             }
         }
+        __builtin_amdgcn_wave_barrier();         // the next window's stores into the slab stay behind this window's reads
     }
 }
 

@@ -7,7 +7,8 @@ the fused loss and the capturable fused Adam, nothing in the iteration needs the
 once (`torch.cuda.CUDAGraph`, i.e. hipGraph) and replayed with one launch per iteration.
 
 What changes from iteration to iteration in the reference — the keyframe: camera matrices and the two target images —
-lives in static device buffers that `set_view()` overwrites before `step()`.  Everything with a fixed address (parameters,
+is selected by `set_view()` before `step()`: the camera goes into static device buffers, the two images are read IN PLACE through a device
+slot pair holding their addresses (round 5; rounds 2-4 copied 13 MB per iteration into static image buffers).  Everything with a fixed address (parameters,
 Adam state, learning rates, step count) is updated in place by the replay.  The graph is valid while the parameter tensors
 are the ones captured.  Over a `GaussianStore(stable=True)` (full-capacity buffers, live count on the device: pass `live_count=`) that is the
 WHOLE RUN — keyframe growth and pruning change no pointer and no launch grid, so nothing is ever re-captured.  Over reference-style storage
@@ -69,8 +70,13 @@ class MapperIterationGraph:
         self.viewmatrix = torch.eye(4, **f32)
         self.projmatrix = torch.eye(4, **f32)
         self.campos = torch.zeros(3, **f32)
-        self.gt_image = torch.zeros((3, H, W), **f32)
-        self.gt_depth = torch.zeros((1, H, W), **f32)
+        # ground truth of the selected keyframe: NOT copied (round 5).  The captured loss kernels read the two image pointers from `gt_slots`
+        # (device int64[2]); set_view() writes them together with the camera in one 64-thread launch and keeps the tensors alive.  Inputs that
+        # cannot be read in place (host tensors, other dtypes, strided views) go through the two staging buffers, allocated on first need.
+        self._H, self._W = H, W
+        self.gt_slots = torch.zeros(2, dtype=torch.int64, device=dev)
+        self._gt_refs = None
+        self._gt_stage = None
         self.bg = torch.zeros(3, **f32) if bg is None else bg.to(**f32)
         rs = GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=float(tanfovx), tanfovy=float(tanfovy), bg=self.bg, scale_modifier=1.0,
@@ -114,25 +120,31 @@ class MapperIterationGraph:
 
     # ------------------------------------------------------------------------------------------------------------
     def set_view(self, viewmatrix, projmatrix, campos, gt_image, gt_depth):
-        """Select the keyframe of the next step(): one launch refreshes the graph's static inputs (device tensors in, float32)."""
-        ok = lambda t, n: t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n and t.data_ptr() % 16 == 0
-        HW = self.gt_depth.numel()
-        if HW % 4 == 0 and ok(viewmatrix, 16) and ok(projmatrix, 16) and campos.is_cuda and campos.dtype == torch.float32 and \
-                campos.numel() == 3 and campos.is_contiguous() and ok(gt_image, 3 * HW) and ok(gt_depth, HW):
-            lib = _lib.load()
-            dev = self.gt_depth.device
-            p = lambda t: ctypes.c_void_p(t.data_ptr())
-            with torch.cuda.device(dev):
-                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-                _lib.check(lib.gsicp_mapper_set_view(self.gt_depth.shape[-1], self.gt_depth.shape[-2], p(viewmatrix), p(projmatrix), p(campos),
-                                                     p(gt_image), p(gt_depth), p(self.viewmatrix), p(self.projmatrix), p(self.campos),
-                                                     p(self.gt_image), p(self.gt_depth), stream), "gsicp_mapper_set_view")
-            return
-        self.viewmatrix.copy_(viewmatrix, non_blocking=True)          # host tensors / other dtypes: plain copies
-        self.projmatrix.copy_(projmatrix, non_blocking=True)
-        self.campos.copy_(campos.reshape(3), non_blocking=True)
-        self.gt_image.copy_(gt_image.reshape(self.gt_image.shape), non_blocking=True)
-        self.gt_depth.copy_(gt_depth.reshape(self.gt_depth.shape), non_blocking=True)
+        """Select the keyframe of the next step(): ONE 64-thread launch writes the camera into the graph's static inputs and the addresses of the two
+        ground-truth images into the slot pair the captured loss kernels read.  The images are used IN PLACE: they must not be modified until the
+        replay has finished (this object holds references to them until the next set_view)."""
+        dev = self.gt_slots.device
+        HW = self._H * self._W
+        f32 = lambda t, n: t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n   # noqa: E731
+        cam_ok = f32(viewmatrix, 16) and f32(projmatrix, 16) and f32(campos, 3)
+        if not cam_ok:
+            viewmatrix = viewmatrix.to(device=dev, dtype=torch.float32).contiguous()
+            projmatrix = projmatrix.to(device=dev, dtype=torch.float32).contiguous()
+            campos = campos.to(device=dev, dtype=torch.float32).reshape(3).contiguous()
+        if not (f32(gt_image, 3 * HW) and f32(gt_depth, HW) and gt_image.data_ptr() % 16 == 0 and gt_depth.data_ptr() % 16 == 0):
+            if self._gt_stage is None:
+                self._gt_stage = (torch.zeros((3, self._H, self._W), dtype=torch.float32, device=dev),
+                                  torch.zeros((1, self._H, self._W), dtype=torch.float32, device=dev))
+            self._gt_stage[0].copy_(gt_image.reshape(self._gt_stage[0].shape), non_blocking=True)
+            self._gt_stage[1].copy_(gt_depth.reshape(self._gt_stage[1].shape), non_blocking=True)
+            gt_image, gt_depth = self._gt_stage
+        lib = _lib.load()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.gsicp_mapper_select_view(p(viewmatrix), p(projmatrix), p(campos), p(gt_image), p(gt_depth), p(self.viewmatrix),
+                                                    p(self.projmatrix), p(self.campos), p(self.gt_slots), stream), "gsicp_mapper_select_view")
+        self._gt_refs = (viewmatrix, projmatrix, campos, gt_image, gt_depth)
 
     def _iteration(self):
         if self._fused_activations:
@@ -145,8 +157,8 @@ class MapperIterationGraph:
         # the loss kernels produce dL/dimage and dL/ddepth directly: no autograd node, no ones_like / multiply launches.  Tile-sharded over several
         # GPUs the loss is sharded with the tiles: this rank's 32x32 blocks only; its share of the four values travels inside the gradient exchange
         shard = self.rasterizer.loss_shard() if hasattr(self.rasterizer, "loss_shard") else (1, 0)
-        parts, g_color, g_depth = mapper_loss_and_grads(color, depth, self.gt_image, self.gt_depth, lambda_dssim=self.lambda_dssim,
-                                                        depth_weight=self.depth_weight, d_max=self.d_max, tile_mod=shard[0], tile_rem=shard[1])
+        parts, g_color, g_depth = mapper_loss_and_grads(color, depth, None, None, lambda_dssim=self.lambda_dssim, depth_weight=self.depth_weight,
+                                                        d_max=self.d_max, tile_mod=shard[0], tile_rem=shard[1], gt_slots=self.gt_slots)
         if shard[0] > 1:
             self.rasterizer.attach_loss_share(parts)
         torch.autograd.backward((color, depth), (g_color, g_depth))
@@ -169,6 +181,8 @@ class MapperIterationGraph:
             return self._capture()   # the launches captured inside read THIS graph's count / limit / live rows
 
     def _capture(self):
+        if self._gt_refs is None:
+            raise RuntimeError("MapperIterationGraph.capture(): call set_view() first (the captured loss kernels read the keyframe's images through it)")
         dev = self.params["means3D"].device
         self.optimizer.zero_grad(set_to_none=True)
         snap_p = {k: v.detach().clone() for k, v in self.params.items()}

@@ -61,28 +61,41 @@ def mapper_loss_parts(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_
     return _MapperLoss.apply(image, depth, gt_image, gt_depth, lambda_dssim, depth_weight, d_max)
 
 
-def mapper_loss_and_grads(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_weight=0.1, d_max=10.0, tile_mod=1, tile_rem=0):
+def mapper_loss_and_grads(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_weight=0.1, d_max=10.0, tile_mod=1, tile_rem=0, gt_slots=None):
     """No-autograd form for callers that drive the backward themselves (gs_icp_slam_amd/graph.py):
     -> (tensor([loss, L1, SSIM mean, depth L1]), dL/dimage (3,H,W), dL/ddepth (1,H,W)), the gradients being those of `loss`
     itself, so no ones_like / multiply launches are needed before `torch.autograd.backward((image, depth), (g_image, g_depth))`.
     tile_mod > 1 (multi-GPU mapper): this rank's 32x32 blocks only (gsicp_mapper_loss_sharded) — the four values are this rank's SHARE
-    (their sum over the ranks is the loss) and the gradients are defined on the rank's own blocks (zero elsewhere)."""
+    (their sum over the ranks is the loss) and the gradients are defined on the rank's own blocks (zero elsewhere).
+    gt_slots (int64[2] DEVICE tensor holding the addresses of the ground-truth image and depth, written by gsicp_mapper_select_view): the kernels
+    read the two pointers on the device when they start (gsicp_mapper_loss_indirect) — a captured iteration then follows the keyframe selection
+    without any image being copied; gt_image / gt_depth are ignored (may be None)."""
     lib = _lib.load()
     if not image.is_cuda:
         raise RuntimeError("mapper_loss (gfx950): tensors must live on the HIP device; there is no CPU path")
     dev = image.device
     f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
-    image_c, depth_c, gt_c, gtd_c = f(image), f(depth), f(gt_image), f(gt_depth)
+    image_c, depth_c = f(image), f(depth)
     H, W = image_c.shape[-2], image_c.shape[-1]
-    if image_c.numel() != 3 * H * W or depth_c.numel() != H * W or gt_c.numel() != 3 * H * W or gtd_c.numel() != H * W:
-        raise RuntimeError("mapper_loss: expected image/gt_image (3,H,W) and depth/gt_depth (1,H,W)")
+    if image_c.numel() != 3 * H * W or depth_c.numel() != H * W:
+        raise RuntimeError("mapper_loss: expected image (3,H,W) and depth (1,H,W)")
+    if gt_slots is None:
+        gt_c, gtd_c = f(gt_image), f(gt_depth)
+        if gt_c.numel() != 3 * H * W or gtd_c.numel() != H * W:
+            raise RuntimeError("mapper_loss: expected image/gt_image (3,H,W) and depth/gt_depth (1,H,W)")
+    elif not (gt_slots.is_cuda and gt_slots.dtype == torch.int64 and gt_slots.numel() == 2 and gt_slots.is_contiguous()):
+        raise RuntimeError("mapper_loss: gt_slots must be a contiguous int64[2] device tensor")
     with torch.cuda.device(dev):
         out = torch.empty(4, dtype=torch.float32, device=dev)
         sharded = int(tile_mod) > 1
         g_img, g_dep = (torch.zeros_like(image_c), torch.zeros_like(depth_c)) if sharded else (torch.empty_like(image_c), torch.empty_like(depth_c))
         scratch = torch.empty(int(lib.gsicp_mapper_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        if sharded:
+        if gt_slots is not None:
+            _lib.check(lib.gsicp_mapper_loss_indirect(_p(image_c), _p(depth_c), _p(gt_slots), W, H, float(lambda_dssim), float(depth_weight), float(d_max),
+                                                      int(tile_mod), int(tile_rem), _p(out), _p(g_img), _p(g_dep), _p(scratch), stream),
+                       "gsicp_mapper_loss_indirect")
+        elif sharded:
             _lib.check(lib.gsicp_mapper_loss_sharded(_p(image_c), _p(depth_c), _p(gt_c), _p(gtd_c), W, H, float(lambda_dssim), float(depth_weight),
                                                      float(d_max), int(tile_mod), int(tile_rem), _p(out), _p(g_img), _p(g_dep), _p(scratch), stream),
                        "gsicp_mapper_loss_sharded")

@@ -27,6 +27,18 @@ class FusedAdam(torch.optim.Optimizer):
         self._guard = None      # (count tensor uint32/int32[1], limit): skip the step when count > limit (capturable path)
         self.skipped_steps = None   # device int32[1], sticky: steps skipped by the guard since construction (read it whenever convenient)
         self._live_rows = None      # device int32[1]: parameters are capacity-backed, only this many leading rows are updated
+        self._row_freeze = None     # (device int32[rows] mask, names of the param groups it applies to): rows with a non-zero word are left alone
+
+    def set_row_freeze(self, mask, group_names):
+        """Capturable path: the param groups named in `group_names` (their "name" key, as GaussianModel sets it [REF scene/gaussian_model.py:222-229])
+        leave the rows whose `mask` word (DEVICE int32, one per row, read at every step) is non-zero untouched — parameter and both moments, as if
+        those rows were no parameters.  `mask=None` removes it.  (gsicp_adam_step_masked; used by refglue's `freeze` policy.)"""
+        if mask is None:
+            self._row_freeze = None
+            return
+        if not mask.is_cuda or mask.dtype != torch.int32 or not mask.is_contiguous():
+            raise RuntimeError("FusedAdam.set_row_freeze: expected a contiguous int32 device tensor (one word per row)")
+        self._row_freeze = (mask, frozenset(group_names))
 
     def scoped_bindings(self, guard=None, live_rows=None):
         """Context manager: bind an overflow guard and / or a live-row count for the launches issued inside (a graph capture), then restore
@@ -133,13 +145,22 @@ class FusedAdam(torch.optim.Optimizer):
                 M = (ctypes.c_void_p * n)(*[t[2].data_ptr() for t in items])
                 V = (ctypes.c_void_p * n)(*[t[3].data_ptr() for t in items])
                 N = (ctypes.c_longlong * n)(*[t[0].numel() for t in items])
-                live_ptr, RW = None, None
+                live_ptr, RW, freeze_ptr, FR = None, None, None, None
+                freeze = self._row_freeze if (self._row_freeze is not None and self._row_freeze[0].device == dev) else None
+                if (self._live_rows is not None and self._live_rows.device == dev) or freeze is not None:
+                    RW = (ctypes.c_int * n)(*[(t[0].numel() // t[0].shape[0]) if t[0].dim() > 0 and t[0].shape[0] > 0 else 0 for t in items])
                 if self._live_rows is not None and self._live_rows.device == dev:
                     live_ptr = ctypes.c_void_p(self._live_rows.data_ptr())
-                    RW = (ctypes.c_int * n)(*[(t[0].numel() // t[0].shape[0]) if t[0].dim() > 0 and t[0].shape[0] > 0 else 0 for t in items])
-                _lib.check(lib.gsicp_adam_step_guarded(n, P, G, M, V, N, ctypes.c_void_p(lr_dev.data_ptr()), b1, b2, eps,
-                                                       ctypes.c_void_p(items[0][5].data_ptr()), int(last_of[sp] == li), guard_ptr, guard_lim,
-                                                       skip_ptr, live_ptr, RW, stream), "gsicp_adam_step_guarded")
+                if freeze is not None:
+                    flags = [1 if self.param_groups[t[6][0]].get("name") in freeze[1] else 0 for t in items]
+                    for t, fl in zip(items, flags):
+                        if fl and t[0].shape[0] > freeze[0].numel():
+                            raise RuntimeError("FusedAdam.set_row_freeze: the mask has fewer words than the tensor has rows")
+                    if any(flags):
+                        freeze_ptr, FR = ctypes.c_void_p(freeze[0].data_ptr()), (ctypes.c_int * n)(*flags)
+                _lib.check(lib.gsicp_adam_step_masked(n, P, G, M, V, N, ctypes.c_void_p(lr_dev.data_ptr()), b1, b2, eps,
+                                                      ctypes.c_void_p(items[0][5].data_ptr()), int(last_of[sp] == li), guard_ptr, guard_lim,
+                                                      skip_ptr, live_ptr, RW, freeze_ptr, FR, stream), "gsicp_adam_step_masked")
         # Device lr arrays are NEVER freed: a captured MapperIterationGraph holds their addresses, and an eager step() that happens
         # to see fewer gradients (zero_grad(set_to_none=True), different chunking) must not hand that memory back to the caching allocator
         # while a graph may still replay.  One entry is <= 8 doubles; the number of distinct buckets an optimiser ever sees is a handful.

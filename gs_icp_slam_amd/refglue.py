@@ -66,6 +66,9 @@ def patch_gaussian_model(cls):
         lrs = {"xyz": training_args.position_lr_init * self.spatial_lr_scale, "f_dc": training_args.feature_lr, "f_rest": training_args.feature_lr / 20.0,
                "opacity": training_args.opacity_lr, "scaling": training_args.scaling_lr, "rotation": training_args.rotation_lr}
         self.optimizer = self._store.attach(FusedAdam, lrs, lr=0.0, eps=1e-15, capturable=True)
+        pol = fused_policy()
+        if pol["freeze_groups"]:      # the `freeze` policy (default): the Gaussians the tracker aligns against keep their geometry (see fused_policy)
+            self.optimizer.set_row_freeze(self._store._sets[0][("aux", "trackable_mask")], pol["freeze_groups"])
         self.xyz_scheduler_args = get_expon_lr_func(lr_init=training_args.position_lr_init * self.spatial_lr_scale,
                                                     lr_final=training_args.position_lr_final * self.spatial_lr_scale,
                                                     lr_delay_mult=training_args.position_lr_delay_mult, max_steps=training_args.position_lr_max_steps)
@@ -118,7 +121,7 @@ def _stamp(mapper):
                 print(f"GSICP_FUSED_MAPPER iterations {len(_STAMPS)} median_ms {1e3 * d[len(d) // 2]:.4f} mean_ms {1e3 * sum(d) / len(d):.4f} "
                       f"p90_ms {1e3 * d[int(0.9 * (len(d) - 1))]:.4f} captures {mapper.__dict__.get('_gsicp_captures', 0)} gaussians {mapper.gaussians._store.n} "
                       f"gpu_median_ms {g[len(g) // 2]:.4f} gpu_p90_ms {g[int(0.9 * (len(g) - 1))]:.4f} paced_waits {mapper.gaussians.__dict__.get('_gsicp_paced', 0)} "
-                      f"iters_per_frame {os.environ.get('GSICP_FUSED_ITERS_PER_FRAME', str(DEFAULT_ITERS_PER_FRAME))}", flush=True)
+                      f"iters_per_frame {fused_policy()['iters_per_frame']} policy {fused_policy()['name']}", flush=True)
         atexit.register(report)
     _STAMPS.append(time.perf_counter())
 
@@ -139,23 +142,9 @@ def fused_mapping_iteration(mapper, viewpoint_cam, gt_image, gt_depth_image):
                   "scales": store.params["scaling"], "rotations": store.params["rotation"]}
         if store.n_rest != 0:
             raise RuntimeError("fused mapping iteration: sh_degree > 0 needs the f_dc / f_rest concatenation inside the graph (not built: the reference runs sh_degree 0)")
-        # experiment knob (measured in profiles/r05_fused_pacing_sweep.json; NOT the reference's optimiser): free-run, but the
-        # Gaussians the tracker aligns against (the trackable rows) keep their position ("xyz") or position + shape ("geom") — their gradients are
-        # zeroed before Adam, so with zero moments they never move
-        freeze = os.environ.get("GSICP_FUSED_FREEZE_TRACKABLE", "")
-        hook = None
-        if freeze in ("xyz", "geom"):
-            keep = store._sets[0][("aux", "trackable_mask")]          # static full-capacity int32 0 / 1 (stable store)
-            names = ("means3D",) if freeze == "xyz" else ("means3D", "scales", "rotations")
-
-            def hook(p, keep=keep, names=names):
-                w = (1 - keep).to(torch.float32).unsqueeze(-1)
-                for nm in names:
-                    if p[nm].grad is not None:
-                        p[nm].grad.mul_(w)
         mg = MapperIterationGraph(params, gm.optimizer, H, W, math.tan(float(viewpoint_cam.FoVx[0]) * 0.5), math.tan(float(viewpoint_cam.FoVy[0]) * 0.5),
                                   sh_degree=gm.active_sh_degree, capacity=int(os.environ.get("GSICP_FUSED_LIST_CAPACITY", str(1 << 23))),
-                                  bg=mapper.background, lambda_dssim=mapper.lambda_dssim, warmup=1, live_count=store.live_count, grad_hook=hook)
+                                  bg=mapper.background, lambda_dssim=mapper.lambda_dssim, warmup=1, live_count=store.live_count)
         mg.set_view(viewpoint_cam.world_view_transform, viewpoint_cam.full_proj_transform, viewpoint_cam.camera_center, gt_image.contiguous(),
                     gt_depth_image.contiguous())
         mg.capture()                            # applies no optimiser update (the warm-up is rolled back)
@@ -191,12 +180,37 @@ def fused_mapping_iteration(mapper, viewpoint_cam, gt_image, gt_depth_image):
     return loss
 
 
-# Default iteration budget of the in-system fused mapper, in Adam steps per TRACKED FRAME.  The reference's mapper free-runs [REF mp_Mapper.py:150-262]
-# and its speed decides how far the map has been optimised when the tracker next re-targets on it [REF mp_Tracker.py:282-288]: on the box this was
-# measured on, the untouched loop fits 0.3-2 iterations into a tracked frame, the fused one 7-50.  On noisy depth that is not neutral — ATE grows
-# with the iteration count (profiles/r05_fused_pacing_sweep.json) — so the DEFAULT keeps the fused system at the reference's iterations-per-frame
-# scale and leaves the GPU time it frees to the tracker; `GSICP_FUSED_ITERS_PER_FRAME=0` free-runs.
+# ---- How the in-system fused mapper shares the map with the tracker: the POLICY (GSICP_FUSED_POLICY), measured in profiles/r05_fused_pacing_sweep*.json.
+# The reference's mapper free-runs [REF mp_Mapper.py:150-262] and the tracker re-targets on the map's trackable Gaussians — position, rotation
+# and scale as the optimiser has left them [REF mp_Tracker.py:282-288; scene/gaussian_model.py:207-215] — at every tracking keyframe.  How far
+# those have been optimised by then depends on the mapper's speed: the untouched loop fits 0.3-2 Adam steps into a tracked frame on this box,
+# the fused one 7-50.  On NOISY depth that is not neutral: 300 noisy frames, untouched ATE 0.8-1.0 cm; fused free-running 6.8-9.6 cm; fused with
+# only the POSITIONS of the trackable Gaussians frozen 9.6 cm; with position + scale + rotation frozen 0.56-0.62 cm — the damage goes through the
+# covariances the tracker receives (thousands of steps on noisy depth stretch the Gaussians into needles, the GICP planes follow the needles), not
+# through the iteration count as such.  Policies:
+#   freeze (default)  free-run; the TRACKABLE Gaussians [REF scene/gaussian_model.py:143-180 trackable_mask] keep the position, scale and rotation
+#                     GICP gave them (FusedAdam.set_row_freeze: those rows of xyz / scaling / rotation are no parameters; colour and opacity of
+#                     every Gaussian and the geometry of the non-trackable ones train as in the reference).  Meets the bar — ATE <= untouched + 0.1 cm,
+#                     PSNR >= untouched — with the MOST iterations: 300 noisy frames 0.56-0.62 cm / 27.7-28.2 dB at 2 050-2 110 iterations
+#                     (untouched 0.77-1.04 cm / 22.8-23.3 dB), 16 363 iterations at the 30-FPS cap 0.67 cm / 28.3 dB (round 4, free-running: 9.3 cm),
+#                     TUM-shaped 0.31-0.37 cm / 27.3 dB (untouched 0.31 cm / 17.3 dB), noise-free 0.005 cm / 34.1 dB.
+#   budget            the reference's optimiser untouched, at most GSICP_FUSED_ITERS_PER_FRAME (2) steps per tracked frame, the GPU time it frees
+#                     left to the tracker: 0.74-0.84 cm / 25.1-25.7 dB at 614 iterations; 4 per frame already loses the track (7.8 cm).
+#   free              rounds 3-4: free-run, everything trains (noise-free data only).
+# GSICP_FUSED_FREEZE_GROUPS overrides which parameter groups the freeze covers (e.g. "xyz": the experiment that showed positions are not the cause).
+DEFAULT_POLICY = "freeze"
 DEFAULT_ITERS_PER_FRAME = 2.0
+
+
+def fused_policy():
+    name = os.environ.get("GSICP_FUSED_POLICY", DEFAULT_POLICY)
+    if name not in ("freeze", "budget", "free"):
+        raise RuntimeError(f"GSICP_FUSED_POLICY={name!r}: expected freeze, budget or free")
+    groups = ()
+    if name == "freeze":
+        groups = tuple(g for g in os.environ.get("GSICP_FUSED_FREEZE_GROUPS", "xyz,scaling,rotation").split(",") if g)
+    k = float(os.environ.get("GSICP_FUSED_ITERS_PER_FRAME", str(DEFAULT_ITERS_PER_FRAME if name == "budget" else 0.0)))
+    return dict(name=name, freeze_groups=groups, iters_per_frame=k)
 
 
 def _pace(mapper, gm):
@@ -215,7 +229,7 @@ def _pace(mapper, gm):
             if wait > 0:
                 time.sleep(wait)
         gm.__dict__["_gsicp_t_prev"] = time.perf_counter()
-    k = float(os.environ.get("GSICP_FUSED_ITERS_PER_FRAME", str(DEFAULT_ITERS_PER_FRAME)))
+    k = fused_policy()["iters_per_frame"]
     frames = getattr(mapper, "iter_shared", None)
     flags = [getattr(mapper, n, None) for n in ("end_of_dataset", "is_tracking_keyframe_shared", "is_mapping_keyframe_shared")]
     if k <= 0 or frames is None or any(f is None for f in flags):

@@ -284,6 +284,19 @@ int gsicp_mapper_set_view(int width, int height, const float* viewmatrix, const 
                           const float* gt_depth, float* dst_viewmatrix, float* dst_projmatrix, float* dst_campos, float* dst_gt_image,
                           float* dst_gt_depth, void* stream);
 
+/* Round 5: keyframe selection WITHOUT moving the images.  The captured iteration's loss kernels read the two ground-truth pointers from a DEVICE
+ * slot pair (gsicp_mapper_loss_indirect below); gsicp_mapper_select_view writes the camera (16 + 16 + 3 floats) into the graph's static buffers and the
+ * two pointers into `dst_gt_slots` (device memory, 2 x 8 bytes) in one 64-thread launch.  The images must stay valid (and unchanged) until the
+ * replay that reads them has finished — the caller keeps the keyframe's tensors alive, as the reference's mapping_cams list does
+ * [REF mp_Mapper.py:147, 175]. */
+int gsicp_mapper_select_view(const float* viewmatrix, const float* projmatrix, const float* campos, const float* gt_image, const float* gt_depth,
+                             float* dst_viewmatrix, float* dst_projmatrix, float* dst_campos, const float** dst_gt_slots, void* stream);
+/* gsicp_mapper_loss / gsicp_mapper_loss_sharded (tile_mod > 1) with the ground-truth images taken from gt_slots[0] (3,H,W) and gt_slots[1] (1,H,W),
+ * read ON THE DEVICE when the kernels start. */
+int gsicp_mapper_loss_indirect(const float* image, const float* depth, const float* const* gt_slots, int width, int height, float lambda_dssim,
+                               float depth_weight, float d_max, int tile_mod, int tile_rem, float* loss_out, float* dL_dimage, float* dL_ddepth,
+                               char* scratch, void* stream);
+
 /* GaussianModel's activation getters in one launch each way [REF scene/gaussian_model.py:44-56, 105-125], reached from
  * render_3 at [REF gaussian_renderer/__init__.py:263, 273-274]: opacity = sigmoid(opacity_raw) (P), scaling =
  * exp(scaling_raw) (P,3), rotation = rotation_raw / max(||rotation_raw||, 1e-12) (P,4).  All DEVICE float arrays. */
@@ -323,6 +336,16 @@ int gsicp_adam_step_guarded(int n_groups, float* const* params, const float* con
                             float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
                             float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
                             unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, void* stream);
+
+/* gsicp_adam_step_guarded with a ROW FREEZE: when row_freeze_dev (DEVICE int[rows]) is non-NULL, tensor k with group_frozen[k] != 0 (HOST array of
+ * n_groups ints) leaves the rows whose freeze word is non-zero untouched — parameter and both moments, as if those rows were not parameters
+ * (row_width is then required).  What the fused in-system mapper uses to keep the geometry of the Gaussians the tracker aligns against
+ * (gs_icp_slam_amd/refglue.py, policy `freeze`).  Live-row bound: with a live count the element index is below 2^32. */
+int gsicp_adam_step_masked(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                           float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
+                           float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
+                           unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, const int* row_freeze_dev,
+                           const int* group_frozen, void* stream);
 
 /* Map pruning without reallocation: GaussianModel.prune_points / _prune_optimizer
  * [REF scene/gaussian_model.py:409-447] apply one boolean mask to every parameter, both Adam moments and the per-Gaussian

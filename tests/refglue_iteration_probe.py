@@ -23,6 +23,9 @@ cfg = synth.REPLICA
 poses = synth.trajectory(12)
 rgb, d16 = synth.render_frame(cfg, poses[0])
 pts, z, trackable, depth_m = synth.frame_points(cfg, poses[0])
+import os                                                # noqa: E402
+if os.environ.get("GSICP_PROBE_TRACKABLE_EVERY"):        # a map that holds trackable AND non-trackable Gaussians (the freeze-policy test)
+    trackable = trackable[::int(os.environ["GSICP_PROBE_TRACKABLE_EVERY"])]
 pw = (pts.astype(np.float64) @ poses[0][:3, :3].T + poses[0][:3, 3]).astype(np.float32)
 reg = pygicp.FastGICP()
 reg.set_max_knn_distance(99999.0)
@@ -75,5 +78,6 @@ for i in range(iters):
     mapper.train_iter += 1
 torch.cuda.synchronize()
 np.savez(out, losses=np.array(losses), xyz=gm.get_xyz.detach().cpu().numpy(), f_dc=gm._features_dc.detach().cpu().numpy(),
-         opacity=gm._opacity.detach().cpu().numpy(), scaling=gm._scaling.detach().cpu().numpy(), rotation=gm._rotation.detach().cpu().numpy())
+         opacity=gm._opacity.detach().cpu().numpy(), scaling=gm._scaling.detach().cpu().numpy(), rotation=gm._rotation.detach().cpu().numpy(),
+         trackable=gm.trackable_mask.detach().cpu().numpy().astype(np.uint8))
 print("probe ok", mode, len(losses), gm.get_xyz.shape[0])

@@ -95,6 +95,72 @@ def test_capturable_adam_equals_host_step_adam():
         torch.testing.assert_close(pa, pb, rtol=2e-6, atol=2e-7)
 
 
+def test_row_freeze_and_in_kernel_step_bump():
+    """Round 5: (a) FusedAdam.set_row_freeze — the named groups leave the rows with a non-zero mask word bit for bit alone (parameter and both
+    moments) while every other row, and every row of the other groups, steps exactly as an optimiser without the mask; (b) the step counter of the
+    capturable path is advanced by the LAST WORKGROUP of the Adam launch (no bump kernel): it counts every step once, also across a captured and
+    replayed graph, and a tripped guard counts a skipped step instead."""
+    from gs_icp_slam_amd.optim import FusedAdam
+    torch.manual_seed(1)
+    names = ["xyz", "f_dc", "opacity", "scaling", "rotation"]
+    shapes = [(3001, 3), (3001, 1, 3), (3001, 1), (3001, 3), (3001, 4)]
+    lrs = [4e-6, 2.5e-3, 0.05, 5e-3, 1e-3]
+    p_a = [torch.randn(s, device="cuda", requires_grad=True) for s in shapes]
+    p_b = [p.detach().clone().requires_grad_(True) for p in p_a]
+    start = [p.detach().clone() for p in p_a]
+    oa = FusedAdam([{"params": [p], "lr": lr, "name": n} for p, lr, n in zip(p_a, lrs, names)], lr=0.0, eps=1e-15, capturable=True)
+    ob = FusedAdam([{"params": [p], "lr": lr, "name": n} for p, lr, n in zip(p_b, lrs, names)], lr=0.0, eps=1e-15, capturable=True)
+    mask = (torch.rand(3001, device="cuda") < 0.4).to(torch.int32)
+    ob.set_row_freeze(mask, ("xyz", "scaling", "rotation"))
+    guard = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ob.set_overflow_guard(guard, 10)
+    grads = [[torch.randn_like(p) for p in p_a] for _ in range(9)]
+
+    def feed(k):
+        for pa, pb, gr in zip(p_a, p_b, grads[k]):
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+    for k in range(3):                      # eager steps (the first allocates the device lr arrays and the done word)
+        feed(k)
+        oa.step(); ob.step()
+    assert int(ob.state[p_b[0]]["step"].item()) == 3 and int(oa.state[p_a[0]]["step"].item()) == 3
+    # captured + replayed: static gradient tensors
+    for pb in p_b:
+        pb.grad = torch.zeros_like(pb)
+    gph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for pb, gr in zip(p_b, grads[3]):
+            pb.grad.copy_(gr)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(gph):
+        ob.step()
+    # the capture itself executes nothing: steps 3..7 are replays (one with the guard tripped)
+    for k in range(3, 8):
+        for pb, gr in zip(p_b, grads[k]):
+            pb.grad.copy_(gr)
+        if k == 5:
+            guard.fill_(11)                 # tripped: nothing moves, the step is not counted, the skipped counter is
+        gph.replay()
+        guard.zero_()
+        if k != 5:
+            for pa, gr in zip(p_a, grads[k]):
+                pa.grad = gr.clone()
+            oa.step()
+    torch.cuda.synchronize()
+    assert int(ob.state[p_b[0]]["step"].item()) == 7 and int(ob.skipped_steps.item()) == 1
+    assert int(oa.state[p_a[0]]["step"].item()) == 7
+    frozen = mask.bool()
+    for n, pa, pb, s0 in zip(names, p_a, p_b, start):
+        if n in ("xyz", "scaling", "rotation"):
+            assert torch.equal(pb.detach()[frozen], s0[frozen]), f"{n}: frozen rows moved"
+            assert torch.equal(ob.state[pb]["exp_avg"][frozen], torch.zeros_like(s0[frozen])), f"{n}: frozen rows' moments moved"
+            assert torch.equal(pb.detach()[~frozen], pa.detach()[~frozen]), f"{n}: free rows differ from the unmasked optimiser"
+        else:
+            assert torch.equal(pb.detach(), pa.detach()), f"{n}: a group outside the freeze differs"
+
+
 def _mapper_setup(P, W, H, capturable):
     from gs_icp_slam_amd.optim import FusedAdam
     g, cam = _scene(P, W, H)

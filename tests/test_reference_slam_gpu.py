@@ -136,7 +136,9 @@ def test_fused_iteration_tracks_the_references_own_statements(tmp_path):
     plain, fused = os.path.join(ROOT, "oracle", "_ref", "refpy"), find_reference(fused=True)
     if fused is None or not os.path.exists(os.path.join(plain, "_lifted_mapping_block.pyc")):
         pytest.skip("oracle/_ref/refpy{,_fused} (with the lifted training block) not built")
-    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests", "refstubs")]))
+    # GSICP_FUSED_POLICY=free: this test pins the ARITHMETIC of the fused iteration to the reference's statements; the default policy (freeze: the
+    # trackable Gaussians keep their geometry) is a deliberate, measured deviation covered by the two tests below
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests", "refstubs")]), GSICP_FUSED_POLICY="free")
     res = {}
     for mode, tree, n in (("ref", plain, 12), ("fused", fused, 12), ("ref0", plain, 0)):
         out = str(tmp_path / (mode + ".npz"))
@@ -158,3 +160,60 @@ def test_fused_iteration_tracks_the_references_own_statements(tmp_path):
     for k, s_ in stats.items():
         assert s_["travelled"] > 0 and s_["apart"] <= 1e-2 * s_["travelled"], (k, s_)      # measured: 1e-6 .. 5e-5 of the distance travelled, xyz 1.7e-3
         assert s_["within_1pct"] >= 0.999, (k, s_)       # Adam steps by lr x a sign-like ratio: an element whose gradient sits at rounding level may go the other way
+
+
+def test_default_policy_freezes_the_geometry_the_tracker_aligns_against(tmp_path):
+    """The default policy of the in-system fused mapper (refglue.fused_policy: `freeze`): twelve fused iterations over the probe's three keyframe
+    views leave position, scale and rotation of every TRACKABLE Gaussian bit for bit where GICP put them (FusedAdam.set_row_freeze -> the row mask of
+    gsicp_adam_step_masked), while their colour and opacity, and every parameter of the non-trackable Gaussians, train."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from tools.run_reference_slam import find_reference
+    plain, fused = os.path.join(ROOT, "oracle", "_ref", "refpy"), find_reference(fused=True)
+    if fused is None or not os.path.exists(os.path.join(plain, "_lifted_mapping_block.pyc")):
+        pytest.skip("oracle/_ref/refpy{,_fused} (with the lifted training block) not built")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests", "refstubs")]))
+    env.pop("GSICP_FUSED_POLICY", None)
+    env["GSICP_PROBE_TRACKABLE_EVERY"] = "2"
+    res = {}
+    for mode, n in (("fused", 12), ("fused0", 0)):
+        out = str(tmp_path / (mode + ".npz"))
+        r = subprocess.run([sys.executable, "-W", "ignore", os.path.join(ROOT, "tests", "refglue_iteration_probe.py"), fused, "fused", out, str(n)],
+                           env=env, capture_output=True, text=True, timeout=400)
+        assert r.returncode == 0 and "probe ok" in r.stdout, r.stderr[-3000:]
+        res[mode] = np.load(out)
+    a, start = res["fused"], res["fused0"]
+    tr = a["trackable"].astype(bool)
+    assert 0 < tr.sum() < tr.size, "the probe's map must hold trackable and non-trackable Gaussians"
+    for k in ("xyz", "scaling", "rotation"):
+        assert np.array_equal(a[k][tr], start[k][tr]), f"{k}: trackable rows moved under the freeze policy"
+        assert np.abs(a[k][~tr] - start[k][~tr]).max() > 0, f"{k}: non-trackable rows did not train"
+    for k in ("f_dc", "opacity"):
+        assert np.abs(a[k][tr] - start[k][tr]).max() > 0, f"{k}: trackable rows' appearance did not train"
+    assert a["losses"][-1] < a["losses"][0]
+
+
+@pytest.mark.parametrize("shape", ["replica", "tum"])
+def test_fused_system_keeps_tracking_accuracy_under_sensor_noise(shape):
+    """the reference's two-process system on NOISY depth (sensor model sigma(z) = 1.2 mm + 1.9 mm (z - 0.4)^2, 15 % holes), untouched
+    and with SURVEY 8(f)'s rows applied at the DEFAULT policy (refglue.fused_policy).  Replica-shaped: 300 frames of fast hand-held motion
+    (12-14 mm / 0.3-0.5 deg per frame + 3 mm tremor) at replica.sh's flags; TUM-shaped: 200 frames in TUM's layout at tum.sh's flags.  The fused
+    system must track as well as the untouched one — the reference's printed statistic (mean aligned error) AND the true RMSE within +0.1 cm (plus
+    the run-to-run spread of the untouched system itself, measured at 0.77-1.04 cm printed over three runs of the Replica-shaped sequence: the
+    bar is max(untouched, its measured floor) + 0.1) — with a map at least as good (PSNR).  Round 4's free-running default gave 4-12 cm here."""
+    sys.path.insert(0, ROOT)
+    from tools.run_reference_slam import find_reference
+    if find_reference(fused=True) is None:
+        pytest.skip("oracle/_ref/refpy_fused not built")
+    seq = ["--synthetic", "300", "--noise", "--speed", "2", "--jitter", "0.003"] if shape == "replica" else ["--synthetic", "200", "--shape", "tum", "--noise"]
+    floor = {"replica": (0.77, 0.88), "tum": (0.31, 0.35)}[shape]       # lowest (printed mean, true RMSE) the untouched system reached in rounds 4-5
+    plain = _run(seq + ["--cache", "/tmp/gsicp_cache"])
+    fused = _run(seq + ["--cache", "/tmp/gsicp_cache", "--fused"])
+    fm = fused["fused_mapper"]
+    print(f"noisy {shape}: untouched ATE {plain['ate_rmse_cm']} / {plain['ate_true_rmse_cm']} cm PSNR {plain['psnr']}; fused ({fm.get('policy')}) ATE "
+          f"{fused['ate_rmse_cm']} / {fused['ate_true_rmse_cm']} cm PSNR {fused['psnr']}, {fm['iterations']} iterations, {fm.get('gpu_median_ms_per_iteration')} ms each")
+    assert fm.get("policy") == "freeze" and fm["graph_captures"] == 1, fm
+    assert fused["ate_rmse_cm"] <= max(plain["ate_rmse_cm"], floor[0]) + 0.1, (fused["ate_rmse_cm"], plain["ate_rmse_cm"])
+    assert fused["ate_true_rmse_cm"] <= max(plain["ate_true_rmse_cm"], floor[1]) + 0.1, (fused["ate_true_rmse_cm"], plain["ate_true_rmse_cm"])
+    assert fused["psnr"] >= plain["psnr"], (fused["psnr"], plain["psnr"])
+    assert fm["iterations"] >= 3 * 200, fm          # the policy does not buy accuracy by idling: several Adam steps per tracked frame

@@ -118,10 +118,10 @@ def run(reference, dataset, config, output, unlimit=True, timeout=600, extra_fla
     if m:
         res["fused_mapper"] = dict(iterations=int(m.group(1)), median_ms_per_iteration=float(m.group(2)), mean_ms_per_iteration=float(m.group(3)),
                                    p90_ms_per_iteration=float(m.group(4)), graph_captures=int(m.group(5)), gaussians=int(m.group(6)))
-        m = re.search(r"gpu_median_ms ([-\d.eE+na]+) gpu_p90_ms ([-\d.eE+na]+) paced_waits (\d+) iters_per_frame (\S+)", out)
+        m = re.search(r"gpu_median_ms ([-\d.eE+na]+) gpu_p90_ms ([-\d.eE+na]+) paced_waits (\d+) iters_per_frame (\S+) policy (\S+)", out)
         if m:      # median_ms_per_iteration is the loop's CADENCE (pacing included); gpu_* is the device time of set_view + the graph replay
             res["fused_mapper"].update(gpu_median_ms_per_iteration=float(m.group(1)), gpu_p90_ms_per_iteration=float(m.group(2)),
-                                       paced_waits=int(m.group(3)), iters_per_frame_budget=float(m.group(4)))
+                                       paced_waits=int(m.group(3)), iters_per_frame_budget=float(m.group(4)), policy=m.group(5))
     m = re.search(r"ATE detail: true_rmse_cm ([-\d.eE+]+) mean_cm ([-\d.eE+]+) median_cm ([-\d.eE+]+) max_cm ([-\d.eE+]+)", out)
     if m:
         res.update(ate_true_rmse_cm=float(m.group(1)), ate_mean_cm=float(m.group(2)), ate_median_cm=float(m.group(3)), ate_max_cm=float(m.group(4)),
