@@ -73,7 +73,9 @@ struct GridView {
 };
 
 // ---------------------------------------------------------------------------------------------- device helpers
-// 20 bits per axis (coarse cells of >= 4 cm: +-20 km), so that key << 3 | octant still fits the 63 bits the radix sort looks at
+// 20 bits per axis, so that key << 3 | octant still fits the 63 bits the radix sort looks at: +-20 km with the gate-sized level's coarse cells
+// (2 x gate >= 4 cm), +-1.5 km with the second level's smallest cells (2 x 0.15 x gate = 6 mm at Replica's gate).  Beyond that the key wraps:
+// two far-apart cells then share a key and a query scans both — slower, never wrong (every candidate's distance is computed exactly).
 __device__ inline unsigned long long cell_key(int cx, int cy, int cz) {
     const unsigned long long o = 1ull << 19;
     return ((unsigned long long)(cx + (long long)o) & 0xFFFFFull) << 40 | ((unsigned long long)(cy + (long long)o) & 0xFFFFFull) << 20 |
@@ -2540,11 +2542,15 @@ int build_grid(gsicp_gicp* g) {
     // one room corner's surfaces) 109 | 138, m = 57 (1e6) 203 | 190, m = 171 (3e6) 425 | 303 — a query that starts several mm off the
     // surface falls through to the gate-sized level in the first linearisation, so the second level only pays where cells are very full; the
     // build costs +25-35 %.  A whole-room Replica map of 1-2 M Gaussians has m ~ 16-32: one level.
-    static const int two_level = [] { const char* v = std::getenv("GSICP_INDEX_LEVELS"); return v ? std::atoi(v) : 2; }();   // A/B switch
+    // A/B switches, read at every build (keyframe rate): GSICP_INDEX_LEVELS=1 keeps one level; GSICP_INDEX_L2_MIN_FILL moves the threshold (tests)
+    const char* lv_env = std::getenv("GSICP_INDEX_LEVELS");
+    const char* fill_env = std::getenv("GSICP_INDEX_L2_MIN_FILL");
+    const int two_level = lv_env ? std::atoi(lv_env) : 2;
+    const double min_fill = fill_env ? std::atof(fill_env) : 64.0;
     if (g->lv[0].cells_known && two_level >= 2) {
         const double m = (double)n / (double)g->lv[0].n_cells_host;
         double f = std::sqrt(3.8 / m);
-        if (m >= 64.0) {
+        if (m >= min_fill) {
             if (f < 0.15) f = 0.15;
             const double r1 = g->max_corr * f;
             if (int rc = build_level(g, 1, r1)) return rc;

@@ -738,8 +738,7 @@ __global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const dou
     if (!skip) adam_tensor_body<CAPTURABLE>(t, lr_dev, step_dev, beta1, beta2, eps, inv_bc2_sqrt_host, live_rows, &s_bc1, &s_inv_bc2_sqrt, row_freeze);
     if (CAPTURABLE && done) {
         __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
+        if (threadIdx.x == 0) {      // no fence: only the counter and the step word are shared, and a workgroup reads the step word before it counts itself in
             if (atomicAdd(done, 1u) == gridDim.x * gridDim.y - 1u) {
                 *done = 0u;
                 if (skip) { if (skipped_dev) *skipped_dev += 1u; } else *step_rw += 1;
@@ -1146,8 +1145,9 @@ int gsicp_mapper_activations_backward(int P, const float* opacity, const float* 
     return 0;
 }
 
-// GSICP_ADAM_BUMP_KERNEL=1: keep the separate one-thread bump launch of rounds 2-4 (A/B)
-static std::atomic<int> g_adam_bump_kernel([] { const char* e = getenv("GSICP_ADAM_BUMP_KERNEL"); return (e && e[0] == '1') ? 1 : 0; }());
+// GSICP_ADAM_INKERNEL_BUMP=1: the step bump by the last workgroup of the Adam launch instead of the one-thread bump kernel (an experiment: the first
+// version, with an agent-scope fence per workgroup — on gfx950 a write-back of the XCD's L2 — took the Adam kernel from 20 to 188 us; default OFF)
+static std::atomic<int> g_adam_bump_kernel([] { const char* e = getenv("GSICP_ADAM_INKERNEL_BUMP"); return (e && e[0] == '1') ? 0 : 1; }());
 static unsigned* adam_done_word(const int* step_dev, hipStream_t stream) {
     static std::mutex mu;
     static std::map<const int*, unsigned*> words;     // keyed by the step counter: one optimiser = one counter = one word

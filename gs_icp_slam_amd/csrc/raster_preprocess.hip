@@ -286,10 +286,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// The two backward functions below contract a * b + c into FMAs (the library is built with -ffp-contract=off because radii, tile counts and depth
-// keys of the FORWARD must round like the oracle; gradients are compared to 1e-5 / 1e-4 and lose nothing).  The forward helpers they inline
-// (quat_to_R, cov3_from_scale_rot, ewa_M, cov2_from_M) keep their own setting.
-#pragma clang fp contract(fast)
+// Round 5: the backward functions below are compiled WITHOUT FMA contraction, like the rest of this file (rounds 1-4 allowed it here).  With
+// contraction the compiler chooses which a * b + c become FMAs per kernel it inlines this code into: the legacy kernel and the compacted kernel
+// of round 5 then rounded differently in the last bit, and one ill-conditioned Gaussian of the S-map crossed the parity bound.  Without it every
+// operation is one IEEE operation in source order — the two kernels are bit-identical by construction (tests/test_raster_gpu.py), and the sequence
+// is the one the fp32 oracle evaluates.  The kernel is latency-bound (VALU issue floor 4.6 us of 12): the extra multiplies cost nothing.
 
 __device__ inline void sh_backward(int deg, int M, const float* mean, const float* campos, const float* sh, unsigned cm,
                                    const float* dcol, float* dL_dsh, float* dm) {
@@ -626,28 +627,40 @@ __global__ __launch_bounds__(256) void entry_run_sum_kernel(const uint32_t* __re
             slab[3 * lane] = es[3 * (size_t)u]; slab[3 * lane + 1] = es[3 * (size_t)u + 1]; slab[3 * lane + 2] = es[3 * (size_t)u + 2];
         }
         __builtin_amdgcn_wave_barrier();         // a wave's LDS operations execute in program order; this only stops the compiler from reordering them
-        if (tail && hl >= 0) {                   // a complete run inside the window: left fold of slab[hl .. lane]
+        if (tail && hl >= 0) {                   // a complete run inside the window: left fold of slab[hl .. lane], four records' LDS reads in flight
             float v[NGRAD];
 #pragma unroll
             for (int c = 0; c < NGRAD; ++c) v[c] = 0.f;
-            for (int j = hl; j <= lane; ++j) {
-                const float4 q0 = slab[3 * j], q1 = slab[3 * j + 1], q2 = slab[3 * j + 2];
-                v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w; v[8] += q2.x; v[9] += q2.y;
+            for (int j = hl; j <= lane; j += 4) {
+                float4 q[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = j + u <= lane ? j + u : lane;
+                    q[u][0] = slab[3 * jj]; q[u][1] = slab[3 * jj + 1]; q[u][2] = slab[3 * jj + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j + u <= lane) {
+                        v[0] += q[u][0].x; v[1] += q[u][0].y; v[2] += q[u][0].z; v[3] += q[u][0].w; v[4] += q[u][1].x; v[5] += q[u][1].y; v[6] += q[u][1].z;
+                        v[7] += q[u][1].w; v[8] += q[u][2].x; v[9] += q[u][2].y;
+                    }
+                }
             }
             es[3 * (size_t)u] = make_float4(v[0], v[1], v[2], v[3]);
             es[3 * (size_t)u + 1] = make_float4(v[4], v[5], v[6], v[7]);
             es[3 * (size_t)u + 2] = make_float4(v[8], v[9], 0.f, 0.f);
         }
-        // the run that starts in this window and leaves it: 64 records per trip through the slab, lane 0 folds
+        // the run that starts in this window and leaves it: 64 records per trip through the slab; lane c < 12 folds component c (a left fold is
+        // a chain of dependent additions: its pace is one addition per record, so the twelve chains run side by side on twelve lanes, sixteen
+        // LDS words in flight each — a single lane folding whole records was the kernel's tail: 64 records x 150 cycles per trip)
         const int hl63 = __shfl(hl, 63, 64);
         const int open63 = __shfl((int)(valid && !tail), 63, 64);
         if (open63 != 0 && hl63 >= 0) {
             const uint32_t s0 = w * 64u + (uint32_t)hl63;
             const uint32_t gsp = (uint32_t)__shfl((int)g, 63, 64);
             const uint32_t n = tiles_touched[gsp];
-            float acc[NGRAD];
-#pragma unroll
-            for (int c = 0; c < NGRAD; ++c) acc[c] = 0.f;
+            const float* slab_f = (const float*)slab;
+            float acc = 0.f;
             for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
                 const uint32_t pos = c0 + (uint32_t)lane;
                 __builtin_amdgcn_wave_barrier();
@@ -656,27 +669,24 @@ __global__ __launch_bounds__(256) void entry_run_sum_kernel(const uint32_t* __re
                     slab[3 * lane] = es[3 * uu]; slab[3 * lane + 1] = es[3 * uu + 1]; slab[3 * lane + 2] = es[3 * uu + 2];
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (lane == 0) {
+                if (lane < SLOT_F) {
                     const int cnt = (n - c0) >= 64u ? 64 : (int)(n - c0);
-                    for (int j = 0; j < cnt; ++j) {
-                        const float4 q0 = slab[3 * j], q1 = slab[3 * j + 1], q2 = slab[3 * j + 2];
-                        acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w; acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;
-                        acc[8] += q2.x; acc[9] += q2.y;
+                    for (int j = 0; j < cnt; j += 16) {
+                        float x[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) x[u] = slab_f[SLOT_F * (j + u < cnt ? j + u : cnt - 1) + lane];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) if (j + u < cnt) acc += x[u];
                     }
                 }
             }
-            if (lane == 0) {
-                const size_t ut = (size_t)s0 + n - 1u;
-                es[3 * ut] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                es[3 * ut + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                es[3 * ut + 2] = make_float4(acc[8], acc[9], 0.f, 0.f);
-            }
+            if (lane < SLOT_F) entry_sum[((size_t)s0 + n - 1u) * SLOT_F + lane] = lane < NGRAD ? acc : 0.f;
         }
         __builtin_amdgcn_wave_barrier();         // the next window's stores into the slab stay behind this window's reads
     }
 }
 
-__global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void preprocess_backward_kernel(PreprocessBwdArgs a) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= a.P) return;
     SplatRec r0;
@@ -710,8 +720,6 @@ __global__ __launch_bounds__(256) void preprocess_backward_kernel(PreprocessBwdA
     }
     prebwd_finish(a, i, true, gs, r_early, p_early, sc_early, q_early);
 }
-
-#pragma clang fp contract(off)
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* means3D, const float* view, unsigned char* present) {
     const int i = blockIdx.x * 256 + threadIdx.x;

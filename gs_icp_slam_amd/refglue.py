@@ -46,7 +46,9 @@ def patch_gaussian_model(cls):
     plain_update_lr = cls.update_learning_rate
 
     def create_from_pcd2_tensor(self, points, colors, rots_, scales_, z_vals_, trackable_idxs):
-        capacity = int(os.environ.get("GSICP_FUSED_CAPACITY", "1500000"))
+        # rows of the capacity-backed map (~260 B each incl. both Adam moments and the second buffer set: 4 M rows = 1 GB of 288 GB).  The reference's map
+        # grows without bound [REF scene/gaussian_model.py:474-492]; whole-room Replica maps reach 1-2 M Gaussians.
+        capacity = int(os.environ.get("GSICP_FUSED_CAPACITY", "4000000"))
         n_rest = (self.max_sh_degree + 1) ** 2 - 1
         self._store = GaussianStore(capacity, n_rest=n_rest, device=points.device, stable=True)
         rows, mask = rows_from_gicp(points.float(), colors.float(), rots_.float(), scales_.float(), z_vals_.float(), trackable_idxs, self.max_sh_degree)
@@ -57,6 +59,14 @@ def patch_gaussian_model(cls):
     def add_from_pcd2_tensor(self, points, colors, rots_, scales_, z_vals_, trackable_idxs):
         rows, mask = rows_from_gicp(points.float(), colors.float(), rots_.float(), scales_.float(), z_vals_.float(),
                                     trackable_idxs if len(trackable_idxs) != 0 else None, self.max_sh_degree)
+        if self._store.n + rows["xyz"].shape[0] > self._store.capacity:
+            # say what to do instead of dying with a bare RuntimeError deep inside the mapper process (the tracker would wait on the
+            # shared flags until its timeout).  The keyframe's Gaussians are dropped; mapping and tracking go on with the map as it is.
+            if not self.__dict__.get("_gsicp_capacity_warned"):
+                print(f"GSICP: map capacity {self._store.capacity} rows exhausted ({self._store.n} live + {rows['xyz'].shape[0]} new): the new keyframe's "
+                      f"Gaussians are DROPPED.  Raise GSICP_FUSED_CAPACITY.", flush=True)
+                self.__dict__["_gsicp_capacity_warned"] = True
+            return
         self._store.append(rows, mask)          # rows written in place, live count bumped on the device: the captured iteration keeps replaying
         _refresh_views(self)
 

@@ -9,8 +9,12 @@ rank that blends a block computes the loss gradient of that block (gs_icp_slam_a
   forward : ALL-GATHER of each rank's own tiles — `gsicp_tiles_pack` writes the rank's tiles (r, g, b, depth) as one contiguous chunk
             (13/N MB at 1200x680), one all_gather_into_tensor moves the N chunks, `gsicp_tiles_unpack` writes the full image.  Every
             pixel is produced by exactly one rank, so the image is bit-identical to the single-GPU one; nothing is summed.  The loss
-            (SSIM needs an 11x11 window, [REF utils/loss_utils.py:37-69]) is then computed redundantly on the full image on every
-            rank, so the backward needs no image collective at all;
+            (SSIM needs an 11x11 window, [REF utils/loss_utils.py:37-69]: every block reads a 5-pixel halo of its neighbours, which the
+            gathered full image provides) is computed on the rank's OWN 32x32 blocks only (`gsicp_mapper_loss_sharded`, one fused kernel
+            whose work divides by N); the ranks' shares of the four loss values travel inside the gradient exchange.  The backward needs
+            no image collective.  (With round-robin super-tiles the halos of a rank's blocks touch every other rank's tiles, hence the
+            all-gather of the whole image; contiguous, load-balanced bands with a two-neighbour halo exchange — 0.2 MB instead of
+            13.7 MB per rank — are the next step of this mode)
   backward: ALL-REDUCE(sum) of the per-Gaussian gradients of the VISIBLE Gaussians only — radii are replicated (every rank
             preprocesses all Gaussians), so every rank compacts the same rows (radii > 0: ~26 % of the map on the benchmark view) in
             index order into one packed block (14 floats x P_vis = 4.4 MB instead of 16.8 MB), all-reduces it and scatters it back;

@@ -245,7 +245,7 @@ def raycast_pixels(cfg, pose_c2w, u, v):
     return depth
 
 
-def tracker_map_cloud(n_points, n_keyframes=32, seed=5, cfg=REPLICA, keyframe_every=10, first_frame=0):
+def tracker_map_cloud(n_points, n_keyframes=32, seed=5, cfg=REPLICA, keyframe_every=10, first_frame=0, noise=False):
     """World-frame points of a MAP as the tracker sees it after many keyframes [REF mp_Tracker.py:282-288; scene/gaussian_model.py:207-215]:
     the union of `n_keyframes` keyframes of `trajectory` (every `keyframe_every`-th frame), each contributing n_points / n_keyframes
     back-projected depth samples at randomly picked integer pixels (sensor-quantised depth, the front-end's float32 arithmetic), so the
@@ -262,6 +262,8 @@ def tracker_map_cloud(n_points, n_keyframes=32, seed=5, cfg=REPLICA, keyframe_ev
         pix = rng.choice(W * H, size=per[k], replace=False) if per[k] <= W * H else rng.integers(0, W * H, per[k])
         u, v = (pix % W).astype(np.float32), (pix // W).astype(np.float32)
         depth = raycast_pixels(cfg, pose, u, v)
+        if noise:      # the sensor model of frame_points (SURVEY 8d S-tum): the map's keyframes carry the noise of the frames they came from
+            depth = depth + rng.normal(size=depth.shape) * (0.0012 + 0.0019 * (depth - 0.4) ** 2)
         d16 = np.clip(np.round(depth * cfg["depth_scale"]), 0, 65535).astype(np.uint16)
         z = d16.astype(np.float32) / np.float32(cfg["depth_scale"])
         x_pre = (u - np.float32(cfg["cx"])) / np.float32(cfg["fx"])
@@ -274,7 +276,7 @@ def tracker_map_cloud(n_points, n_keyframes=32, seed=5, cfg=REPLICA, keyframe_ev
     return dict(points=np.concatenate(pts), keyframe=np.concatenate(kf), z=np.concatenate(zs), poses=poses, frame_ids=ids)
 
 
-def tracker_map(n_target, cov_fn, n_keyframes=32, seed=5, cfg=REPLICA, pass_fraction=0.5, opacity_th=0.05):
+def tracker_map(n_target, cov_fn, n_keyframes=32, seed=5, cfg=REPLICA, pass_fraction=0.5, opacity_th=0.05, noise=False):
     """A synthetic MAP of Gaussians sized so that ~n_target of them pass the tracker hand-off's selection
     `opacity > opacity_th and trackable` [REF scene/gaussian_model.py:207-215]: n_target / pass_fraction rows in random order, positions from
     `tracker_map_cloud`, rotations (xyzw) / scales from `cov_fn(world_points_of_one_keyframe) -> (rots (n,4), scales (n,3))` — the k-NN
@@ -282,7 +284,7 @@ def tracker_map(n_target, cov_fn, n_keyframes=32, seed=5, cfg=REPLICA, pass_frac
     scales shrunk as the mapper's initialisation shrinks them (scales / clamp_min(2 z^1.5, 1)) [REF scene/gaussian_model.py:143-145].
     Rows failing the selection are split between non-trackable ones and low-opacity ones."""
     total = int(round(n_target / pass_fraction))
-    cloud = tracker_map_cloud(total, n_keyframes=n_keyframes, seed=seed, cfg=cfg)
+    cloud = tracker_map_cloud(total, n_keyframes=n_keyframes, seed=seed, cfg=cfg, noise=noise)
     pts, kf, z = cloud["points"], cloud["keyframe"], cloud["z"]
     rots = np.zeros((len(pts), 4), np.float32)
     scales = np.zeros((len(pts), 3), np.float32)

@@ -190,7 +190,10 @@ int gsicp_gicp_get_source_scales(gsicp_gicp*, float* out, int capacity_points);
 int gsicp_gicp_set_target_covariances_fromqs(gsicp_gicp*, const float* rots_flat, int n_rots, const float* scales_flat,
                                              int n_scales);
 /* initial/final: HOST 4x4 row-major f64 camera-to-world.  Returns the number of outer iterations (>= 0)
- * [REF mp_Tracker.py:199] */
+ * [REF mp_Tracker.py:199].  Synchronous, like every call of this object.  The FIRST align after a target change also builds the target index
+ * (lazily): for targets of >= 32 768 points that build reads the occupied-cell count back once per index level (one or two 4-byte
+ * device-to-host reads, each a stream drain) and may re-allocate the hash table and cell records sized by it — expect that align to
+ * take 0.3-3 ms longer and not to be allocation-free. */
 int gsicp_gicp_align(gsicp_gicp*, const double* initial_pose, double* final_pose);
 /* One entry per trackable source point: nearest-target index (-1 when farther than the correspondence gate) and
  * the squared distance to the nearest target point, as of the last linearisation  [REF mp_Tracker.py:231].

@@ -537,3 +537,121 @@ def test_knn_covariances_of_a_map_sized_cloud():
     print("knn stats", reg.knn_stats())
     np.testing.assert_allclose(sg, so, rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(quat_cov(qg, sg), quat_cov(qo, so), rtol=0, atol=2e-7)
+
+
+def test_tum_configuration_at_map_scale():
+    """the steady-state tracker under the TUM configuration [REF tum.sh:135-142: gate 0.03 m, stride 5 -> 12 416-point frames at
+    640x480, depth truncated at 3 m, trackable_opacity_th 0.09] with SENSOR NOISE on both sides: the map = ~1e5 selected Gaussians of 32 noisy
+    TUM-shaped keyframes (k-NN covariances of the noisy clouds, 2K rows, the opacity threshold of tum.sh), the source = a noisy frame with 15 %
+    holes.  Three routes (host arrays / device hand-off) against the oracle: indices and squared distances bit-exact (also beyond the gate), pose
+    <= 1e-6, same LM iteration count; a second case starts 8 frames back."""
+    import oracle
+    import pygicp
+    import torch
+    cfg = synth.TUM
+    m = synth.tracker_map(170_000, _oracle_knn_export, cfg=cfg, opacity_th=0.09, noise=True, seed=6)      # ~1e5 pass the 3 m truncation + the selection
+    keep = m["trackable"] & (m["opacity"] > m["opacity_th"])
+    sel = np.where(keep)[0]
+    tp, tr, ts = m["points"][sel], m["rotations"][sel], m["scales"][sel]
+    fid = 155
+    poses = synth.trajectory(fid + 1)
+    src, _, trackable, _ = synth.frame_points(cfg, poses[fid], noise_seed=77, holes=0.15)
+    assert 9000 < len(src) <= 12416 and 80_000 < len(sel) < 130_000
+    f_src = filt(len(src), trackable)
+    for back in (1, 8):
+        init = poses[fid - back]
+
+        def frame(reg):
+            reg.set_input_source(src)
+            reg.set_source_filter(len(trackable), f_src)
+            T = reg.align(init)
+            idx, d2 = reg.get_source_correspondence()
+            return T, idx, d2
+        out = []
+        for reg in (oracle.OracleGICP(), pygicp.FastGICP()):
+            reg.set_max_correspondence_distance(cfg["max_corr"])
+            reg.set_max_knn_distance(99999.0)
+            reg.set_input_target(tp)
+            reg.set_target_covariances_fromqs(tr.flatten(), ts.flatten())
+            out.append(frame(reg) + (reg,))
+        (To, io, do, oreg), (Tp, ip, dp, reg) = out
+        st = reg.last_align_stats()
+        ang, mm = pose_err(Tp, poses[fid])
+        print(f"TUM configuration, K={len(sel)} back={back}: HIP {st}, oracle iterations {oreg.iterations}, pose error {ang:.4f} deg / {mm:.2f} mm, "
+              f"in-gate {np.mean(do < cfg['max_corr'] ** 2):.3f}, index {reg.target_index_stats()}")
+        assert np.array_equal(ip, io), f"{(ip != io).sum()} correspondence indices differ"
+        assert np.array_equal(dp, do), f"max |d2 diff| {np.abs(dp - do).max()}"
+        np.testing.assert_allclose(Tp, To, rtol=0, atol=1e-6)
+        assert st["iterations"] == oreg.iterations and st["barrier_retries"] == 0
+        assert 0.9 < np.mean(do < cfg["max_corr"] ** 2) < 1.0 and len(trackable) < 0.8 * len(src)     # a few misses; a third of the frame beyond the 3 m truncation
+        r3 = pygicp.FastGICP()
+        r3.set_max_correspondence_distance(cfg["max_corr"])
+        n = r3.set_target_from_gaussians(torch.from_numpy(m["points"]).cuda(), torch.from_numpy(m["rotations"]).cuda(), torch.from_numpy(m["scales"]).cuda(),
+                                         torch.from_numpy(m["opacity"]).cuda(), trackable_mask=torch.from_numpy(m["trackable"]).cuda(), opacity_th=m["opacity_th"])
+        assert n == len(sel)
+        T3, i3, d3 = frame(r3)
+        assert np.array_equal(i3, ip) and np.array_equal(d3, dp)
+        np.testing.assert_array_equal(T3, Tp)
+
+
+def test_second_index_level_is_exact_on_a_very_dense_target(monkeypatch):
+    """the SECOND level of the target index (built when an occupied gate-sized cell holds >= 64 points — first reached by
+    real maps at ~3e6 Gaussians, above every other test) against the kd-tree oracle.  Target: 120 000 points on three dense, mutually
+    perpendicular wall patches (a 0.6 x 0.4 m patch + two strips: ~300 points per coarse cell), isotropic covariances through fromqs.  Source: 3 000
+    points at four kinds of distance from the surface — inside the fine radius (answered by level 1), between the fine radius and the gate (level 1
+    misses, the gate-sized level answers), just beyond the gate, and far away — so both the fine-level search and the fall-through run.  Bars: the
+    index has two levels; correspondence indices and squared distances bit-equal to the oracle (also beyond the gate) and to the same object with
+    GSICP_INDEX_LEVELS=1; the pose within 1e-6 of the oracle's; a second target on the SAME object (sort / temp buffers shared by the two builds
+    of a two-level index, then reused) stays exact."""
+    import oracle
+    import pygicp
+    rng = np.random.default_rng(42)
+    gate = 0.02
+
+    def cloud(n, shift):      # three mutually perpendicular dense patches (a corner): the registration is well conditioned
+        na, nb = n * 3 // 5, n // 5
+        a = np.stack([rng.uniform(0, 0.6, na), rng.uniform(0, 0.4, na), 2.0 + 2e-4 * rng.standard_normal(na)], 1)
+        b = np.stack([0.6 + 2e-4 * rng.standard_normal(nb), rng.uniform(0, 0.4, nb), rng.uniform(1.9, 2.0, nb)], 1)
+        c = np.stack([rng.uniform(0, 0.6, n - na - nb), 0.4 + 2e-4 * rng.standard_normal(n - na - nb), rng.uniform(1.9, 2.0, n - na - nb)], 1)
+        return (np.concatenate([a, b, c]) + shift).astype(np.float32)
+
+    def source(tgt, n):
+        base = tgt[rng.choice(len(tgt), n, replace=False)].astype(np.float64)
+        kind = rng.integers(0, 4, n)
+        off = np.where(kind == 0, rng.uniform(0, 0.002, n), np.where(kind == 1, rng.uniform(0.004, 0.018, n),
+                                                                      np.where(kind == 2, rng.uniform(0.0205, 0.03, n), rng.uniform(0.1, 0.5, n))))
+        d = rng.standard_normal((n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return (base + d * off[:, None]).astype(np.float32), kind
+
+    def run(reg, tgt, src):
+        reg.set_max_correspondence_distance(gate)
+        reg.set_input_target(tgt)
+        q = np.tile(np.array([0, 0, 0, 1], np.float32), (len(tgt), 1))
+        reg.set_target_covariances_fromqs(q.flatten(), np.full((len(tgt), 3), 0.01, np.float32).flatten())
+        reg.set_input_source(src)
+        T = reg.align(np.eye(4))
+        idx, d2 = reg.get_source_correspondence()
+        return np.asarray(T), np.asarray(idx), np.asarray(d2)
+
+    monkeypatch.delenv("GSICP_INDEX_LEVELS", raising=False)
+    reg = pygicp.FastGICP()
+    for trial, shift in enumerate((np.zeros(3), np.array([0.013, -0.007, 0.021]))):       # the second target reuses the object's buffers
+        tgt = cloud(120_000, shift)
+        src, kind = source(tgt, 3000)
+        To, io, do = run(oracle.OracleGICP(), tgt, src)
+        Tp, ip, dp = run(reg, tgt, src)
+        st = reg.target_index_stats()
+        print(f"two-level index, trial {trial}: {st}; in-gate {np.mean(do < gate * gate):.3f}, answered inside the fine radius "
+              f"{np.mean(do < st['levels'][-1]['radius_m'] ** 2):.3f}")
+        assert len(st["levels"]) == 2 and st["levels"][1]["radius_m"] < gate, st
+        assert (do < st["levels"][1]["radius_m"] ** 2).mean() > 0.1 and ((do >= st["levels"][1]["radius_m"] ** 2) & (do < gate * gate)).mean() > 0.1
+        assert np.array_equal(ip, io), f"{(ip != io).sum()} correspondence indices differ from the oracle"
+        assert np.array_equal(dp, do), f"max |d2 diff| {np.abs(dp - do).max()}"
+        np.testing.assert_allclose(Tp, To, rtol=0, atol=1e-6)
+        monkeypatch.setenv("GSICP_INDEX_LEVELS", "1")
+        one = pygicp.FastGICP()
+        T1, i1, d1 = run(one, tgt, src)
+        assert len(one.target_index_stats()["levels"]) == 1
+        assert np.array_equal(i1, ip) and np.array_equal(d1, dp)
+        np.testing.assert_allclose(T1, Tp, rtol=0, atol=1e-6)
+        monkeypatch.delenv("GSICP_INDEX_LEVELS", raising=False)
