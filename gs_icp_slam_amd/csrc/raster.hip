@@ -257,6 +257,66 @@ __global__ __launch_bounds__(256) void emit_kernel(int P, const uint32_t* __rest
     }
 }
 
+// Round 5, unsharded images (tile_mod == 1): the same slots, filled SLOT-PARALLEL.  emit_kernel walks a Gaussian's run with one thread — at step j
+// the 64 lanes of a wave store to 64 runs' j-th slots, ~30 B apart (a run is 7.5 slots on a trained map): ~30 cache lines per store instruction
+// instead of 4, four arrays, as many steps as the wave's longest run (35), and on the S-map 82 % of the lanes hold a culled Gaussian.  Here a
+// workgroup's 256 Gaussians publish their rectangle, footprint box and depth bits in LDS together with the inclusive scan of their run lengths;
+// the runs of one workgroup are contiguous and in thread order (preprocess_kernel allocates them that way, and this kernel uses the same
+// 256-Gaussian blocking), so thread t then fills slots t, t + 256, ... of the workgroup's range: binary search of the slot in the scan (8 LDS
+// reads), tile = the (slot - run start)-th of the rectangle in row-major order — the order the per-thread walk emits.  Same words in the same
+// slots; every store instruction writes 64 consecutive words.
+__global__ __launch_bounds__(256) void emit_flat_kernel(int P, const uint32_t* __restrict__ total, uint32_t cap,
+                                                        const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ slot_base,
+                                                        const SplatRec* __restrict__ rec, const int* __restrict__ radii, int gx, int gy,
+                                                        uint32_t* __restrict__ emit_tile, uint32_t* __restrict__ emit_depth, uint32_t* __restrict__ entry_gauss,
+                                                        uint32_t* __restrict__ entry_bits, uint32_t* __restrict__ num_rendered_dev) {
+    __shared__ uint32_t s_incl[256], s_cnt[256], s_dbits[256], s_wave_tot[4], s_base0;
+    __shared__ int s_x0[256], s_y0[256], s_w[256];
+    __shared__ float s_fx0[256], s_fx1[256], s_fy0[256], s_fy1[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int id = blockIdx.x * 256 + tid;
+    if (id == 0 && num_rendered_dev) *num_rendered_dev = *total;   // the caller's copy of R (async path)
+    const bool active = id < P && tiles_touched[id] != 0 && *total <= cap;
+    uint32_t cnt = 0;
+    if (tid == 0) s_base0 = 0u;
+    if (active) {
+        cnt = tiles_touched[id];
+        const SplatRec r = rec[id];
+        int x0, y0, x1, y1;
+        tile_rect(r.px, r.py, radii[id], gx, gy, x0, y0, x1, y1);
+        s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0;
+        s_dbits[tid] = __float_as_uint(r.depth);
+        s_fx0[tid] = r.px - r.hx; s_fx1[tid] = r.px + r.hx; s_fy0[tid] = r.py - r.hy; s_fy1[tid] = r.py + r.hy;   // alpha footprint box
+    }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += s_wave_tot[w];
+    incl += wave_off;
+    s_incl[tid] = incl;
+    s_cnt[tid] = cnt;
+    if (active) s_base0 = slot_base[id] - (incl - cnt);          // the same value from every active thread: the workgroup's first slot
+    __syncthreads();
+    const uint32_t tot = s_incl[255], base0 = s_base0;
+    for (uint32_t k = (uint32_t)tid; k < tot; k += 256u) {
+        int lo = 0;                                               // number of Gaussians whose runs end at or before slot k = the Gaussian that owns it
+#pragma unroll
+        for (int step = 128; step > 0; step >>= 1)
+            if (s_incl[lo + step - 1] <= k) lo += step;
+        const uint32_t off = k - (s_incl[lo] - s_cnt[lo]);
+        const int w = s_w[lo];
+        const int x = s_x0[lo] + (int)(off % (uint32_t)w), y = s_y0[lo] + (int)(off / (uint32_t)w);
+        emit_one(x, y, gx, 1, 0, s_fx0[lo], s_fx1[lo], s_fy0[lo], s_fy1[lo], s_dbits[lo], (uint32_t)(blockIdx.x * 256 + lo), base0 + k, emit_tile,
+                 emit_depth, entry_gauss, entry_bits);
+    }
+}
+
 // Tile multi-split, pass 1: each workgroup histograms its contiguous chunk of emission slots over all T tiles in LDS
 // (LDS atomics; no global atomics) and writes its row of the (split block, tile) count table.
 __global__ __launch_bounds__(1024) void split_hist_kernel(const uint32_t* __restrict__ total, uint32_t cap, int T,
@@ -295,7 +355,7 @@ __global__ __launch_bounds__(256) void split_colscan_kernel(int T, int nb, uint3
 __global__ __launch_bounds__(1024) void split_scatter_kernel(const uint32_t* __restrict__ total, uint32_t cap, int T, const uint32_t* __restrict__ emit_tile,
                                                              const uint32_t* __restrict__ emit_depth, const uint32_t* __restrict__ entry_bits,
                                                              const uint32_t* __restrict__ block_hist, const uint2* __restrict__ ranges,
-                                                             uint32_t* __restrict__ sc_keys, uint32_t* __restrict__ sc_vals) {
+                                                             const uint32_t* __restrict__ entry_gauss, uint4* __restrict__ sc_pack) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist_dyn[];
     const int R = device_R(total, cap), chunk = (R + (int)gridDim.x - 1) / (int)gridDim.x;
     for (int t = threadIdx.x; t < T; t += 1024) s_hist_dyn[t] = 0;
@@ -305,8 +365,9 @@ __global__ __launch_bounds__(1024) void split_scatter_kernel(const uint32_t* __r
         const uint32_t t = emit_tile[u];
         const uint32_t r = atomicAdd(&s_hist_dyn[t], 1u);
         const uint32_t pos = ranges[t].x + block_hist[(size_t)blockIdx.x * T + t] + r;
-        sc_keys[pos] = emit_depth[u];
-        sc_vals[pos] = (uint32_t)u | (entry_bits[u] << STRIP_SHIFT);
+        // round 5: depth bits, list word AND the Gaussian id in one 16-byte store (rounds 1-4: two scattered 4-byte stores here, and a dependent
+        // 4-byte gather of entry_gauss[slot] per entry in the per-tile sort)
+        sc_pack[pos] = make_uint4(emit_depth[u], (uint32_t)u | (entry_bits[u] << STRIP_SHIFT), entry_gauss[u], 0u);
     }
 }
 
@@ -387,8 +448,8 @@ __device__ inline uint32_t refine_block_bits(const uint32_t word, const SplatRec
 
 template <int CAP, int THREADS, int MIN_N>
 __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uint32_t* __restrict__ s_val, const uint32_t tile,
-                                     const uint2* __restrict__ ranges, const uint32_t* __restrict__ sc_keys, const uint32_t* __restrict__ sc_vals,
-                                     const uint32_t* __restrict__ entry_gauss, uint32_t* __restrict__ point_list,
+                                     const uint2* __restrict__ ranges, const uint4* __restrict__ sc_pack,
+                                     uint32_t* __restrict__ point_list,
                                      uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ list_gauss, const SplatRec* __restrict__ rec, const int gx) {
     const uint2 range = ranges[tile];
     const float tile_x0 = (float)((int)(tile % (uint32_t)gx) * TILE), tile_y0 = (float)((int)(tile / (uint32_t)gx) * TILE);
@@ -400,16 +461,15 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
         // are bitonic-sorted in LDS and written back in place; because (depth bits, Gaussian id) is a TOTAL order with unique keys, an
         // entry's final rank is its rank inside its own chunk plus, for every other chunk, the number of that chunk's keys below it —
         // one binary search per other chunk.  O(n (n / CAP) log CAP) instead of the O(n^2) rank sort this replaces, and still exact.
-        uint32_t* gk = const_cast<uint32_t*>(sc_keys) + range.x;   // forward-only scratch: reordered in place
-        uint32_t* gv = const_cast<uint32_t*>(sc_vals) + range.x;
+        uint4* gp = const_cast<uint4*>(sc_pack) + range.x;        // forward-only scratch: reordered in place
         const int n_chunks = (n + CAP - 1) / CAP;
         for (int c = 0; c < n_chunks; ++c) {
             const int base = c * CAP, m = (n - base) < CAP ? (n - base) : CAP;
             for (int i = tid; i < CAP; i += THREADS) {
                 if (i < m) {
-                    const uint32_t v = gv[base + i];
-                    s_val[i] = v;
-                    s_key[i] = ((unsigned long long)gk[base + i] << 32) | entry_gauss[v & ID_MASK];
+                    const uint4 e = gp[base + i];
+                    s_val[i] = e.y;
+                    s_key[i] = ((unsigned long long)e.x << 32) | e.z;
                 } else {
                     s_key[i] = ~0ull;
                     s_val[i] = 0;
@@ -418,15 +478,15 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
             __syncthreads();
             bitonic_pairs<THREADS>(s_key, s_val, CAP, tid);
             __syncthreads();
-            for (int i = tid; i < m; i += THREADS) { gk[base + i] = (uint32_t)(s_key[i] >> 32); gv[base + i] = s_val[i]; }
+            for (int i = tid; i < m; i += THREADS) gp[base + i] = make_uint4((uint32_t)(s_key[i] >> 32), s_val[i], (uint32_t)s_key[i], 0u);
             __syncthreads();
         }
         __threadfence_block();
         __syncthreads();
         for (int i = tid; i < n; i += THREADS) {
-            const uint32_t v = gv[i];
-            const uint32_t gid = entry_gauss[v & ID_MASK];
-            const unsigned long long key = ((unsigned long long)gk[i] << 32) | gid;
+            const uint4 e = gp[i];
+            const uint32_t v = e.y, gid = e.z;
+            const unsigned long long key = ((unsigned long long)e.x << 32) | gid;
             const int own = i / CAP;
             int rank = i - own * CAP;
             for (int c = 0; c < n_chunks; ++c) {
@@ -435,8 +495,8 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
                 int lo = 0, hi = m;                       // number of keys of chunk c below `key`
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    const uint32_t vm = gv[base + mid];
-                    const unsigned long long km = ((unsigned long long)gk[base + mid] << 32) | entry_gauss[vm & ID_MASK];
+                    const uint4 em = gp[base + mid];
+                    const unsigned long long km = ((unsigned long long)em.x << 32) | em.z;
                     if (km < key) lo = mid + 1; else hi = mid;
                 }
                 rank += lo;
@@ -451,9 +511,9 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
     while (npad < n) npad <<= 1;
     for (int i = tid; i < npad; i += THREADS) {
         if (i < n) {
-            const uint32_t v = sc_vals[range.x + i];
-            s_val[i] = v;
-            s_key[i] = ((unsigned long long)sc_keys[range.x + i] << 32) | entry_gauss[v & ID_MASK];
+            const uint4 e = sc_pack[range.x + i];
+            s_val[i] = e.y;
+            s_key[i] = ((unsigned long long)e.x << 32) | e.z;
         } else {
             s_key[i] = ~0ull;
             s_val[i] = 0;
@@ -474,8 +534,7 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
 // number of tiles read from the device).
 template <int CAP, int THREADS, int MIN_N>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int n_tiles, const uint32_t* __restrict__ limit_dev, const uint32_t* __restrict__ order,
-                                                            const uint2* __restrict__ ranges, const uint32_t* __restrict__ sc_keys,
-                                                            const uint32_t* __restrict__ sc_vals, const uint32_t* __restrict__ entry_gauss,
+                                                            const uint2* __restrict__ ranges, const uint4* __restrict__ sc_pack,
                                                             uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
                                                             uint32_t* __restrict__ list_gauss, const SplatRec* __restrict__ rec, int gx) {
     __shared__ unsigned long long s_key[CAP];
@@ -483,7 +542,7 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int n_tiles, const u
     int limit = n_tiles;
     if (limit_dev) { const int l = (int)*limit_dev; limit = l < limit ? l : limit; }
     for (int bi = blockIdx.x; bi < limit; bi += gridDim.x) {
-        tile_sort_one<CAP, THREADS, MIN_N>(s_key, s_val, order[bi], ranges, sc_keys, sc_vals, entry_gauss, point_list, tile_keys, list_gauss, rec, gx);
+        tile_sort_one<CAP, THREADS, MIN_N>(s_key, s_val, order[bi], ranges, sc_pack, point_list, tile_keys, list_gauss, rec, gx);
         __syncthreads();   // the LDS arrays are reused by the next list
     }
 }
@@ -952,8 +1011,13 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     uint32_t* block_hist = (uint32_t*)(bin + BL.block_hist);
     if (num_rendered > 0) {
         { ProfileScope ps(ST_EMIT, stream);
-          hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, total_counter, cap, tiles_touched, slot_base, rec, radii, gx, gy,
-                             tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits, num_rendered_dev); }
+          static const bool emit_walk = [] { const char* e = getenv("GSICP_EMIT_WALK"); return e && e[0] == '1'; }();   // A/B: the per-thread walk of rounds 1-4
+          if (tile_mod == 1 && !emit_walk)
+              hipLaunchKernelGGL(emit_flat_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, total_counter, cap, tiles_touched, slot_base, rec, radii, gx,
+                                 gy, emit_tile, emit_depth, entry_gauss, entry_bits, num_rendered_dev);
+          else
+              hipLaunchKernelGGL(emit_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, total_counter, cap, tiles_touched, slot_base, rec, radii, gx, gy,
+                                 tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits, num_rendered_dev); }
         { ProfileScope ps(ST_SPLIT_HIST, stream);
           hipLaunchKernelGGL(split_hist_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, block_hist); }
         { ProfileScope ps(ST_SPLIT_COLSCAN, stream);
@@ -967,7 +1031,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
         {
             ProfileScope ps(ST_SPLIT_SCATTER, stream);
             hipLaunchKernelGGL(split_scatter_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, emit_depth,
-                               entry_bits, block_hist, ranges, (uint32_t*)(bin + BL.scatter_keys), (uint32_t*)(bin + BL.scatter_vals));
+                               entry_bits, block_hist, ranges, entry_gauss, (uint4*)(bin + BL.scatter_pack));
         }
         const int n_local = count_local_tiles(gx, gy, tile_mod, tile_rem);
         // ONE class: lists up to SORT_SMALL entries (everything the BASELINE scenes produce: their longest lists are ~500 entries) are sorted
@@ -975,7 +1039,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
         // 4.5 us launch in EVERY iteration to find nothing to do (kernels in a replayed graph cost ~4 us each whatever they compute).
         { ProfileScope ps(ST_TILE_SORT, stream);
           hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 256, 0>), dim3(n_local), dim3(256), 0, stream, n_local, (const uint32_t*)nullptr, order, ranges,
-                             (const uint32_t*)(bin + BL.scatter_keys), (const uint32_t*)(bin + BL.scatter_vals), entry_gauss, point_list,
+                             (const uint4*)(bin + BL.scatter_pack), point_list,
                              (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss), (const SplatRec*)rec, gx); }
     }
 

@@ -52,7 +52,7 @@ __host__ __device__ inline int tile_chunk_slots(int gx, int gy, int tile_mod) {
 
 // Section offsets inside the three torch-owned scratch buffers.
 struct GeomLayout { size_t records, clamped, slot_base, tiles_touched, vis_list, total; };
-struct BinLayout { size_t point_list, tile_keys, list_gauss, entry_gauss, entry_bits, emit_tile, emit_depth, scatter_keys, scatter_vals, block_hist, total; };
+struct BinLayout { size_t point_list, tile_keys, list_gauss, entry_gauss, entry_bits, emit_tile, emit_depth, scatter_pack, block_hist, total; };
 constexpr int SPLIT_BLOCKS_MAX = 128;   // workgroups of the tile multi-split (each owns a contiguous chunk of emission slots)
 struct ImgLayout { size_t ranges, final_T, n_contrib, order, tile_count, total; };
 
@@ -79,8 +79,8 @@ inline BinLayout bin_layout(size_t R, size_t T) {
     L.entry_bits = o; o = align_up(o + Rp * 4);       // emission slot -> strip bits
     L.emit_tile = o; o = align_up(o + Rp * 4);        // forward-only: tile id of each emission slot
     L.emit_depth = o; o = align_up(o + Rp * 4);       // forward-only: depth bits of each emission slot
-    L.scatter_keys = o; o = align_up(o + Rp * 4);     // forward-only: depth bits in scatter order
-    L.scatter_vals = o; o = align_up(o + Rp * 4);     // forward-only: list words in scatter order
+    L.scatter_pack = o; o = align_up(o + Rp * 16);    // forward-only: {depth bits, list word, Gaussian id, -} per entry in scatter order (ONE 16-byte
+                                                      // store per entry; the per-tile sort reads it coalesced and gathers nothing)
     L.block_hist = o; o = align_up(o + (size_t)SPLIT_BLOCKS_MAX * (T > 0 ? T : 1) * 4);   // forward-only: per-(split block, tile) counts
     L.total = o;
     return L;

@@ -2,7 +2,7 @@
 # Round 5, GPU call 4: backward without FMA contraction (legacy == new bit for bit), unrolled run-sum folds, Adam bump A/B, new tracker tests, bench line.
 set -u
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/r05d
+OUT=$ROOT/gpurun_out/r05e
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_raster_gpu.py tests/test_graph_gpu.py -q > $OUT/pytest_mapper.log 2>&1
@@ -17,10 +17,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_trai
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_mapper -o bench -- $M > $OUT/mapper_only.json 2> $OUT/kt_mapper.err
 GSICP_ADAM_INKERNEL_BUMP=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_mapper_inkernel_bump -o bench -- $M > $OUT/mapper_only_inkernel_bump.json 2> $OUT/kt_mapper_b.err
 $M > $OUT/mapper_only_plain.json 2>> $OUT/kt_mapper.err
-timeout 900 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+GSICP_EMIT_WALK=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_mapper_emit_walk -o bench -- $M > $OUT/mapper_only_emit_walk.json 2> $OUT/kt_mapper_w.err
 cd $ROOT
 find $OUT -name '*.csv' -size +20M -delete
-for d in kt_trained kt_mapper kt_mapper_inkernel_bump; do echo == $d; python - <<PY
+for d in kt_trained kt_mapper kt_mapper_inkernel_bump kt_mapper_emit_walk; do echo == $d; python - <<PY
 import csv, re
 for r in list(csv.DictReader(open("$OUT/$d/bench_kernel_stats.csv")))[:17]:
     m = re.search(r'(\w+_kernel)', r["Name"])
@@ -29,13 +29,6 @@ PY
 done
 python -c "
 import json
-for f in ('mapper_only_plain','trained_leg','bench'):
-    try:
-        d=json.load(open('$OUT/'+f+'.json')); print(f, d['ms_per_step'], d.get('value'))
-    except Exception as e: print(f, 'failed', e)
-d=json.load(open('$OUT/bench.json'))
-print({k: d.get(k) for k in ('system_fps','ate_cm','psnr','ate_cm_noisy','ate_cm_noisy_fused','ate_true_rmse_cm_noisy','ate_true_rmse_cm_noisy_fused')})
-print('roofline', d['roofline']['frac'], d['roofline']['kernel_us'], d['roofline'].get('traffic'))
-lg=d['legs']; print('trained', lg['mapper_trained_map'].get('ms_per_iteration'), 'tum', lg.get('step_tum',{}).get('ms_per_step'), 'mapper_only', lg['mapper_only'])
+for f in ('mapper_only_plain','trained_leg'):
+    d=json.load(open('$OUT/'+f+'.json')); print(f, d['ms_per_step'], d.get('value'))
 "
-tail -5 $OUT/bench.err
