@@ -46,9 +46,11 @@ def patch_gaussian_model(cls):
     plain_update_lr = cls.update_learning_rate
 
     def create_from_pcd2_tensor(self, points, colors, rots_, scales_, z_vals_, trackable_idxs):
-        # rows of the capacity-backed map (~260 B each incl. both Adam moments and the second buffer set: 4 M rows = 1 GB of 288 GB).  The reference's map
-        # grows without bound [REF scene/gaussian_model.py:474-492]; whole-room Replica maps reach 1-2 M Gaussians.
-        capacity = int(os.environ.get("GSICP_FUSED_CAPACITY", "4000000"))
+        # rows of the capacity-backed map (376 B each: parameters, both Adam moments and statistics in two buffer sets: 2 M rows = 0.75 GB of 288 GB;
+        # the per-row kernels run their grids over the capacity, so it is not made larger than a run needs).  The reference's map grows without
+        # bound [REF scene/gaussian_model.py:474-492]; whole-room Replica maps reach 1-2 M Gaussians: when the capacity is exhausted the new
+        # keyframe's Gaussians are dropped with a message naming this variable (add_from_pcd2_tensor below), the run goes on.
+        capacity = int(os.environ.get("GSICP_FUSED_CAPACITY", "2000000"))
         n_rest = (self.max_sh_degree + 1) ** 2 - 1
         self._store = GaussianStore(capacity, n_rest=n_rest, device=points.device, stable=True)
         rows, mask = rows_from_gicp(points.float(), colors.float(), rots_.float(), scales_.float(), z_vals_.float(), trackable_idxs, self.max_sh_degree)

@@ -88,7 +88,8 @@ def main():
                  "reference_run_unlimit400", "reference_run_limit30_300", "reference_run_tum_layout60", "bench_gpus2_gloo_one_gpu",
                  "mfma_cov_experiment", "bench_mapper_only", "bench_tracker_only", "bench_force_collectives", "rccl_graph_probe",
                  "bench_pair_survey", "bench_pair_basin", "bench_driver_cmd", "tracker_vs_map", "reference_run_fused_unlimit400", "reference_run_fused_limit30_300",
-                 "reference_run_unlimit1500", "reference_run_fused_unlimit1500"):
+                 "reference_run_unlimit1500", "reference_run_fused_unlimit1500", "bench_trained_leg", "fused_pacing_sweep", "fused_pacing_sweep_v2",
+                 "bench_mapper_only_emit_walk", "bench_mapper_only_legacy_backward", "bench_mapper_only_inkernel_bump"):
         j = last_json_line(os.path.join(src, name + ".json"))
         if j is not None:
             json.dump(j, open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
@@ -99,7 +100,9 @@ def main():
         if os.path.exists(os.path.join(src, name)):
             import shutil
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
-    for sub, suffix in (("kt", ""), ("kt_mapper", "_mapper_only"), ("kt_tracker", "_tracker_only")):
+    for sub, suffix in (("kt", ""), ("kt_mapper", "_mapper_only"), ("kt_tracker", "_tracker_only"), ("kt_trained", "_trained_map"),
+                        ("kt_mapper_emit_walk", "_mapper_only_emit_walk"), ("kt_mapper_legacy", "_mapper_only_legacy_backward"),
+                        ("kt_mapper_inkernel_bump", "_mapper_only_inkernel_bump")):
         ks = find(os.path.join(src, sub), "*kernel_stats.csv")
         if ks:
             rows = list(csv.DictReader(open(ks)))
@@ -126,16 +129,17 @@ def main():
                     traffic[STAGE_OF[k]] = {"fetch_bytes": fb, "write_bytes": wb, "kernel": k}
         json.dump(traffic, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
         print("traffic:", {k: (v["fetch_bytes"] + v["write_bytes"]) // 1000000 for k, v in traffic.items()}, "MB")
-    sq = pmc_means(os.path.join(src, "sq"))
-    for k_, v_ in pmc_means(os.path.join(src, "sq2")).items():      # second counter pass (tools/capture_profiles.sh)
-        sq.setdefault(k_, {}).update(v_)
-    if sq:
-        cols = sorted({c for v in sq.values() for c in v})
-        with open(os.path.join(dst, f"{tag}_rocprofv3_pmc_sq.csv"), "w") as fh:
-            fh.write("kernel," + ",".join(cols) + "\n")
-            for k in sorted(sq):
-                fh.write(k + "," + ",".join(f"{sq[k].get(c, 0.0):.1f}" for c in cols) + "\n")
-        print("sq counters:", len(sq), "kernels")
+    for a_, b_, suffix in (("sq", "sq2", ""), ("sq_trained", "sq2_trained", "_trained_map")):
+        sq = pmc_means(os.path.join(src, a_))
+        for k_, v_ in pmc_means(os.path.join(src, b_)).items():      # second counter pass (tools/capture_profiles.sh)
+            sq.setdefault(k_, {}).update(v_)
+        if sq:
+            cols = sorted({c for v in sq.values() for c in v})
+            with open(os.path.join(dst, f"{tag}_rocprofv3_pmc_sq{suffix}.csv"), "w") as fh:
+                fh.write("kernel," + ",".join(cols) + "\n")
+                for k in sorted(sq):
+                    fh.write(k + "," + ",".join(f"{sq[k].get(c, 0.0):.1f}" for c in cols) + "\n")
+            print("sq counters" + suffix + ":", len(sq), "kernels")
 
 
 def refresh_bench_lines(tag):
