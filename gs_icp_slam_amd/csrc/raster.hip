@@ -112,11 +112,11 @@ __global__ void publish_count_kernel(const uint32_t* __restrict__ total, uint32_
 // Single workgroup: exclusive scan of the per-tile duplicate counts -> list ranges, and an LPT dispatch order by a
 // counting sort over 64 length buckets (exact ordering is not needed for load balance).  Any T; one launch.
 constexpr int LPT_BUCKETS = 64;   // = the wave size (the bucket scan below runs on one wave)
-__global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int gx, int tile_mod, int tile_rem, const uint32_t* __restrict__ tile_count,
-                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_hist[LPT_BUCKETS];
-    __shared__ uint32_t s_maxlen;
+template <int THREADS>
+__device__ __forceinline__ void tile_scan_lpt_body(int T, int gx, int tile_mod, int tile_rem, const uint32_t* tile_count, uint2* __restrict__ ranges,
+                                                   uint32_t* __restrict__ order, uint32_t* s_wave /* [THREADS / 64] */, uint32_t* s_hist /* [LPT_BUCKETS] */,
+                                                   uint32_t* s_maxlen_p) {
+    uint32_t& s_maxlen = *s_maxlen_p;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_maxlen = 0;
     if (tid < LPT_BUCKETS) s_hist[tid] = 0;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int gx, int 
     // exclusive scan in ONE pass: thread i owns the `per` consecutive tiles starting at i * per (one wave scan + 16 wave totals, two barriers,
     // whatever T is; a 1024-tile-per-round loop cost three barriers per round)
     {
-        const int per = (T + 1023) / 1024;
+        const int per = (T + THREADS - 1) / THREADS;
         const int t0 = tid * per, t1 = (t0 + per) < T ? (t0 + per) : T;
         uint32_t sum = 0, wmax = 0;
         for (int t = t0; t < t1; ++t) { const uint32_t c = tile_count[t]; sum += c; wmax = c > wmax ? c : wmax; }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int gx, int 
     // LPT order over this rank's tiles
     const uint32_t maxlen = s_maxlen;
     const uint32_t div = maxlen / LPT_BUCKETS + 1;
-    for (int t = tid; t < T; t += 1024) {
+    for (int t = tid; t < T; t += THREADS) {
         if (!tile_is_mine(t, gx, tile_mod, tile_rem)) continue;
         const uint32_t c = tile_count[t];
         atomicAdd(&s_hist[LPT_BUCKETS - 1 - (c / div)], 1u);     // bucket 0 = longest lists
@@ -167,12 +167,19 @@ __global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int gx, int 
         s_hist[tid] = incl - h;
     }
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) {
+    for (int t = tid; t < T; t += THREADS) {
         if (!tile_is_mine(t, gx, tile_mod, tile_rem)) continue;
         const uint32_t c = tile_count[t];
         const uint32_t pos = atomicAdd(&s_hist[LPT_BUCKETS - 1 - (c / div)], 1u);
         order[pos] = (uint32_t)t;
     }
+}
+__global__ __launch_bounds__(1024) void tile_scan_lpt_kernel(int T, int gx, int tile_mod, int tile_rem, const uint32_t* __restrict__ tile_count,
+                                                             uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_hist[LPT_BUCKETS];
+    __shared__ uint32_t s_maxlen;
+    tile_scan_lpt_body<1024>(T, gx, tile_mod, tile_rem, tile_count, ranges, order, s_wave, s_hist, &s_maxlen);
 }
 
 // One thread per Gaussian (id order): fill its contiguous run of emission slots — tile id, depth bits, list word
@@ -331,9 +338,7 @@ __global__ __launch_bounds__(1024) void split_hist_kernel(const uint32_t* __rest
     for (int t = threadIdx.x; t < T; t += 1024) block_hist[(size_t)blockIdx.x * T + t] = s_hist_dyn[t];
 }
 // pass 2: one thread per tile turns its column of the table into exclusive prefixes and yields the tile's total
-__global__ __launch_bounds__(256) void split_colscan_kernel(int T, int nb, uint32_t* __restrict__ block_hist, uint32_t* __restrict__ tile_count) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
+__device__ __forceinline__ void split_colscan_column(int T, int nb, int t, uint32_t* __restrict__ block_hist, uint32_t* __restrict__ tile_count) {
     uint32_t run = 0;
     int b = 0;
     for (; b + 8 <= nb; b += 8) {   // eight independent (coalesced across threads) loads in flight per step
@@ -349,6 +354,27 @@ __global__ __launch_bounds__(256) void split_colscan_kernel(int T, int nb, uint3
         run += c;
     }
     tile_count[t] = run;
+}
+// Round 5: the LAST workgroup of this launch to finish also turns the tile totals into list ranges and the LPT order (tile_scan_lpt_body) — the
+// single-workgroup tile_scan_lpt_kernel (7.4 us, most of it launch floor) is no launch of its own any more.  `done` is a zeroed word of the
+// forward's counter block; ~13 workgroups count themselves in after an agent-scope fence (their tile totals must be visible to the last one:
+// a fence per workgroup is an L2 write-back on gfx950 — affordable for 13 workgroups, ruinous for the 6 144 of the Adam launch).
+__global__ __launch_bounds__(256) void split_colscan_kernel(int T, int nb, uint32_t* __restrict__ block_hist, uint32_t* tile_count, uint32_t* done, int gx,
+                                                            int tile_mod, int tile_rem, uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_hist[LPT_BUCKETS];
+    __shared__ uint32_t s_maxlen;
+    __shared__ int s_last;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < T) split_colscan_column(T, nb, t, block_hist, tile_count);
+    if (!done) return;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    tile_scan_lpt_body<256>(T, gx, tile_mod, tile_rem, tile_count, ranges, order, s_wave, s_hist, &s_maxlen);
 }
 // pass 3: scatter every emission slot into its tile's range; the rank inside the (block, tile) cell comes from an LDS
 // cursor.  Order inside a tile is arbitrary here — the per-tile sort that follows makes it unique.
@@ -1020,10 +1046,15 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                                  tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits, num_rendered_dev); }
         { ProfileScope ps(ST_SPLIT_HIST, stream);
           hipLaunchKernelGGL(split_hist_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, block_hist); }
+        static const bool scan_launch = [] { const char* e = getenv("GSICP_TILE_SCAN_LAUNCH"); return e && e[0] == '1'; }();   // A/B: rounds 1-4's separate launch
         { ProfileScope ps(ST_SPLIT_COLSCAN, stream);
-          hipLaunchKernelGGL(split_colscan_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, nb, block_hist, tile_count); }
-    }
-    {
+          hipLaunchKernelGGL(split_colscan_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, nb, block_hist, tile_count,
+                             scan_launch ? (uint32_t*)nullptr : total_counter + 2, gx, tile_mod, tile_rem, ranges, order); }
+        if (scan_launch) {
+            ProfileScope ps(ST_RANGES, stream);
+            hipLaunchKernelGGL(tile_scan_lpt_kernel, dim3(1), dim3(1024), 0, stream, T, gx, tile_mod, tile_rem, tile_count, ranges, order);
+        }
+    } else {    // no duplicates at all (synchronous path only): the tile totals are the zeros of zero_fill_kernel
         ProfileScope ps(ST_RANGES, stream);
         hipLaunchKernelGGL(tile_scan_lpt_kernel, dim3(1), dim3(1024), 0, stream, T, gx, tile_mod, tile_rem, tile_count, ranges, order);
     }
