@@ -355,10 +355,10 @@ __device__ __forceinline__ void split_colscan_column(int T, int nb, int t, uint3
     }
     tile_count[t] = run;
 }
-// Round 5: the LAST workgroup of this launch to finish also turns the tile totals into list ranges and the LPT order (tile_scan_lpt_body) — the
-// single-workgroup tile_scan_lpt_kernel (7.4 us, most of it launch floor) is no launch of its own any more.  `done` is a zeroed word of the
-// forward's counter block; ~13 workgroups count themselves in after an agent-scope fence (their tile totals must be visible to the last one:
-// a fence per workgroup is an L2 write-back on gfx950 — affordable for 13 workgroups, ruinous for the 6 144 of the Adam launch).
+// Round 5 experiment (`done` non-NULL: GSICP_TILE_SCAN_MERGED=1, default OFF): the LAST workgroup of this launch to finish also turns the tile totals
+// into list ranges and the LPT order (tile_scan_lpt_body), so that the single-workgroup tile_scan_lpt_kernel is no launch of its own.  `done` is a
+// zeroed word of the forward's counter block; the ~13 workgroups count themselves in after an agent-scope fence (their tile totals must be visible
+// to the last one).  LOST: on gfx950 such a fence writes back the XCD's L2 — 21.9 us for this kernel against 7.4 + 7.6 us for the two launches.
 __global__ __launch_bounds__(256) void split_colscan_kernel(int T, int nb, uint32_t* __restrict__ block_hist, uint32_t* tile_count, uint32_t* done, int gx,
                                                             int tile_mod, int tile_rem, uint2* __restrict__ ranges, uint32_t* __restrict__ order) {
     __shared__ uint32_t s_wave[4];
@@ -1046,7 +1046,10 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                                  tile_mod, tile_rem, emit_tile, emit_depth, entry_gauss, entry_bits, num_rendered_dev); }
         { ProfileScope ps(ST_SPLIT_HIST, stream);
           hipLaunchKernelGGL(split_hist_kernel, dim3(nb), dim3(1024), lds_bytes, stream, total_counter, cap, T, emit_tile, block_hist); }
-        static const bool scan_launch = [] { const char* e = getenv("GSICP_TILE_SCAN_LAUNCH"); return e && e[0] == '1'; }();   // A/B: rounds 1-4's separate launch
+        // GSICP_TILE_SCAN_MERGED=1: ranges + LPT order by the last workgroup of the column scan instead of a launch of their own — measured and LOST
+        // (round 5: 21.9 us against 7.4 + 7.6: the agent-scope fence each of the 13 workgroups needs before it counts itself in is a write-back of its
+        // XCD's whole L2, which at that point holds the emit and histogram kernels' fresh output); the default keeps the separate launch
+        static const bool scan_launch = [] { const char* e = getenv("GSICP_TILE_SCAN_MERGED"); return !(e && e[0] == '1'); }();
         { ProfileScope ps(ST_SPLIT_COLSCAN, stream);
           hipLaunchKernelGGL(split_colscan_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, T, nb, block_hist, tile_count,
                              scan_launch ? (uint32_t*)nullptr : total_counter + 2, gx, tile_mod, tile_rem, ranges, order); }
