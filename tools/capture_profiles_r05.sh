@@ -9,6 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 rm -rf $ROOT/gpurun_out/parity_report
+find $ROOT/gpurun_out -mindepth 1 -maxdepth 1 ! -name $TAG -exec rm -rf {} + 2>/dev/null    # the box starts without gpurun_out anyway; keep the result small
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu_final.log 2>&1
 tail -6 $OUT/pytest_gpu_final.log | cut -c1-300
 python -c "import __graft_entry__ as g; g.smoke()" >> $OUT/pytest_gpu_final.log 2>&1
@@ -32,8 +33,14 @@ timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/sq2_trained -o p -- $T > /dev/null 2> $OUT/sq2_trained.err
 cd $ROOT
 (GSICP_ALIGN_TRACE=1 timeout 120 python tools/tracker_latency.py --map 300000 > $OUT/tracker_latency_map300k.txt 2>&1)
-find $OUT -name '*.csv' -size +20M -delete
-ls $OUT | head -50
+# only gpurun_out/ comes back, and at most 64 MiB of it: summarise ON THE BOX into $OUT/profiles_out (what tools/collect_profiles.py would write into
+# profiles/), then drop the raw traces and counter dumps (10-40 MB each)
+GSICP_PROFILES_DST=$OUT/profiles_out python tools/collect_profiles.py $TAG r05 > $OUT/collect.log 2>&1
+tail -12 $OUT/collect.log
+rm -rf $OUT/kt $OUT/kt_mapper $OUT/kt_tracker $OUT/kt_trained $OUT/fetch $OUT/write $OUT/sq $OUT/sq2 $OUT/sq_trained $OUT/sq2_trained
+rm -rf $ROOT/gpurun_out/reference_slam_*.log $ROOT/gpurun_out/trained_*.npz
+du -sh $ROOT/gpurun_out
+ls $OUT $OUT/profiles_out | head -70
 python - <<PY
 import json
 d = json.load(open("$OUT/bench.json"))

@@ -82,7 +82,7 @@ def main():
     src_tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     tag = sys.argv[2] if len(sys.argv) > 2 else src_tag          # collect_profiles.py <gpurun_out subdir> [<profiles prefix>]
     src = os.path.join(ROOT, "gpurun_out", src_tag)
-    dst = os.path.join(ROOT, "profiles")
+    dst = os.environ.get("GSICP_PROFILES_DST") or os.path.join(ROOT, "profiles")     # on the GPU box: a directory under gpurun_out/ (only that comes back)
     os.makedirs(dst, exist_ok=True)
     for name in ("bench", "bench_tum", "bench_basin", "bench_eager", "bench_under_rocprof", "reference_run_replica", "reference_run_tum_shaped",
                  "reference_run_unlimit400", "reference_run_limit30_300", "reference_run_tum_layout60", "bench_gpus2_gloo_one_gpu",
@@ -95,7 +95,7 @@ def main():
             json.dump(j, open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
             if "value" in j:
                 print(name, j["value"], j["unit"], j["ms_per_step"], "ms/step")
-    for name in ("slam_demo.txt", "reference_call_trace.json", "reference_call_trace_fused.json", "tracker_latency_survey.txt", "tracker_latency_map300k.txt",
+    for name in ("pytest_gpu_final.log", "slam_demo.txt", "reference_call_trace.json", "reference_call_trace_fused.json", "tracker_latency_survey.txt", "tracker_latency_map300k.txt",
                  "map_quality_curve.json", "scale_coverage.json", "pmc_calibration.json"):
         if os.path.exists(os.path.join(src, name)):
             import shutil
@@ -145,7 +145,7 @@ def main():
 def refresh_bench_lines(tag):
     """bench.py reads profiles/<tag>_pmc_traffic.json and _pmc_sq.csv for `roofline.traffic` and the issue-floor note; the bench
     lines captured in the same gpurun call were produced BEFORE this collection, so restate both fields from the fresh counters."""
-    dst = os.path.join(ROOT, "profiles")
+    dst = os.environ.get("GSICP_PROFILES_DST") or os.path.join(ROOT, "profiles")
     tpath, sqpath = os.path.join(dst, f"{tag}_pmc_traffic.json"), os.path.join(dst, f"{tag}_rocprofv3_pmc_sq.csv")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     sq = {r["kernel"]: r for r in csv.DictReader(open(sqpath))} if os.path.exists(sqpath) else {}
