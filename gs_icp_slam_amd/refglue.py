@@ -206,8 +206,9 @@ def fused_mapping_iteration(mapper, viewpoint_cam, gt_image, gt_depth_image):
 #                     PSNR >= untouched — with the MOST iterations: 300 noisy frames 0.56-0.62 cm / 27.7-28.2 dB at 2 050-2 110 iterations
 #                     (untouched 0.77-1.04 cm / 22.8-23.3 dB), 16 363 iterations at the 30-FPS cap 0.67 cm / 28.3 dB (round 4, free-running: 9.3 cm),
 #                     TUM-shaped 0.31-0.37 cm / 27.3 dB (untouched 0.31 cm / 17.3 dB), noise-free 0.005 cm / 34.1 dB.
-#   budget            the reference's optimiser untouched, at most GSICP_FUSED_ITERS_PER_FRAME (2) steps per tracked frame, the GPU time it frees
-#                     left to the tracker: 0.74-0.84 cm / 25.1-25.7 dB at 614 iterations; 4 per frame already loses the track (7.8 cm).
+#   budget            DIAGNOSTIC: the reference's optimiser untouched, at most GSICP_FUSED_ITERS_PER_FRAME (2) steps per tracked frame, the GPU time it
+#                     frees left to the tracker: 0.74-0.84 cm / 25.1-25.7 dB over 300 frames (614 steps) — but it only postpones the damage: 4 per frame
+#                     lose the track over 300 frames (7.8 cm), 2 per frame over 600 (14.5 cm at 1 217 steps, where `freeze` gives 0.61 cm at 4 061).
 #   free              rounds 3-4: free-run, everything trains (noise-free data only).
 # GSICP_FUSED_FREEZE_GROUPS overrides which parameter groups the freeze covers (e.g. "xyz": the experiment that showed positions are not the cause).
 DEFAULT_POLICY = "freeze"
