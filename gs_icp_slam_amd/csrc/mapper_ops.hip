@@ -87,7 +87,12 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
     const int n_tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
     const int lx = tid & 31, ry = tid >> 5;      // this thread's output column and its group of four rows
     float l1 = 0.f, ssum = 0.f;
-    if (ch == 3) {   // depth term: L1(depth / d_max, gt_depth / d_max), masked where gt == 0
+    // Round 5 experiment (grid z = 3, GSICP_LOSS_DEPTH_IN_CH0=1, default OFF): the depth term of a tile computed by the tile's channel-0 workgroup after
+    // its colour work, by the same threads in the same order (same partial-sum slot, same bits).  The idea: the z = 3 slice is a quarter of the launch's
+    // workgroups, each holding a 39 KB LDS allocation for a few loads and a reduction.  Measured: no gain (they leave their slots at once).
+    const bool depth_here = ch == 3 || (gridDim.z == 3 && ch == 0);
+    float l1d = 0.f;
+    if (depth_here) {   // depth term: L1(depth / d_max, gt_depth / d_max), masked where gt == 0 (loads issued before the colour work)
         const int px = x0 + lx;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -95,9 +100,12 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
             if (px < W && py < H) {
                 const float g = gt_depth[(size_t)py * W + px] / d_max;
                 const float d = depth[(size_t)py * W + px] / d_max;
-                if (g != 0.f) l1 += fabsf(d - g);
+                if (g != 0.f) l1d += fabsf(d - g);
             }
         }
+    }
+    if (ch == 3) {
+        l1 = l1d;
     } else {
         // stage the halo tile: y = gt * (gt_depth > 0), x = where(y != 0, image, 0); zero outside the image.  All loads of the
         // (unrolled) loop are unconditional on clamped addresses and issued before the first use: this phase is pure latency.
@@ -199,6 +207,16 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
         partial[((size_t)ch * n_tiles + tile) * 2 + 0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
         partial[((size_t)ch * n_tiles + tile) * 2 + 1] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
     }
+    if (depth_here && ch != 3) {   // the tile's depth sum into the slot the z = 3 workgroup used to fill (its SSIM word is zero there as well)
+        __syncthreads();
+        l1d = wave_sum_f(l1d);
+        if ((tid & 63) == 0) { s_red[tid >> 6][0] = l1d; s_red[tid >> 6][1] = 0.f; }
+        __syncthreads();
+        if (tid == 0) {
+            partial[((size_t)3 * n_tiles + tile) * 2 + 0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+            partial[((size_t)3 * n_tiles + tile) * 2 + 1] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+        }
+    }
 }
 
 // Finish the sums in a fixed order and form the loss.  out = {loss, L1, SSIM mean, depth L1}.  256 threads; called either by the
@@ -259,7 +277,8 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, ch = blockIdx.z;
     const size_t HW = (size_t)W * H;
     const int px = x0 + lx;
-    if (ch == 3) {
+    const bool depth_here = ch == 3 || (gridDim.z == 3 && ch == 0);     // round 5: grid z = 3, the depth gradient of a tile by its channel-0 workgroup
+    if (depth_here) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int py = y0 + 4 * ry + j;
@@ -271,6 +290,8 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
                 dL_ddepth[pix] = gr;
             }
         }
+    }
+    if (ch == 3) {
         if (blockIdx.x == 0 && blockIdx.y == 0 && red.out) loss_reduce_body(red, tid);   // pass 1's partial sums are complete: finish the loss value here
         return;
     }
@@ -330,6 +351,10 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
             }
             dL_dimage[ch * HW + pix] = gr;
         }
+    }
+    if (gridDim.z == 3 && ch == 0 && blockIdx.x == 0 && blockIdx.y == 0 && red.out) {
+        __syncthreads();
+        loss_reduce_body(red, tid);   // pass 1's partial sums are complete: finish the loss value here (same 256 threads, same order: same bits)
     }
 }
 
@@ -935,7 +960,11 @@ static int mapper_loss_impl(const float* image, const float* depth, const float*
         for (int i = 0; i < 11; ++i) win.w[i] = g1[i] / sum;
     }
     const size_t HW = (size_t)width * height;
-    const dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, 4);
+    // GSICP_LOSS_DEPTH_IN_CH0=1: the two passes with grid z = 3, a tile's depth term computed by its channel-0 workgroup — measured and NOT adopted
+    // (round 5: 32.4 + 31.6 us against 31.9 + 30.7: the z = 3 slice's workgroups leave their CU slots at once; they were not costing workgroup rounds)
+    static const bool depth_slice = [] { const char* e = getenv("GSICP_LOSS_DEPTH_IN_CH0"); return !(e && e[0] == '1'); }();
+    const dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, 4);                          // the sharded (fused) kernel keeps its own depth slice
+    const dim3 grid2p(grid.x, grid.y, depth_slice ? 4 : 3);                                    // the two-pass form: depth folded into channel 0
     const int n_tiles = grid.x * grid.y;
     float* abc = (float*)scratch;
     float* partial = (float*)(scratch + align_up(9 * HW * sizeof(float)));
@@ -959,12 +988,12 @@ static int mapper_loss_impl(const float* image, const float* depth, const float*
         return 0;
     }
     { ProfileScope ps(ST_LOSS_PASS1, stream);
-      hipLaunchKernelGGL(loss_pass1_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
+      hipLaunchKernelGGL(loss_pass1_kernel, grid2p, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                          -lambda_dssim / n_img, abc, partial, gt_slots);
       if (!with_grads) hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, red); }
     if (with_grads) {   // one workgroup of pass 2 finishes the loss value (no launch of its own)
         ProfileScope ps(ST_LOSS_PASS2, stream);
-        hipLaunchKernelGGL(loss_pass2_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
+        hipLaunchKernelGGL(loss_pass2_kernel, grid2p, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                            (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth, red, gt_slots);
     }
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss: kernel launch failed"; return -1; }
