@@ -188,3 +188,53 @@ def test_fused_transform_edits_exactly_the_documented_statements():
             "print('fused ok')\n") % fused
     r = subprocess.run([sys.executable, "-W", "ignore", "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_fused_policy_and_pacing_host_logic(monkeypatch):
+    """gs_icp_slam_amd/refglue.py's policy switch and the `budget` pacing loop, without a GPU: the default is `freeze` over xyz / scaling / rotation with
+    no pacing; `budget` holds the loop to k optimiser steps per tracked frame (the shared frame counter), lets an iteration through at once when the
+    tracker raises a keyframe flag (it blocks on the mapper there [REF mp_Tracker.py:285-286]) and never waits longer than GSICP_FUSED_MAX_WAIT_MS."""
+    import threading
+    import time
+    import types
+    from gs_icp_slam_amd import refglue
+    for k in ("GSICP_FUSED_POLICY", "GSICP_FUSED_ITERS_PER_FRAME", "GSICP_FUSED_FREEZE_GROUPS", "GSICP_FUSED_MIN_PERIOD_MS", "GSICP_FUSED_BURST", "GSICP_FUSED_MAX_WAIT_MS"):
+        monkeypatch.delenv(k, raising=False)
+    p = refglue.fused_policy()
+    assert p["name"] == "freeze" and set(p["freeze_groups"]) == {"xyz", "scaling", "rotation"} and p["iters_per_frame"] == 0.0
+    monkeypatch.setenv("GSICP_FUSED_POLICY", "free")
+    assert refglue.fused_policy() == dict(name="free", freeze_groups=(), iters_per_frame=0.0)
+    monkeypatch.setenv("GSICP_FUSED_POLICY", "nonsense")
+    with pytest.raises(RuntimeError):
+        refglue.fused_policy()
+    monkeypatch.setenv("GSICP_FUSED_POLICY", "budget")
+    assert refglue.fused_policy()["iters_per_frame"] == refglue.DEFAULT_ITERS_PER_FRAME and refglue.fused_policy()["freeze_groups"] == ()
+
+    monkeypatch.setenv("GSICP_FUSED_BURST", "2")
+    monkeypatch.setenv("GSICP_FUSED_MAX_WAIT_MS", "400")
+    frames, eod, tkf, mkf = [0], [0], [0], [0]
+    mapper = types.SimpleNamespace(iter_shared=frames, end_of_dataset=eod, is_tracking_keyframe_shared=tkf, is_mapping_keyframe_shared=mkf)
+    gm = types.SimpleNamespace()
+
+    def paced(steps_done):
+        gm.__dict__["_gsicp_steps"] = steps_done
+        t0 = time.perf_counter()
+        refglue._pace(mapper, gm)
+        return time.perf_counter() - t0
+    assert paced(0) < 0.05 and paced(3) < 0.05            # burst 2 + 2 x (0 + 1) = 4 steps allowed while frame 0 is being tracked
+    # over budget: waits until the tracker has consumed another frame
+    threading.Timer(0.08, lambda: frames.__setitem__(0, 1)).start()
+    dt = paced(4)
+    assert 0.05 < dt < 0.35, dt
+    # over budget, but the tracker raises a tracking keyframe: the iteration goes through at once
+    threading.Timer(0.05, lambda: tkf.__setitem__(0, 1)).start()
+    dt = paced(100)
+    assert 0.02 < dt < 0.3, dt
+    tkf[0] = 0
+    # a stalled frame counter cannot hang the mapper
+    monkeypatch.setenv("GSICP_FUSED_MAX_WAIT_MS", "60")
+    dt = paced(100)
+    assert 0.04 < dt < 0.3, dt
+    assert gm.__dict__.get("_gsicp_paced", 0) >= 3
+    # a mapper object without the shared flags (the iteration probe of the tests): no pacing at all
+    assert refglue._pace(types.SimpleNamespace(iter_shared=[0]), gm) is None
