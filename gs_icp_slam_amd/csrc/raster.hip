@@ -538,9 +538,7 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
     for (int i = tid; i < npad; i += THREADS) {
         if (i < n) {
             const uint4 e = sc_pack[range.x + i];
-            // round 5: the block bits are made exact HERE, before the sort (the refinement is a function of the entry alone): the gather of the
-            // Gaussian's record is in flight with the list loads instead of a dependent round of its own behind the sort's last barrier
-            s_val[i] = refine_block_bits(e.y, rec[e.z], tile_x0, tile_y0);
+            s_val[i] = e.y;
             s_key[i] = ((unsigned long long)e.x << 32) | e.z;
         } else {
             s_key[i] = ~0ull;
@@ -552,9 +550,10 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
     bitonic_pairs<THREADS>(s_key, s_val, npad, tid);
     __syncthreads();
     for (int i = tid; i < n; i += THREADS) {
-        point_list[range.x + i] = s_val[i];
+        const uint32_t gid = (uint32_t)s_key[i];        // low word of the sort key = Gaussian id
+        point_list[range.x + i] = refine_block_bits(s_val[i], rec[gid], tile_x0, tile_y0);
         tile_keys[range.x + i] = tile;
-        list_gauss[range.x + i] = (uint32_t)s_key[i];   // low word of the sort key = Gaussian id
+        list_gauss[range.x + i] = gid;
     }
 }
 // One workgroup per tile of the LPT order (grid-stride, so a smaller persistent grid also works; `limit_dev`, optional, bounds the
