@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void loss_fused_kernel(const float* __restrict
     float l1 = 0.f, ssum = 0.f;
     // multi-GPU: a 32x32 block is one 2x2 super-tile of the rasteriser (raster_common.hpp tile_xy_is_mine); only its owner works on it, the
     // others contribute zero partial sums and leave its pixels of dL_dimage / dL_ddepth alone (nobody reads them on this rank)
-    if (tile_mod > 1 && (tile % tile_mod) != tile_rem) {
+    if (tile_mod > 1 && !(tile_mod_is_band(tile_mod) ? super_row_is_mine((int)blockIdx.y, tile_mod) : (tile % tile_mod) == tile_rem)) {
         if (tid == 0) { partial[((size_t)ch * n_tiles + tile) * 2 + 0] = 0.f; partial[((size_t)ch * n_tiles + tile) * 2 + 1] = 0.f; }
         return;
     }
@@ -977,7 +977,7 @@ static int mapper_loss_impl(const float* image, const float* depth, const float*
         // 70 us / N against 33 + 33 us replicated (on one GPU the two passes are faster: csrc/experiments/README.md).  loss_out receives this
         // rank's SHARE {loss, L1, SSIM mean, depth L1}: the sum over the ranks is the loss (the constant lambda is split N ways).
         const LossReduceArgs red_n{(const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim, depth_weight, loss_out,
-                                   lambda_dssim / (float)tile_mod};
+                                   lambda_dssim / (float)tile_world(tile_mod, tile_rem)};
         { ProfileScope ps(ST_LOSS_PASS1, stream);
           hipLaunchKernelGGL(loss_fused_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                              -lambda_dssim / n_img, (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), dL_dimage, dL_ddepth, partial,

@@ -31,7 +31,16 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // S = (ty / 2) * ceil(gx / 2) + tx / 2 belongs to rank S % tile_mod.  A super-tile is exactly one 32x32-pixel block of the loss kernels, so
 // the rank that blends a block also owns its loss gradient (round 3; rounds 1-2 dealt single tiles, t % tile_mod, and every rank computed the
 // whole loss).  Interleaving keeps the load balanced; tile_mod <= 1 means "all tiles".
+// BAND ownership (round 5): instead of dealing super-tiles round-robin, a rank may own a CONTIGUOUS band of super-tile rows (= rows of 32x32 loss
+// blocks).  Encoded in the same two integers so that no signature changes: tile_mod = TILE_BAND_FLAG | hi << 15 | lo owns the super-tile rows
+// [lo, hi); tile_rem = world << 16 | rank.  With bands a rank's loss blocks need the image of its two neighbours only within the SSIM window's
+// reach (10 pixel rows each way: 0.4 MB at 1200 px instead of the whole 13.7 MB image) — gs_icp_slam_amd/sharded.py, `bands=`.
+constexpr int TILE_BAND_FLAG = 1 << 30;
+__host__ __device__ inline bool tile_mod_is_band(int tile_mod) { return (tile_mod & TILE_BAND_FLAG) != 0; }
+__host__ __device__ inline int tile_world(int tile_mod, int tile_rem) { return tile_mod_is_band(tile_mod) ? (tile_rem >> 16) : tile_mod; }
+__host__ __device__ inline bool super_row_is_mine(int srow, int tile_mod) { return srow >= (tile_mod & 0x7FFF) && srow < ((tile_mod >> 15) & 0x7FFF); }
 __host__ __device__ inline bool tile_xy_is_mine(int tx, int ty, int gx, int tile_mod, int tile_rem) {
+    if (tile_mod_is_band(tile_mod)) return super_row_is_mine(ty >> 1, tile_mod);
     return tile_mod <= 1 || ((((ty >> 1) * ((gx + 1) >> 1)) + (tx >> 1)) % tile_mod) == tile_rem;
 }
 __host__ __device__ inline bool tile_is_mine(int t, int gx, int tile_mod, int tile_rem) {

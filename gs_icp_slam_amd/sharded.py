@@ -77,6 +77,108 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+# ---------------------------------------------------------------------------------------------------------------- band ownership (round 5)
+TILE_BAND_FLAG = 1 << 30          # csrc/raster_common.hpp: tile_mod = FLAG | hi << 15 | lo owns the super-tile rows [lo, hi); tile_rem = world << 16 | rank
+BAND_HALO = 10                    # pixel rows a band needs from each neighbour: the gradient at a pixel reaches 5 px to the SSIM-map values it enters, each of
+#                                   which reaches 5 px into the image [REF utils/loss_utils.py:37-69: 11x11 window] — what loss_fused_kernel stages around a block
+
+
+def band_code(lo, hi, rank, world):
+    """(tile_mod, tile_rem) of the band of super-tile rows [lo, hi) — 32-pixel rows of 32x32 loss blocks — owned by `rank` of `world`."""
+    lo, hi = int(lo), int(hi)
+    if not (0 <= lo < hi < (1 << 15)) or not (0 <= rank < world < (1 << 14)):
+        raise RuntimeError(f"band_code: bad band [{lo}, {hi}) / rank {rank} of {world}")
+    return TILE_BAND_FLAG | (hi << 15) | lo, (int(world) << 16) | int(rank)
+
+
+def tile_owner_mask(W, H, tile_mod, tile_rem):
+    """(H, W) bool: the pixels of the tiles (tile_mod, tile_rem) owns — the rule of csrc/raster_common.hpp tile_xy_is_mine, both encodings."""
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    if int(tile_mod) & TILE_BAND_FLAG:
+        lo, hi = int(tile_mod) & 0x7FFF, (int(tile_mod) >> 15) & 0x7FFF
+        return ((ys // 32) >= lo) & ((ys // 32) < hi)
+    if int(tile_mod) <= 1:
+        return torch.ones((H, W), dtype=torch.bool)
+    sgx = ((W + 15) // 16 + 1) // 2
+    return (((ys // 32) * sgx + (xs // 32)) % int(tile_mod)) == int(tile_rem)
+
+
+def equal_bands(H, world):
+    """Boundaries (world + 1 super-tile rows) of `world` bands of equal height."""
+    n = (H + 31) // 32
+    if world > n:
+        raise RuntimeError(f"equal_bands: {world} ranks for {n} super-tile rows")
+    return [round(i * n / world) for i in range(world + 1)]
+
+
+def balanced_bands(row_load, world):
+    """Boundaries (world + 1) of contiguous bands of super-tile rows with balanced load: `row_load[r]` = work of super-tile row r (e.g. the
+    duplicates of its tiles, from the ranges of a probe forward).  Greedy on the prefix sums with at least one row per band; the largest
+    band is within one row's load of the optimum.  Re-compute at keyframe rate: new boundaries mean a new ShardedGaussianRasterizer (and a
+    re-capture of the iteration: the boundaries are launch constants)."""
+    load = [float(x) for x in row_load]
+    n = len(load)
+    if world > n:
+        raise RuntimeError(f"balanced_bands: {world} ranks for {n} super-tile rows")
+    total = sum(load)
+    bounds, acc, r = [0], 0.0, 0
+    for k in range(1, world):
+        target = total * k / world
+        while r < n - (world - k) and (acc + load[r] <= target or r < bounds[-1] + 1):
+            acc += load[r]
+            r += 1
+        if r < bounds[-1] + 1:
+            acc += load[r]
+            r += 1
+        bounds.append(r)
+    bounds.append(n)
+    return bounds
+
+
+def band_halo_chunk(color, depth, bounds, rank):
+    """This rank's contribution to the halo exchange: the first and the last BAND_HALO pixel rows of its band, (2, 4, BAND_HALO, W) — r, g, b, depth."""
+    H = color.shape[-2]
+    y0, y1 = 32 * bounds[rank], min(H, 32 * bounds[rank + 1])
+    img = torch.cat([color, depth], dim=0)
+    return torch.stack([img[:, y0:y0 + BAND_HALO, :], img[:, y1 - BAND_HALO:y1, :]]).contiguous()
+
+
+def band_apply_halos(color, depth, gathered, bounds, rank):
+    """Write the neighbours' rows into this rank's image: `gathered` (world, 2, 4, BAND_HALO, W) holds every rank's chunk; rank r takes the LAST rows of
+    band r - 1 (they lie just above its band) and the FIRST rows of band r + 1.  Returns new (color, depth); every pixel of the band and of its halo is
+    then what the single-GPU rasteriser produces, bit for bit (each was rendered by exactly one rank)."""
+    H = color.shape[-2]
+    y0, y1 = 32 * bounds[rank], min(H, 32 * bounds[rank + 1])
+    color, depth = color.clone(), depth.clone()
+    if rank > 0:
+        color[:, y0 - BAND_HALO:y0, :] = gathered[rank - 1, 1, 0:3]
+        depth[:, y0 - BAND_HALO:y0, :] = gathered[rank - 1, 1, 3:4]
+    if rank + 1 < gathered.shape[0] and y1 < H:
+        n = min(BAND_HALO, H - y1)
+        color[:, y1:y1 + n, :] = gathered[rank + 1, 0, 0:3, :n]
+        depth[:, y1:y1 + n, :] = gathered[rank + 1, 0, 3:4, :n]
+    return color, depth
+
+
+class _ExchangeHalos(torch.autograd.Function):
+    """Band mode: ONE all-gather of every rank's 2 x BAND_HALO boundary rows (2 x 10 x W x 4 floats = 0.38 MB per rank at W = 1200, against the 13.7 MB
+    image of the round-robin mode), torch slicing around it (the same code on CPU and GPU; all sizes static: capturable).  Backward: identity —
+    every rank's loss kernel produces the full gradient of its own pixels, and the rasteriser backward consumes only those."""
+
+    @staticmethod
+    def forward(ctx, depth, color, group, holder, rank, world, bounds):
+        mine = band_halo_chunk(color, depth, bounds, rank)
+        gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        _all_gather_flat(gathered.view(world, -1), mine.view(-1), group)
+        holder.last_image_bytes = mine.numel() * mine.element_size()
+        c, d = band_apply_halos(color, depth, gathered, bounds, rank)
+        return d, c
+
+    @staticmethod
+    def backward(ctx, g_depth, g_color):
+        return g_depth, g_color, None, None, None, None, None
+
+
 class _GatherImage(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, color, group, holder, rank, world):
@@ -265,7 +367,11 @@ class ShardedGaussianRasterizer(nn.Module):
     ``rasterizer_cls`` is injectable so that the CPU (gloo) tests can exercise the collective logic."""
 
     def __init__(self, raster_settings, group=None, rasterizer_cls=None, force_collectives=False, compact_grads=True, sync_is_used=False,
-                 vis_capacity=0):
+                 vis_capacity=0, bands=None):
+        """bands (round 5): None = super-tiles dealt round-robin, the whole image all-gathered (rounds 1-4); "equal" or a list of world + 1
+        super-tile-row boundaries (`equal_bands`, `balanced_bands`) = every rank owns a CONTIGUOUS band of 32-pixel rows and only 2 x BAND_HALO
+        boundary rows per rank are exchanged.  The returned image is then defined on the rank's band and its halo (what its loss blocks read) and
+        zero elsewhere."""
         super().__init__()
         if rasterizer_cls is None:
             from .rasterizer import GaussianRasterizer as rasterizer_cls
@@ -274,7 +380,20 @@ class ShardedGaussianRasterizer(nn.Module):
         self.group, self.world, self.rank = group, world, rank
         self.force_collectives = bool(force_collectives) and dist.is_initialized()   # exercise the collective path at world size 1
         self.compact_grads, self.sync_is_used = bool(compact_grads), bool(sync_is_used)
-        self.raster_settings = raster_settings._replace(tile_mod=world, tile_rem=rank)
+        self.bands = None
+        if bands is not None and world > 1:
+            H = int(raster_settings.image_height)
+            b = equal_bands(H, world) if isinstance(bands, str) else [int(x) for x in bands]
+            n_rows = (H + 31) // 32
+            if len(b) != world + 1 or b[0] != 0 or b[-1] != n_rows or any(b[i + 1] <= b[i] for i in range(world)):
+                raise RuntimeError(f"ShardedGaussianRasterizer: bands must be {world + 1} increasing super-tile-row boundaries from 0 to {n_rows}, got {b}")
+            if min(min(H, 32 * b[i + 1]) - 32 * b[i] for i in range(world)) < BAND_HALO:
+                raise RuntimeError(f"ShardedGaussianRasterizer: every band must be at least {BAND_HALO} pixel rows high (image height {H}, bands {b})")
+            self.bands = b
+            code = band_code(b[rank], b[rank + 1], rank, world)
+            self.raster_settings = raster_settings._replace(tile_mod=code[0], tile_rem=code[1])
+        else:
+            self.raster_settings = raster_settings._replace(tile_mod=world, tile_rem=rank)
         self.inner = rasterizer_cls(raster_settings=self.raster_settings)
         self.holder = _Holder()
         self.holder.vis_capacity = int(vis_capacity or 0)
@@ -285,6 +404,8 @@ class ShardedGaussianRasterizer(nn.Module):
 
     def loss_shard(self):
         """(tile_mod, tile_rem) for `mapper_loss_and_grads`: this rank computes the loss on the 32x32 blocks (= 2x2 super-tiles) it blends."""
+        if self.bands is not None:
+            return self.raster_settings.tile_mod, self.raster_settings.tile_rem
         return (self.world, self.rank) if self.world > 1 else (1, 0)
 
     def attach_loss_share(self, parts):
@@ -335,7 +456,10 @@ class ShardedGaussianRasterizer(nn.Module):
         cap = int(getattr(self.raster_settings, "capacity", 0) or 0)
         count = getattr(self.inner, "num_rendered", None)
         holder.guard = (count, cap) if (cap > 0 and count is not None) else None
-        depth, color = _GatherImage.apply(depth, color, self.group, holder, self.rank, self.world)
+        if self.bands is not None:
+            depth, color = _ExchangeHalos.apply(depth, color, self.group, holder, self.rank, self.world, self.bands)
+        else:
+            depth, color = _GatherImage.apply(depth, color, self.group, holder, self.rank, self.world)
         if self.sync_is_used:
             is_used = is_used.clone()
             dist.all_reduce(is_used, op=dist.ReduceOp.MAX, group=self.group)

@@ -16,9 +16,8 @@ from tests import util
 
 
 def _tile_mask(W, H, mod, rem):
-    sy, sx = np.meshgrid(np.arange(H) // 32, np.arange(W) // 32, indexing="ij")      # tiles are dealt in 2x2 super-tiles (32x32-pixel blocks)
-    sid = sy * (((W + 15) // 16 + 1) // 2) + sx
-    return torch.from_numpy((sid % mod) == rem)
+    from gs_icp_slam_amd.sharded import tile_owner_mask      # the ownership rule of csrc/raster_common.hpp in torch: round-robin super-tiles or a band
+    return tile_owner_mask(W, H, mod, rem)
 
 
 class _OracleRasterFn(torch.autograd.Function):
@@ -212,3 +211,90 @@ def test_two_rank_keyframe_parallel_sums_the_views_gradients():
     for k in outs[0][2]:
         assert np.array_equal(outs[0][2][k], outs[1][2][k])
     assert not np.array_equal(outs[0][1], outs[1][1])
+
+
+# ---------------------------------------------------------------------------------------------------------------- band mode (round 5)
+def _band_worker(rank, world, port, q, H, bands):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gs_icp_slam_amd.sharded import BAND_HALO, ShardedGaussianRasterizer, tile_owner_mask
+    W = 80
+    cam = synth.make_camera(W, H, 64.0, 64.0)
+    g = _scene()
+    target = torch.from_numpy(np.random.default_rng(0).random((4, H, W)).astype(np.float32))
+    sh = ShardedGaussianRasterizer(_settings(cam), rasterizer_cls=_OracleRasterizer, bands=bands)
+    own = tile_owner_mask(W, H, *sh.loss_shard())
+    t = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in g.items()}
+    m2d = torch.zeros_like(t["means3D"], requires_grad=True)
+    depth, color, radii, used = sh(means3D=t["means3D"], means2D=m2d, shs=t["shs"], opacities=t["opacities"], scales=t["scales"], rotations=t["rotations"])
+    # every rank takes the loss of ITS OWN band (as the sharded loss kernel does); the shares sum to the full-image loss
+    n = float(3 * H * W)
+    loss = (((color - target[:3]).abs() * own).sum() / n) + 0.1 * (((depth - target[3:]).abs() * own).sum() / float(H * W))
+    loss.backward()
+    q.put((rank, color.detach().numpy(), depth.detach().numpy(), own.numpy(), {k: v.grad.numpy() for k, v in t.items()}, float(loss.detach()),
+           sh.holder.last_image_bytes, sh.bands))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,bands", [(2, 48, "equal"), (3, 128, [0, 1, 3, 4]), (8, 256, "equal")])
+def test_band_sharding_exchanges_halos_not_images(world, H, bands):
+    """contiguous bands of super-tile rows + a halo exchange instead of round-robin super-tiles + an all-gather of the image.
+    On every rank the image equals the single-process image BIT FOR BIT on its band and on the BAND_HALO rows above and below it (everything its loss
+    blocks read); the bytes a rank contributes are 2 x BAND_HALO x W x 4 floats whatever the image height; the ranks' own-band losses sum to the
+    full loss and the all-reduced gradients equal the single-process gradients."""
+    from gs_icp_slam_amd.sharded import BAND_HALO
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, q, H, bands)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=300) for _ in procs], key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    W = 80
+    cam = synth.make_camera(W, H, 64.0, 64.0)
+    g = _scene()
+    target = torch.from_numpy(np.random.default_rng(0).random((4, H, W)).astype(np.float32))
+    color, depth, grads, used = _run(_OracleRasterizer(_settings(cam)), g, target)
+    color, depth = color.numpy(), depth.numpy()
+    covered = np.zeros((H, W), bool)
+    total = 0.0
+    for rank, c, d, own, gr, loss, nbytes, b in outs:
+        assert nbytes == 2 * 4 * BAND_HALO * W * 4, nbytes                       # this rank's contribution to the exchange: independent of H
+        rows = np.where(own.any(1))[0]
+        y0, y1 = rows.min(), rows.max() + 1
+        assert (y0, y1) == (32 * b[rank], min(H, 32 * b[rank + 1])) and own[y0:y1].all() and not covered[own].any()
+        covered |= own
+        lo, hi = max(0, y0 - BAND_HALO), min(H, y1 + BAND_HALO)
+        assert np.array_equal(c[:, lo:hi], color[:, lo:hi]) and np.array_equal(d[:, lo:hi], depth[:, lo:hi]), f"rank {rank}: band + halo differ"
+        total += loss
+        for k in grads:
+            # the sum of `world` fp32 partial gradients against one fp32 chain: rounding of the largest partial, relative to the tensor's scale
+            np.testing.assert_allclose(gr[k], grads[k].numpy(), rtol=2e-5, atol=1e-6 * (np.abs(grads[k].numpy()).max() + 1e-30))
+    assert covered.all()
+    full = float((torch.from_numpy(color) - target[:3]).abs().mean() + 0.1 * (torch.from_numpy(depth) - target[3:]).abs().mean())
+    assert abs(total - full) <= 1e-5 * abs(full)
+    for k in outs[0][4]:
+        assert all(np.array_equal(outs[0][4][k], o[4][k]) for o in outs[1:])       # every rank holds the same all-reduced gradients
+
+
+def test_balanced_bands_follow_the_load():
+    from gs_icp_slam_amd.sharded import balanced_bands, band_code, equal_bands, tile_owner_mask
+    assert equal_bands(680, 8) == [0, 3, 6, 8, 11, 14, 16, 19, 22] and equal_bands(480, 2) == [0, 8, 15]
+    assert balanced_bands([1, 1, 1, 10, 1, 1, 1, 1], 3) == [0, 3, 4, 8]                 # the heavy row gets a band of its own
+    b = balanced_bands([5.0] * 22, 8)
+    assert b[0] == 0 and b[-1] == 22 and all(2 <= b[i + 1] - b[i] <= 3 for i in range(8))
+    load = np.random.default_rng(1).integers(0, 50000, 22).tolist()
+    b = balanced_bands(load, 8)
+    sums = [sum(load[b[i]:b[i + 1]]) for i in range(8)]
+    assert all(b[i + 1] > b[i] for i in range(8)) and max(sums) <= sum(load) / 8 + max(load)
+    with pytest.raises(RuntimeError):
+        balanced_bands([1, 2], 3)
+    m = tile_owner_mask(80, 96, *band_code(1, 3, 1, 2))
+    assert m[32:].all() and not m[:32].any()
