@@ -263,7 +263,7 @@ def test_band_sharding_with_halo_exchange_on_emulated_ranks(hip_lib, world, W, H
         parts, g_c, g_d = mapper_loss_and_grads(c_in, d_in, gtc, gtd, tile_mod=shard[0], tile_rem=shard[1])
         torch.autograd.backward((color, depth), (g_c, g_d))
         return dict(color=color.detach(), depth=depth.detach(), c_in=c_in, d_in=d_in, parts=parts.clone(), g_c=g_c.clone(), g_d=g_d.clone(),
-                    grads={k: v.grad.clone() for k, v in t.items()}, ranges=ranges)
+                    grads={k: v.grad.clone() for k, v in t.items() if v.grad is not None}, ranges=ranges)
     full = run(rs)
     gx = (W + 15) // 16
     per_tile = (full["ranges"][:, 1] - full["ranges"][:, 0]).reshape(-1, gx).sum(1)                 # duplicates per tile row
