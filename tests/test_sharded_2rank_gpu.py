@@ -59,20 +59,24 @@ def _iterate(params, rast, gt_c, gt_d, steps):
     return np.stack(losses)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, bands=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gs_icp_slam_amd.sharded import ShardedGaussianRasterizer
     dev = torch.device("cuda", 0)
     params, rs, gt_c, gt_d = _setup(dev)
-    losses = _iterate(params, ShardedGaussianRasterizer(rs), gt_c, gt_d, STEPS)
-    q.put((rank, losses, {k: v.detach().cpu().numpy() for k, v in params.items()}))
+    rast = ShardedGaussianRasterizer(rs, bands=bands)
+    losses = _iterate(params, rast, gt_c, gt_d, STEPS)
+    q.put((rank, losses, {k: v.detach().cpu().numpy() for k, v in params.items()}, rast.holder.last_image_bytes))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_walk_the_single_gpu_trajectory(hip_lib):
+@pytest.mark.parametrize("bands", [None, "equal", [0, 2, 7]])
+def test_two_ranks_on_one_gpu_walk_the_single_gpu_trajectory(hip_lib, bands):
+    """bands=None: round-robin super-tiles + all-gather of the image (rounds 3-4).  bands="equal" / a list (round 5): contiguous bands of super-tile rows
+    + a halo exchange of 2 x 10 pixel rows per rank — the same trajectory with 1/27 of the image bytes exchanged at this size."""
     from diff_gaussian_rasterization import GaussianRasterizer
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -80,7 +84,7 @@ def test_two_ranks_on_one_gpu_walk_the_single_gpu_trajectory(hip_lib):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bands)) for r in range(2)]
     for p in procs:
         p.start()
     outs = sorted([q.get(timeout=420) for _ in procs], key=lambda o: o[0])
@@ -90,7 +94,11 @@ def test_two_ranks_on_one_gpu_walk_the_single_gpu_trajectory(hip_lib):
     dev = torch.device("cuda", 0)
     params, rs, gt_c, gt_d = _setup(dev)
     ref_losses = _iterate(params, GaussianRasterizer(rs), gt_c, gt_d, STEPS)
-    for rank, losses, pr in outs:
+    for rank, losses, pr, image_bytes in outs:
+        if bands is None:
+            assert image_bytes >= 4 * W * H * 4 // 2                     # this rank's half of the image (padded to whole super-tile slots)
+        else:
+            assert image_bytes == 2 * 4 * 10 * W * 4                     # 2 x BAND_HALO rows x W x {r, g, b, depth}
         np.testing.assert_allclose(losses, ref_losses, rtol=2e-5, atol=1e-7, err_msg=f"rank {rank}: summed loss shares differ from the single-GPU loss")
         for k, v in params.items():
             ref = v.detach().cpu().numpy()
