@@ -384,6 +384,10 @@ def main():
                     "letting the two halves run their --steps steps at their own pace inside the timed block")
     ap.add_argument("--no-graph", action="store_true", help="drive the mapper iteration eagerly from Python instead of replaying the captured HIP graph")
     ap.add_argument("--only", choices=["tracker", "mapper", "trained"], default=None, help="diagnostics: run only one half (the JSON line is then NOT the contract metric)")
+    ap.add_argument("--mp-bands", choices=["off", "equal", "balanced"], default="off",
+                    help="N > 1, --mp-mode tiles: `off` = super-tiles dealt round-robin + all-gather of the image (rounds 3-4, the rehearsed default); `equal` / "
+                         "`balanced` (round 5) = contiguous bands of 32-pixel rows per rank + a halo exchange of 2 x 10 rows (0.4 MB instead of 13.7 MB per rank); "
+                         "`balanced` places the boundaries by the duplicates per row, averaged over the keyframe views")
     ap.add_argument("--mp-mode", choices=["tiles", "keyframes"], default="tiles",
                     help="N > 1 GPUs: `tiles` (default) = ONE view per step, its screen tiles sharded over the ranks (same optimiser trajectory as 1 GPU: "
                          "strong scaling); `keyframes` = every rank renders its OWN view, one dense gradient all-reduce, N views per optimiser step "
@@ -523,7 +527,33 @@ def main():
             views.append(dict(rs=rs_v, gt_color=gc_v.clone(), gt_depth=gd_v.clone()))
         del t2
     gt_color, gt_depth = views[0]["gt_color"], views[0]["gt_depth"]     # the S-map camera: what the single-view legs use
-    rast = ShardedGaussianRasterizer(rs)
+    # N > 1, band mode (round 5): boundaries of the ranks' bands of super-tile rows — identical on every rank (same inputs, same arithmetic)
+    bands = None
+    if world > 1 and args.mp_bands != "off":
+        from gs_icp_slam_amd.sharded import balanced_bands, equal_bands
+        if args.mp_bands == "equal":
+            bands = equal_bands(H, world)
+        else:
+            import ctypes
+            lib_ = _lib.load()
+            gx_ = (W + 15) // 16
+            n_rows = (H + 31) // 32
+            load = np.zeros(n_rows)
+            with torch.no_grad():
+                o_, s__, q_ = activate(params["opacities"].detach(), params["scales"].detach(), params["rotations"].detach())
+            for v in views:     # duplicates per tile row from the ranges of an unsharded probe forward of this view
+                m3 = params["means3D"].detach().requires_grad_(True)
+                d_, c_, _r, _u = GaussianRasterizer(v["rs"])(means3D=m3, means2D=torch.zeros_like(m3), shs=params["shs"].detach(), opacities=o_, scales=s__, rotations=q_)
+                lay = (ctypes.c_size_t * 12)()
+                lib_.gsicp_raster_layout(P, int(c_.grad_fn.num_rendered), W, H, lay)
+                T_ = gx_ * ((H + 15) // 16)
+                rng_ = c_.grad_fn.saved_tensors[9][lay[6]: lay[6] + T_ * 8].cpu().numpy().view(np.uint32).reshape(T_, 2).astype(np.int64)
+                per_row = (rng_[:, 1] - rng_[:, 0]).reshape(-1, gx_).sum(1)
+                load += np.array([per_row[2 * r: 2 * r + 2].sum() for r in range(n_rows)], dtype=np.float64)
+                del d_, c_, m3
+            bands = balanced_bands(load.tolist(), world)
+    shard_kw = dict(bands=bands) if bands is not None else {}
+    rast = ShardedGaussianRasterizer(rs, **shard_kw)
     view_i = [0]
 
     # ---------------- tracker inputs (S-pairs) ----------------
@@ -706,7 +736,8 @@ def main():
         worst_r, worst_vis = 0, 0
         for v in views:
             while True:   # plain rasteriser on this rank's tiles: no collective inside a loop whose trip count may differ between ranks
-                probe = GaussianRasterizer(v["rs"]._replace(capacity=cap, tile_mod=world, tile_rem=rank))
+                own = rast.raster_settings if bands is not None else None       # band mode: this rank's band code
+                probe = GaussianRasterizer(v["rs"]._replace(capacity=cap, tile_mod=(own.tile_mod if own else world), tile_rem=(own.tile_rem if own else rank)))
                 with torch.no_grad():
                     a0 = activated()
                     radii_p = probe(means3D=a0["means3D"], means2D=torch.zeros_like(a0["means3D"]), shs=a0["shs"], opacities=a0["opacities"],
@@ -719,7 +750,7 @@ def main():
             worst_r, worst_vis = max(worst_r, r), max(worst_vis, v["visible"])
         return int(1.5 * worst_r) + 4096, int(1.5 * worst_vis) + 1024
     capacity, vis_capacity = probe_capacity()      # over ALL views; vis_capacity: rows of the static gradient all-reduce block (same on every rank: radii are replicated)
-    rasts = [ShardedGaussianRasterizer(v["rs"]._replace(capacity=capacity)) for v in views]   # eager iterations also run without the forward's host sync
+    rasts = [ShardedGaussianRasterizer(v["rs"]._replace(capacity=capacity), **shard_kw) for v in views]   # eager iterations also run without the forward's host sync
     rast = rasts[0]
 
     mg = None
@@ -730,7 +761,7 @@ def main():
         from gs_icp_slam_amd.graph import MapperIterationGraph
         # N > 1: the tile-sharded rasteriser with its static-size exchange (tile chunks all-gathered, visible gradient rows all-reduced) is
         # captured in the same graph, RCCL calls included (gs_icp_slam_amd/sharded.py)
-        factory = (lambda rs_: ShardedGaussianRasterizer(rs_, vis_capacity=vis_capacity, force_collectives=force_coll)) if (world > 1 or force_coll) else None
+        factory = (lambda rs_: ShardedGaussianRasterizer(rs_, vis_capacity=vis_capacity, force_collectives=force_coll, **shard_kw)) if (world > 1 or force_coll) else None
         mg = MapperIterationGraph(params, optimizer, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=capacity,
                                   lambda_dssim=0.2, warmup=2, rasterizer_factory=factory)
         mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_color, gt_depth)
@@ -1374,6 +1405,7 @@ def main():
                                                    if (mg is not None and (world > 1 or force_coll)) else None),
                        "variants": {"depth_mode": "sum z alpha T (un-normalised)", "fromqs_scale_mode": "s^2", "regularization": "PLANE"},
                        "mp_mode": (args.mp_mode if (world > 1 or force_coll) else None),
+                       "mp_bands": ({"mode": args.mp_bands, "super_tile_row_boundaries": bands} if world > 1 else None),
                        "parallelism": ("single GPU" if world == 1 else
                                        (f"mapper tiles sharded x{world} (RCCL all-gather of own tiles + all-reduce of visible gradient rows), tracker replicated"
                                         if args.mp_mode == "tiles" else
