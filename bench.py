@@ -1407,7 +1407,9 @@ def main():
                        "mp_mode": (args.mp_mode if (world > 1 or force_coll) else None),
                        "mp_bands": ({"mode": args.mp_bands, "super_tile_row_boundaries": bands} if world > 1 else None),
                        "parallelism": ("single GPU" if world == 1 else
-                                       (f"mapper tiles sharded x{world} (RCCL all-gather of own tiles + all-reduce of visible gradient rows), tracker replicated"
+                                       (f"mapper tiles sharded x{world} ({'collective' if backend != 'nccl' else 'RCCL'} "
+                                        + ("all-gather of own tiles" if bands is None else "halo exchange between contiguous bands of super-tile rows")
+                                        + " + all-reduce of visible gradient rows), tracker replicated"
                                         if args.mp_mode == "tiles" else
                                         f"data-parallel over keyframes x{world} (every rank its own view, one dense RCCL gradient all-reduce per step), tracker replicated")),
                        "world_size": world, "backend": backend if world > 1 else None, "rccl_ranks_seen": ranks_seen},

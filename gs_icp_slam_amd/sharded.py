@@ -12,9 +12,13 @@ rank that blends a block computes the loss gradient of that block (gs_icp_slam_a
             (SSIM needs an 11x11 window, [REF utils/loss_utils.py:37-69]: every block reads a 5-pixel halo of its neighbours, which the
             gathered full image provides) is computed on the rank's OWN 32x32 blocks only (`gsicp_mapper_loss_sharded`, one fused kernel
             whose work divides by N); the ranks' shares of the four loss values travel inside the gradient exchange.  The backward needs
-            no image collective.  (With round-robin super-tiles the halos of a rank's blocks touch every other rank's tiles, hence the
-            all-gather of the whole image; contiguous, load-balanced bands with a two-neighbour halo exchange — 0.2 MB instead of
-            13.7 MB per rank — are the next step of this mode)
+            no image collective.
+            `bands="equal" | "balanced-boundaries list"` (round 5) replaces the round-robin ownership by CONTIGUOUS bands of super-tile rows
+            (`tile_mod = TILE_BAND_FLAG | hi << 15 | lo`, decoded by the same kernels) and the image all-gather by a HALO exchange: each
+            rank contributes the first and last BAND_HALO = 10 pixel rows of its band (the fused one-pass loss reads 5 rows for the SSIM
+            window of a pixel and 5 more for the windows its gradient sums over), one all_gather of 2 x 4 x 10 x W floats per rank
+            (0.38 MB at W = 1200 instead of 13.7 MB), and every rank copies its two neighbours' rows next to its band.  Pixels outside
+            band + halo stay undefined and are never read.  `balanced_bands()` places the boundaries from per-row duplicate counts.
   backward: ALL-REDUCE(sum) of the per-Gaussian gradients of the VISIBLE Gaussians only — radii are replicated (every rank
             preprocesses all Gaussians), so every rank compacts the same rows (radii > 0: ~26 % of the map on the benchmark view) in
             index order into one packed block (14 floats x P_vis = 4.4 MB instead of 16.8 MB), all-reduces it and scatters it back;
