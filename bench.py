@@ -551,7 +551,7 @@ def main():
                 per_row = (rng_[:, 1] - rng_[:, 0]).reshape(-1, gx_).sum(1)
                 load += np.array([per_row[2 * r: 2 * r + 2].sum() for r in range(n_rows)], dtype=np.float64)
                 del d_, c_, m3
-            bands = balanced_bands(load.tolist(), world)
+            bands = balanced_bands(load.tolist(), world, H=H)
     shard_kw = dict(bands=bands) if bands is not None else {}
     rast = ShardedGaussianRasterizer(rs, **shard_kw)
     view_i = [0]

@@ -115,11 +115,12 @@ def equal_bands(H, world):
     return [round(i * n / world) for i in range(world + 1)]
 
 
-def balanced_bands(row_load, world):
+def balanced_bands(row_load, world, H=None):
     """Boundaries (world + 1) of contiguous bands of super-tile rows with balanced load: `row_load[r]` = work of super-tile row r (e.g. the
     duplicates of its tiles, from the ranges of a probe forward).  Greedy on the prefix sums with at least one row per band; the largest
     band is within one row's load of the optimum.  Re-compute at keyframe rate: new boundaries mean a new ShardedGaussianRasterizer (and a
-    re-capture of the iteration: the boundaries are launch constants)."""
+    re-capture of the iteration: the boundaries are launch constants).  With the image height `H` given, a last band that would consist of the
+    image's ragged bottom row alone and hold fewer than BAND_HALO pixel rows (H = 680: row 21 has 8) takes the row above it as well."""
     load = [float(x) for x in row_load]
     n = len(load)
     if world > n:
@@ -136,6 +137,10 @@ def balanced_bands(row_load, world):
             r += 1
         bounds.append(r)
     bounds.append(n)
+    if H is not None and world > 1 and int(H) - 32 * bounds[-2] < BAND_HALO:
+        if bounds[-2] - 1 <= bounds[-3]:
+            raise RuntimeError(f"balanced_bands: no room for a last band of {BAND_HALO} pixel rows (H {H}, boundaries {bounds})")
+        bounds[-2] -= 1
     return bounds
 
 
