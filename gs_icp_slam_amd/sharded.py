@@ -138,9 +138,12 @@ def balanced_bands(row_load, world, H=None):
         bounds.append(r)
     bounds.append(n)
     if H is not None and world > 1 and int(H) - 32 * bounds[-2] < BAND_HALO:
-        if bounds[-2] - 1 <= bounds[-3]:
-            raise RuntimeError(f"balanced_bands: no room for a last band of {BAND_HALO} pixel rows (H {H}, boundaries {bounds})")
         bounds[-2] -= 1
+        for i in range(world - 1, 0, -1):              # keep the boundaries increasing: push the ones above up by a row where needed
+            if bounds[i] >= bounds[i + 1]:
+                bounds[i] = bounds[i + 1] - 1
+        if bounds[1] <= 0:
+            raise RuntimeError(f"balanced_bands: no room for a last band of {BAND_HALO} pixel rows (H {H}, {world} ranks, {n} super-tile rows)")
     return bounds
 
 

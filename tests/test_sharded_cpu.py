@@ -297,6 +297,8 @@ def test_balanced_bands_follow_the_load():
     with pytest.raises(RuntimeError):
         balanced_bands([1, 2], 3)
     heavy_bottom = [1.0] * 21 + [100.0]                    # 680 rows: super-tile row 21 holds 8 pixel rows — not a band (BAND_HALO = 10) on its own
-    assert balanced_bands(heavy_bottom, 4)[-2] == 21 and balanced_bands(heavy_bottom, 4, H=680)[-2] == 20 and balanced_bands(heavy_bottom, 4, H=704)[-2] == 21
+    assert balanced_bands(heavy_bottom, 4) == [0, 19, 20, 21, 22] and balanced_bands(heavy_bottom, 4, H=680) == [0, 18, 19, 20, 22] and balanced_bands(heavy_bottom, 4, H=704)[-2] == 21
+    with pytest.raises(RuntimeError):
+        balanced_bands([1.0, 1.0, 9.0], 3, H=72)
     m = tile_owner_mask(80, 96, *band_code(1, 3, 1, 2))
     assert m[32:].all() and not m[:32].any()
