@@ -88,7 +88,7 @@ def _measure_pmc_traffic(kernel_substr, timeout=120.0):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--only", "mapper", "--steps", "8", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--no-legs"]
+                   "--only", "mapper", "--steps", "8", "--warmup", "2", "--repeats", "1", "--views", "2", "--min-seconds", "0", "--no-cpu-baseline", "--no-legs", "--legs-file", "/tmp/gsicp_bench_legs_pmc_child.json"]
             pr = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
             if pr.returncode != 0:
                 return None, f"rocprofv3 --pmc {counter} exited with {pr.returncode}: {pr.stderr[-300:]}"
@@ -345,6 +345,60 @@ def tracker_vs_map_leg(sizes=(8280, 100_000, 1_000_000), frames=60, fid=155, bac
     return out
 
 
+def compact_line(full, legs_path):
+    """The contract line: the driver's keys, `roofline` / `roofline_longest_kernel` / `cpu_baseline` without prose, and a flat handful of scalars.  Everything else
+    (legs, notes, per-block spreads, per-view arrays) is in the legs file.  tests/test_bench_cli.py holds this under 6 000 characters on a worst-case record."""
+    def cut(v, n):
+        return v if not isinstance(v, str) or len(v) <= n else v[: n - 3] + "..."
+
+    def pick(d, keys, n=160):
+        return None if not d else {k: cut(d.get(k), n) for k in keys if k in d}
+    legs = full.get("legs") or {}
+    cfg = full.get("config") or {}
+    leg = lambda name, key: (legs.get(name) or {}).get(key)   # noqa: E731
+    tm = legs.get("mapper_trained_map") or {}
+    tm_stage = tm.get("stage_us") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = cut(line["metric"], 200)
+    line["config"] = {"workload": cut(cfg.get("workload_short") or cfg.get("workload"), 300)}
+    line["config"].update({k: cut(cfg.get(k), 200) for k in ("gaussians", "width", "height", "duplicates_per_rank", "visible_gaussians", "keyframe_views", "tracker_workload",
+                                                             "lm_iterations", "tracker_target_gaussians", "mapper_iteration", "mp_mode", "parallelism", "world_size", "backend")
+                           if cfg.get(k) is not None})
+    if cfg.get("mp_bands"):
+        line["config"]["mp_bands"] = cfg["mp_bands"].get("mode")
+    line["roofline"] = pick(full.get("roofline"), ("bound", "kernel", "kernel_us", "algorithmic_bytes", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
+                                                   "traffic_last_capture"))
+    if full.get("roofline"):
+        for sub in ("whole_forward", "whole_backward"):
+            line["roofline"][sub + "_frac"] = (full["roofline"].get(sub) or {}).get("frac")
+    line["roofline_longest_kernel"] = pick(full.get("roofline_longest_kernel"), ("bound", "kernel", "kernel_us", "grid_wide_phases", "us_per_phase", "lm_iterations",
+                                                                                "algorithmic_bytes", "achieved", "peak", "unit", "frac", "traffic"), 80)
+    line["cpu_baseline"] = pick(full.get("cpu_baseline"), ("value", "unit", "cores", "host_cores", "kind", "sample", "pose_agrees_with_gpu"), 260)
+    line.update({
+        "block_ms_per_step_p10_p50_p90": full.get("block_ms_per_step_p10_p50_p90"), "repeats": full.get("repeats"), "timed_seconds": full.get("timed_seconds"),
+        "render_bwd_ms_per_iter": full.get("render_bwd_ms_per_iter"), "loss_adam_ms_per_iter": full.get("loss_adam_ms_per_iter"),
+        "render_bwd_ms_per_iter_trained_map": (round(sum(v for k, v in tm_stage.items() if not k.startswith(("loss_", "adam"))) / 1e3, 4) if tm_stage else None),
+        "mapper_iteration_ms_trained_map": tm.get("ms_per_iteration"), "trained_map_duplicates": tm.get("duplicates_mean"),
+        "trained_map_r7_frac": (tm.get("roofline_trained") or {}).get("frac"),
+        "mapper_only_ms_per_iter": leg("mapper_only", "ms_per_iteration"), "tracker_only_ms_per_frame": leg("tracker_only_steady", "ms_per_frame"),
+        "dropin_reference_loop_ms_per_iter": leg("dropin_reference_loop", "ms_per_iteration"),
+        "tracker_align_kernel_us": full.get("tracker_align_kernel_us"), "pose_error_deg_mm": full.get("pose_error_deg_mm"),
+        "tracker_pose_is_the_true_motion": full.get("tracker_pose_is_the_true_motion"),
+        "system_fps": full.get("system_fps"), "ate_cm": full.get("ate_cm"), "psnr": full.get("psnr"), "system_frames": leg("reference_system_run", "frames"),
+        "ate_cm_noisy": full.get("ate_cm_noisy"), "ate_cm_noisy_fused": full.get("ate_cm_noisy_fused"),
+        "fused_policy": full.get("fused_policy"),
+        "step_tum_ms": leg("step_tum", "ms_per_step"),
+        "stage_us_per_step": {k: round(v, 1) for k, v in (full.get("stage_us_per_step") or {}).items()},
+    })
+    for name in ("keyframe_parallel", "tile_sharded"):       # N > 1: the other multi-GPU mode, as two scalars
+        if legs.get(name):
+            line[name + "_value"] = legs[name].get("value")
+            line[name + "_ms_per_step"] = legs[name].get("ms_per_step")
+    line["section_wall_s"] = (full.get("section_wall_s") or {}).get("total")
+    line["legs_file"] = legs_path
+    return line
+
+
 def _spawn_ranks(n):
     import socket
     import subprocess
@@ -376,9 +430,16 @@ def main():
                          "Gaussians, keyframe cadence inside the timed region); `pair` = rounds 1-3's headline (one S-pair re-aligned against a frame-sized target; --pair)")
     ap.add_argument("--mapper-inflight", type=int, default=2, help="mapper iterations the host may have in flight (queued graph launches) inside a timed block")
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the run of the reference's own two-process system (System FPS / ATE / PSNR keys)")
+    ap.add_argument("--system-legs", action="store_true", help="all four runs of the reference's own two-process system on the drop-ins (400 frames clean + 300 frames "
+                    "noisy, each untouched and with SURVEY 8(f)'s rows applied: ~80 s); the default runs ONE 200-frame clean run of the untouched system")
+    ap.add_argument("--all-legs", action="store_true", help="every diagnostic leg (lockstep, tracker call profile, both S-pairs, tracker vs map sizes, mapper across "
+                    "keyframes, the TUM-shaped child run): minutes; the default runs the core legs only")
+    ap.add_argument("--legs-file", default=os.environ.get("GSICP_BENCH_LEGS_FILE", os.path.join(ROOT, "bench_legs.json")),
+                    help="where the FULL record (every leg, notes, per-block spreads) is written; the one JSON line on stdout stays under 6 KB and names this file")
+    ap.add_argument("--full-line", action="store_true", help="print the full record on stdout instead of the compact contract line (tools; NOT for the driver)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (tracker-only, mapper-only, eager, drop-in reference loop)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--serial", action="store_true", help="run tracker and mapper back-to-back on one thread (default: concurrently)")
     ap.add_argument("--lockstep", action="store_true", help="join the tracker frame and the mapper iteration after EVERY step (round 1's timing loop) instead of "
                     "letting the two halves run their --steps steps at their own pace inside the timed block")
@@ -394,6 +455,13 @@ def main():
                          "(SURVEY 8e's throughput alternative: NOT result-parity with the reference's one-view-per-step loop; weak scaling).  With "
                          "`tiles` the keyframes mode is also timed, as legs.keyframe_parallel")
     args = ap.parse_args()
+    sect = {}              # wall seconds of every section of this command (goes to the legs file: what the default command spends where)
+    t_sect = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        sect[name] = round(sect.get(name, 0.0) + now - t_sect[0], 2)
+        t_sect[0] = now
 
     # `python bench.py --gpus N` with N > 1 and no launcher around it (the contract's plain form): start the N ranks ourselves — one process per
     # GPU under torch.distributed.run on 127.0.0.1 with a free port — and pass their output through (rank 0 prints the one JSON line).  Under
@@ -843,6 +911,7 @@ def main():
             out.append(dt)
         return out
 
+    lap("imports_inputs_capture")
     for _ in range(args.warmup):
         step()
     free_running = worker is not None and not args.lockstep
@@ -854,6 +923,7 @@ def main():
     if mg is None and int(rast.inner.num_rendered.item()) > capacity:
         raise RuntimeError("duplicate-list capacity overflowed during the timed region")
     align_stats = trk.reg.last_align_stats() if args.only != "mapper" else {}
+    lap("warmup_and_timed_region")
 
     # ---------------- N > 1: the throughput mode, data-parallel over keyframes (SURVEY 8e alternative), timed on ALL ranks ----------------
     # Every rank renders ITS OWN view of the same map (full image, plain single-GPU rasteriser), one dense all-reduce sums the parameter
@@ -967,6 +1037,7 @@ def main():
             trk.step()
         per_launch_us.update({k: 1e3 * ms / n_e for k, (ms, c) in _lib.profile_read().items() if c > 0 and k.startswith("gicp")})
     _lib.profile_enable(False)
+    lap("per_kernel_hipevent_times")
 
     # ---------------- D (duplicates), P_vis: per keyframe view (counted by the capacity probe), averaged over the cycle ----------------
     D_views, Pvis_views = [v["duplicates"] for v in views], [v["visible"] for v in views]
@@ -1052,6 +1123,7 @@ def main():
 
     # ---------------- legs (rank 0, single GPU) ----------------
     legs = None
+    lap("roofline_and_pmc_passes")
     if rank == 0 and world == 1 and not args.no_legs and args.only is None:
         legs = {}
         reps = max(3, args.repeats)
@@ -1064,13 +1136,13 @@ def main():
 
         # -- the same step with both halves joined after EVERY step (round 1's timing loop; the queue hand-shake per step makes it slower and
         #    bimodal from run to run)
-        if worker is not None and free_running:
+        if worker is not None and free_running and args.all_legs:
             s_lock = rate(step, 100)
             legs["lockstep_step"] = {"frames_per_s": round(1.0 / s_lock, 1), "ms_per_step": round(1e3 * s_lock, 4),
                                      "what": "tracker frame and mapper iteration joined after every step (round-1 loop)"}
         # -- where the tracker's frame goes on the HOST side, alone and next to the free-running mapper: wall time of each of the four calls of a frame
         #    [REF mp_Tracker.py:191-199, 231] (the GPU work of a call is inside it only where the call has to wait: align, get_source_correspondence)
-        if worker is not None and free_running:
+        if worker is not None and free_running and args.all_legs:
             prof = {}
             for mode in ("alone", "co_tenant"):
                 acc = {}
@@ -1095,7 +1167,7 @@ def main():
         motions["steady"] = ("consecutive frames of the synthetic trajectory (~7 mm / 0.25 deg apart) against the map's trackable Gaussians; every 10th frame "
                              "exports the source covariances, every 40th replaces the target (set_target_from_gaussians)")
         cases = {("steady" if steady else args.pair): trk}
-        for name in ("steady", "survey", "basin"):
+        for name in (("steady", "survey", "basin") if args.all_legs else ("steady",)):
             if name not in cases:
                 cases[name] = SteadyTracker(pygicp.FastGICP()) if name == "steady" else TrackerCase(name, pygicp.FastGICP())
         for name, case in cases.items():
@@ -1116,8 +1188,10 @@ def main():
                 legs["tracker_only_steady"].update(target_gaussians=case.n_target, worst_pose_error_deg_mm=[round(case.worst[0], 4), round(case.worst[1], 3)],
                                                    index=case.reg.target_index_stats())
         # -- the tracker against MAP-sized targets (its steady-state configuration after the first tracking keyframe)
-        if os.environ.get("GSICP_BENCH_MAP_LEG", "1") != "0":
+        lap("tracker_legs")
+        if args.all_legs and os.environ.get("GSICP_BENCH_MAP_LEG", "1") != "0":
             legs["tracker_vs_map"] = tracker_vs_map_leg()
+            lap("tracker_vs_map")
         # -- mapper alone: graph replay, eager fused
         s_it = rate(lambda: mapper_iteration(), 100)
         legs["mapper_only"] = {"iterations_per_s": round(1.0 / s_it, 1), "ms_per_iteration": round(1e3 * s_it, 4),
@@ -1140,7 +1214,7 @@ def main():
         # -- the mapper loop ACROSS keyframes [REF mp_Mapper.py:161-195, 244-245]: parameters + Adam state in a GaussianStore(stable=True),
         #    ONE captured graph with the live count on the device; every 10th iteration a keyframe appends 8 280 Gaussians (rows written in
         #    place, count bumped on the device), one prune in the middle.  The rate INCLUDES the ingestion and the prune; re-captures must be 0.
-        if mg is not None:
+        if mg is not None and args.all_legs:
             from gs_icp_slam_amd.gaussian_store import GaussianStore
             from gs_icp_slam_amd.graph import MapperIterationGraph as _MG
             n_kf, per_kf = 12, 8280
@@ -1221,18 +1295,20 @@ def main():
                                          "what": "torch activations + synchronous GaussianRasterizer + torch l1/ssim + loss.backward() + torch.optim.Adam "
                                                  "(the statements of unmodified mp_Mapper.py:219-248)"}
         del rp, topt
+        lap("mapper_legs")
         # -- the mapper iteration where D is REAL: the map the fused loop trains (5x the duplicates of the S-map surfels)
         if args.res == "replica" and os.environ.get("GSICP_BENCH_TRAINED_LEG", "1") != "0":
             try:
                 legs["mapper_trained_map"] = trained_map_leg(dev, steps=100, reps=3, n_views=args.views)
             except Exception as e:   # noqa: BLE001 — a leg must not take the contract line with it
                 legs["mapper_trained_map"] = {"status": "failed", "why": f"{type(e).__name__}: {e}"[:400]}
+            lap("mapper_trained_map")
         # -- BASELINE configs[3]'s proxy: the same steady-state step at TUM's shape (640x480, 12 416-point noisy frames, gate 0.03, opacity threshold
         #    0.09 [REF tum.sh:135-142]) — a child run of this script, its contract line kept as the leg
-        if args.res == "replica" and os.environ.get("GSICP_BENCH_CHILD") != "1" and os.environ.get("GSICP_BENCH_TUM_LEG", "1") != "0":
+        if args.res == "replica" and os.environ.get("GSICP_BENCH_CHILD") != "1" and os.environ.get("GSICP_BENCH_TUM_LEG", "1") != "0" and (args.all_legs or os.environ.get("GSICP_BENCH_TUM_LEG") == "1"):
             import subprocess
             try:
-                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--res", "tum", "--no-legs", "--no-cpu-baseline", "--steps", str(args.steps),
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--res", "tum", "--no-legs", "--no-cpu-baseline", "--full-line", "--legs-file", "/tmp/gsicp_bench_legs_tum_child.json", "--steps", str(args.steps),
                                      "--warmup", str(args.warmup), "--repeats", "3"], capture_output=True, text=True, timeout=300,
                                     env=dict(os.environ, GSICP_BENCH_CHILD="1"))
                 line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
@@ -1242,6 +1318,7 @@ def main():
                                         tracker_target_gaussians=tj["config"]["tracker_target_gaussians"])
             except Exception as e:   # noqa: BLE001
                 legs["step_tum"] = {"status": "failed", "why": f"{type(e).__name__}: {e}"[:400]}
+            lap("step_tum")
 
     # ---------------- CPU baseline: OpenMP GICP oracle (port), rank 0 only ----------------
     cpu = None
@@ -1286,6 +1363,7 @@ def main():
                "sample": what + f", {t_cpu:.1f} s wall, OpenMP kd-tree oracle at its fastest thread count",
                "pose_agrees_with_gpu": agree}
 
+    lap("cpu_baseline")
     # ---------------- the reference's OWN two-process system on the drop-ins: BASELINE's metric as SURVEY 8(d) defines it ----------------
     # System FPS [REF mp_Tracker.py:333] and ATE (the reference's mean statistic [REF mp_Tracker.py:334, 479] and a true RMSE) of the unmodified
     # gs_icp_slam_unlimit.py on a 400-frame synthetic Replica-layout sequence, PSNR / SSIM of its end-of-run pass [REF mp_Mapper.py:335-422]
@@ -1294,39 +1372,39 @@ def main():
     if rank == 0 and world == 1 and args.only is None and not args.no_reference_leg and not args.no_legs and os.environ.get("GSICP_BENCH_CHILD") != "1":
         import subprocess
         torch.cuda.synchronize()
-        t0r = time.perf_counter()
-        try:
-            pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_slam.py"), "--synthetic", "400", "--cache", "/tmp/gsicp_synth_cache",
-                                 "--timeout", "240"], capture_output=True, text=True, timeout=420, env=dict(os.environ, GSICP_ATE_DETAIL="1"))
-            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
-            ref_run = json.loads(line[-1]) if line else {"status": "failed", "why": (pr.stderr or pr.stdout)[-400:]}
-        except Exception as e:   # noqa: BLE001 — the reference run must not take the benchmark line with it
-            ref_run = {"status": "failed", "why": f"{type(e).__name__}: {e}"}
-        ref_run["leg_wall_s"] = round(time.perf_counter() - t0r, 1)
-        # the same run with SURVEY 8(f)'s rows applied to the reference's files (oracle/make_refpy.py --fused; gs_icp_slam_amd/refglue.py)
-        ref_run_fused = None
-        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "refpy_fused", "mp_Mapper.pyc")):
+        have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "refpy", "mp_Mapper.pyc"))
+        have_fused = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "refpy_fused", "mp_Mapper.pyc"))
+
+        def system_run(frames, extra=(), detail=True):
+            """tools/run_reference_slam.py: the reference's unmodified gs_icp_slam_unlimit.py (byte-compiled by oracle/make_refpy.py in the build container) as the
+            DRIVER of the three drop-in packages on a synthetic Replica-layout sequence; its own printed statistics come back as one JSON line."""
+            t0r = time.perf_counter()
+            if not have_ref:
+                return {"status": "skipped", "why": "oracle/_ref/refpy is not on this box (python __graft_entry__.py builds it where /root/reference exists)"}
             try:
-                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_slam.py"), "--synthetic", "400", "--cache", "/tmp/gsicp_synth_cache",
-                                     "--timeout", "240", "--fused"], capture_output=True, text=True, timeout=420)
-                line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
-                ref_run_fused = json.loads(line[-1]) if line else {"status": "failed", "why": (pr.stderr or pr.stdout)[-400:]}
-            except Exception as e:   # noqa: BLE001
-                ref_run_fused = {"status": "failed", "why": f"{type(e).__name__}: {e}"}
-        # the same pair on NOISY depth (sensor model sigma(z) = 1.2 mm + 1.9 mm (z - 0.4)^2, 15 % holes) with fast hand-held motion: the bar of VERDICT r4
-        # item 1 — the fused system (default pacing: refglue.DEFAULT_ITERS_PER_FRAME) must keep the untouched system's ATE
-        for fused_ in (False, True):
-            if os.environ.get("GSICP_BENCH_NOISY_LEG", "1") == "0" or (fused_ and ref_run_fused is None):
-                continue
-            try:
-                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_slam.py"), "--synthetic", "300", "--noise", "--speed", "2", "--jitter", "0.003",
-                                     "--cache", "/tmp/gsicp_synth_cache", "--timeout", "240"] + (["--fused"] if fused_ else []), capture_output=True, text=True, timeout=420,
-                                    env=dict(os.environ, GSICP_ATE_DETAIL="1"))
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_reference_slam.py"), "--synthetic", str(frames), "--cache", "/tmp/gsicp_synth_cache",
+                                     "--timeout", "240"] + list(extra), capture_output=True, text=True, timeout=420,
+                                    env=dict(os.environ, **({"GSICP_ATE_DETAIL": "1"} if detail else {})))
                 line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
                 rj = json.loads(line[-1]) if line else {"status": "failed", "why": (pr.stderr or pr.stdout)[-400:]}
-            except Exception as e:   # noqa: BLE001
+            except Exception as e:   # noqa: BLE001 — the reference run must not take the benchmark line with it
                 rj = {"status": "failed", "why": f"{type(e).__name__}: {e}"}
-            noisy_runs["fused" if fused_ else "untouched"] = rj
+            rj["leg_wall_s"] = round(time.perf_counter() - t0r, 1)
+            return rj
+        if not args.system_legs:
+            ref_run = system_run(200)       # default: ONE short clean run of the untouched system (System FPS / ATE / PSNR of the compact line)
+        else:
+            ref_run = system_run(400)
+            # the same run with SURVEY 8(f)'s rows applied to the reference's files (oracle/make_refpy.py --fused; gs_icp_slam_amd/refglue.py)
+            if have_fused:
+                ref_run_fused = system_run(400, ["--fused"], detail=False)
+            # the same pair on NOISY depth (sensor model sigma(z) = 1.2 mm + 1.9 mm (z - 0.4)^2, 15 % holes) with fast hand-held motion: the bar of VERDICT r4
+            # item 1 — the fused system (default pacing: refglue.DEFAULT_ITERS_PER_FRAME) must keep the untouched system's ATE
+            for fused_ in (False, True):
+                if os.environ.get("GSICP_BENCH_NOISY_LEG", "1") == "0" or (fused_ and not have_fused):
+                    continue
+                noisy_runs["fused" if fused_ else "untouched"] = system_run(300, ["--noise", "--speed", "2", "--jitter", "0.003"] + (["--fused", "--policy", "freeze"] if fused_ else []))
+        lap("reference_system_runs")
 
     # ---------------- multi-GPU bookkeeping ----------------
     ranks_seen = None
@@ -1370,6 +1448,19 @@ def main():
                         f"gate {cfg['max_corr']} m, {it} LM iterations, lands {ang_mm[0]:.3f} deg / {ang_mm[1]:.1f} mm from the true motion] concurrent with one "
                         f"S-map mapper iteration (P={P}, {W}x{H}, sh_degree 0, depth = sum z alpha T, fromqs scale^2) on the next of {n_views} keyframe views")
         rr = ref_run or {}
+        if "T" not in last:
+            workload_short = workload
+        elif steady:
+            workload_short = (f"Replica room0-shaped synthetic (BASELINE configs[2]), steady state: GICP tracker frame ({len(trk.sp['points_b'])} pts, gate {cfg['max_corr']} m, {it} LM it.) "
+                              f"vs {trk.n_target} trackable map Gaussians, keyframes every {trk.map_kf}/{trk.track_kf} frames, concurrent with one mapper iteration "
+                              f"(P={P}, {W}x{H}, sh 0) over {n_views} views")
+        else:
+            workload_short = (f"Replica room0-shaped synthetic (BASELINE configs[2]): GICP tracker frame on the {args.pair} S-pair ({len(trk.sp['points_b'])} pts, gate "
+                              f"{cfg['max_corr']} m, {it} LM it.) concurrent with one mapper iteration (P={P}, {W}x{H}, sh 0) over {n_views} views")
+        fused_pol = None
+        if ref_run_fused is not None or noisy_runs.get("fused") is not None:
+            from gs_icp_slam_amd.refglue import POLICY_NOTES
+            fused_pol = {"reference_system_run_fused": POLICY_NOTES["free"], "reference_system_run_noisy_fused (ate_cm_noisy_fused)": POLICY_NOTES["freeze"]}
         out = {
             "metric": ("SLAM hot-path FPS (GICP tracker frame + one full mapper iteration: render, loss, backward, Adam), Replica room0-shaped synthetic"
                        if args.only is None else f"DIAGNOSTIC: {args.only} half only"),
@@ -1388,7 +1479,8 @@ def main():
             "ate_cm_noisy": noisy_runs.get("untouched", {}).get("ate_rmse_cm"), "ate_cm_noisy_fused": noisy_runs.get("fused", {}).get("ate_rmse_cm"),
             "ate_true_rmse_cm_noisy": noisy_runs.get("untouched", {}).get("ate_true_rmse_cm"),
             "ate_true_rmse_cm_noisy_fused": noisy_runs.get("fused", {}).get("ate_true_rmse_cm"),
-            "config": {"workload": workload,
+            "fused_policy": fused_pol,
+            "config": {"workload": workload, "workload_short": workload_short,
                        "tracker_workload": tkey, "tracker_motion": motions[tkey], "lm_iterations": it,
                        "tracker_target_gaussians": (trk.n_target if steady else None),
                        "gaussians": P, "width": W, "height": H, "duplicates_per_rank": D_local, "visible_gaussians": P_vis,
@@ -1430,7 +1522,18 @@ def main():
         if ref_run is not None:
             out["legs"] = dict(out["legs"] or {}, reference_system_run=ref_run, reference_system_run_fused=ref_run_fused,
                                reference_system_run_noisy=noisy_runs.get("untouched"), reference_system_run_noisy_fused=noisy_runs.get("fused"))
-        print(json.dumps(out))
+        lap("bookkeeping")
+        out["section_wall_s"] = dict(sect, total=round(sum(sect.values()), 1))
+        # ---- the FULL record goes to a file next to this script; stdout carries ONE compact line (a 22 KB line was cut by the driver and parsed as nothing)
+        legs_path = args.legs_file
+        try:
+            with open(legs_path, "w") as fh:
+                json.dump(out, fh, indent=1)
+        except OSError:
+            legs_path = os.path.join("/tmp", "gsicp_bench_legs.json")
+            with open(legs_path, "w") as fh:
+                json.dump(out, fh, indent=1)
+        print(json.dumps(out if args.full_line else compact_line(out, legs_path)))
     if worker is not None:
         jobs.put(None)
     if world > 1 or force_coll:

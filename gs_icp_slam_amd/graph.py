@@ -19,6 +19,7 @@ Several GPUs: pass `rasterizer_factory=lambda rs: ShardedGaussianRasterizer(rs, 
 have static sizes and are captured with everything else; the overflow guard then is the all-reduced flag, identical on every rank.
 """
 import ctypes
+import time
 
 import torch
 
@@ -27,6 +28,34 @@ from .activations import activate
 from .loss import mapper_loss_and_grads
 from .optim import FusedAdam
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def process_group_live():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def drain_process_group_watchdog(dev, seconds=None):
+    """Make a stream capture safe next to a live ProcessGroupNCCL.  The group's watchdog thread polls every outstanding
+    collective with hipEventQuery about every 100 ms until it has seen it finished; a capture in HIP's default GLOBAL mode forbids that call from
+    ANY thread, the query throws on the watchdog thread and the process is terminated (`operation not permitted when stream is capturing`).
+    Two measures, either of which is sufficient: (1) every capture of this package is begun in THREAD_LOCAL mode while a group is initialised
+    (`capture_mode()`), which restricts the rule to the capturing thread; (2) before capturing, the device is synchronised (all eager
+    collectives have finished) and the watchdog is given `seconds` (default 0.5 = several polling periods; GSICP_CAPTURE_DRAIN_S) to retire
+    them, so that nothing is left for it to poll during the capture.  No collective is issued here: a graph may be captured by one rank alone."""
+    if not process_group_live():
+        return
+    torch.cuda.synchronize(dev)
+    if seconds is None:
+        import os
+        seconds = float(os.environ.get("GSICP_CAPTURE_DRAIN_S", "0.5"))
+    time.sleep(max(0.0, seconds))
+    torch.cuda.synchronize(dev)
+
+
+def capture_mode():
+    """capture_error_mode for torch.cuda.graph: thread_local while a process group is initialised (see drain_process_group_watchdog), else the default."""
+    return "thread_local" if process_group_live() else "global"
 
 
 def default_activations(p, live_rows=None):
@@ -218,9 +247,16 @@ class MapperIterationGraph:
             if skipped0 is not None:
                 self.optimizer.skipped_steps.copy_(skipped0)
         torch.cuda.synchronize(dev)
+        drain_process_group_watchdog(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            parts, radii, used = self._iteration()
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
+                parts, radii, used = self._iteration()
+        except Exception:
+            self.graph = None       # a failed capture leaves no half-built graph behind: the caller may fall back to eager iterations
+            self.optimizer.zero_grad(set_to_none=True)
+            self._means2D.grad = None
+            raise
         self.loss_parts, self.radii, self.is_used = parts, radii, used
         self.num_rendered = self.rasterizer.num_rendered if hasattr(self.rasterizer, "num_rendered") else None
         if self.num_rendered is None and hasattr(self.rasterizer, "inner"):

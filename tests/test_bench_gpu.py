@@ -13,14 +13,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(extra, env_extra):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     env = dict(os.environ, **env_extra)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):     # other tests of this pytest process set rendezvous variables
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--repeats", "2", "--gaussians", "60000",
-                          "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
+                          "--no-cpu-baseline", "--legs-file", os.path.join(ROOT, "gpurun_out", "bench_legs_test.json")] + extra, env=env, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, f"stdout: {out.stdout[-2000:]}\nstderr: {out.stderr[-4000:]}"
-    return json.loads(lines[0])
+    assert len(lines[0]) < 6000, f"the contract line must stay under 6 KB (VERDICT r5: a 22 KB line was cut by the driver): {len(lines[0])}"
+    res = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in res, k
+    full = json.load(open(res["legs_file"]))        # the full record (legs, notes, spreads) sits next to the script; the line names the file
+    assert full["value"] == res["value"] and full["ms_per_step"] == res["ms_per_step"]
+    return full
 
 
 def test_gpus_2_starts_two_ranks_and_runs_both_multi_gpu_modes_over_gloo():

@@ -32,10 +32,13 @@ def main():
         dist.all_gather_into_tensor(gathered, mine)
     torch.cuda.synchronize()
     x.fill_(float(rank + 1))
-    side = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
+    # thread_local capture + a drained watchdog: ProcessGroupNCCL's watchdog thread polls the warm-up collectives with hipEventQuery, which a
+    # GLOBAL-mode capture forbids from any thread (gs_icp_slam_amd/graph.py: drain_process_group_watchdog)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gs_icp_slam_amd.graph import capture_mode, drain_process_group_watchdog
+    drain_process_group_watchdog(dev)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, capture_error_mode=capture_mode()):
         y = x * 2.0
         dist.all_reduce(y)
         dist.all_gather_into_tensor(gathered, mine)

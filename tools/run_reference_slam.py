@@ -151,11 +151,15 @@ def main():
     ap.add_argument("--log", default=None, help="write the reference's full stdout here")
     ap.add_argument("--fused", action="store_true", help="run the reference with INTEGRATION.md 6-8's few-line edits applied (oracle/make_refpy.py --fused: fused mapper "
                     "iteration as one hipGraph over a GaussianStore, device-resident target hand-off, front-end kernel) instead of the untouched files")
+    ap.add_argument("--policy", choices=["free", "freeze", "budget"], default=None, help="--fused: GSICP_FUSED_POLICY of the fused mapper (gs_icp_slam_amd/refglue.py; "
+                    "default `free` = the reference's optimiser; `freeze` / `budget` deviate from it)")
     ap.add_argument("--compiled-pygicp", action="store_true", help="let the reference's `import pygicp` resolve to the compiled pybind11 module "
                     "integration/pygicp.<abi>.so instead of the ctypes mirror package")
     ap.add_argument("--compiled-ext", action="store_true", help="all three native boundaries as compiled extension modules: --compiled-pygicp plus "
                     "`diff_gaussian_rasterization` / `simple_knn._C` from integration/torch_ext/ (the pybind11 torch extension `_C` over the C ABI)")
     a = ap.parse_args()
+    if a.policy:
+        os.environ["GSICP_FUSED_POLICY"] = a.policy
     ref = find_reference(a.reference, fused=a.fused)
     if ref is None:
         print(json.dumps({"status": "not measured", "why": "no reference tree (/root/reference or oracle/_ref/refpy) on this machine"}))
