@@ -16,8 +16,9 @@ rank that blends a block computes the loss gradient of that block (gs_icp_slam_a
             `bands="equal" | "balanced-boundaries list"` (round 5) replaces the round-robin ownership by CONTIGUOUS bands of super-tile rows
             (`tile_mod = TILE_BAND_FLAG | hi << 15 | lo`, decoded by the same kernels) and the image all-gather by a HALO exchange: each
             rank contributes the first and last BAND_HALO = 10 pixel rows of its band (the fused one-pass loss reads 5 rows for the SSIM
-            window of a pixel and 5 more for the windows its gradient sums over), one all_gather of 2 x 4 x 10 x W floats per rank
-            (0.38 MB at W = 1200 instead of 13.7 MB), and every rank copies its two neighbours' rows next to its band.  Pixels outside
+            window of a pixel and 5 more for the windows its gradient sums over) and exchanges them with its TWO NEIGHBOURS only (one
+            all_to_all_single with zero-length splits for everybody else: 2 x 4 x 10 x W floats = 0.38 MB sent and received per rank at W = 1200
+            whatever N is, instead of 13.7 MB), and copies the neighbours' rows next to its band.  Pixels outside
             band + halo stay undefined and are never read.  `balanced_bands()` places the boundaries from per-row duplicate counts.
   backward: ALL-REDUCE(sum) of the per-Gaussian gradients of the VISIBLE Gaussians only — radii are replicated (every rank
             preprocesses all Gaussians), so every rank compacts the same rows (radii > 0: ~26 % of the map on the benchmark view) in
@@ -155,35 +156,70 @@ def band_halo_chunk(color, depth, bounds, rank):
     return torch.stack([img[:, y0:y0 + BAND_HALO, :], img[:, y1 - BAND_HALO:y1, :]]).contiguous()
 
 
-def band_apply_halos(color, depth, gathered, bounds, rank):
-    """Write the neighbours' rows into this rank's image: `gathered` (world, 2, 4, BAND_HALO, W) holds every rank's chunk; rank r takes the LAST rows of
-    band r - 1 (they lie just above its band) and the FIRST rows of band r + 1.  Returns new (color, depth); every pixel of the band and of its halo is
+def band_apply_halos(color, depth, from_above, from_below, bounds, rank):
+    """Write the neighbours' rows into this rank's image: `from_above` (4, BAND_HALO, W) = the LAST rows of band rank - 1 (they lie just above this band; None
+    for rank 0), `from_below` = the FIRST rows of band rank + 1 (None for the last rank).  Returns new (color, depth); every pixel of the band and of its halo is
     then what the single-GPU rasteriser produces, bit for bit (each was rendered by exactly one rank)."""
     H = color.shape[-2]
     y0, y1 = 32 * bounds[rank], min(H, 32 * bounds[rank + 1])
     color, depth = color.clone(), depth.clone()
-    if rank > 0:
-        color[:, y0 - BAND_HALO:y0, :] = gathered[rank - 1, 1, 0:3]
-        depth[:, y0 - BAND_HALO:y0, :] = gathered[rank - 1, 1, 3:4]
-    if rank + 1 < gathered.shape[0] and y1 < H:
+    if from_above is not None:
+        color[:, y0 - BAND_HALO:y0, :] = from_above[0:3]
+        depth[:, y0 - BAND_HALO:y0, :] = from_above[3:4]
+    if from_below is not None and y1 < H:
         n = min(BAND_HALO, H - y1)
-        color[:, y1:y1 + n, :] = gathered[rank + 1, 0, 0:3, :n]
-        depth[:, y1:y1 + n, :] = gathered[rank + 1, 0, 3:4, :n]
+        color[:, y1:y1 + n, :] = from_below[0:3, :n]
+        depth[:, y1:y1 + n, :] = from_below[3:4, :n]
     return color, depth
 
 
+def exchange_band_halos(mine, rank, world, group):
+    """The halo exchange proper: rank r sends the FIRST rows of its band to rank r - 1 and the LAST rows to rank r + 1 and receives their counterparts — ONE
+    all_to_all_single whose split sizes are zero for every rank that is not a neighbour (RCCL: a grouped send / recv pair per neighbour, nothing else on the
+    wire; static sizes: capturable in the hipGraph).  Bytes RECEIVED per rank: 2 chunks (1 at the image's top and bottom) whatever the world size — round 5's
+    all_gather received `world` x 2 chunks for the same result.  `mine`: (2, 4, BAND_HALO, W) from band_halo_chunk.  Returns
+    (from_above, from_below, bytes_received)."""
+    n = mine[0].numel()
+    send_split = [0] * world
+    recv_split = [0] * world
+    parts = []
+    if rank > 0:
+        send_split[rank - 1] = n
+        recv_split[rank - 1] = n
+        parts.append(mine[0].reshape(-1))        # my first rows lie just below band r - 1
+    if rank + 1 < world:
+        send_split[rank + 1] = n
+        recv_split[rank + 1] = n
+        parts.append(mine[1].reshape(-1))        # my last rows lie just above band r + 1
+    send = torch.cat(parts) if parts else mine.new_empty(0)
+    recv = torch.empty(sum(recv_split), dtype=mine.dtype, device=mine.device)
+    try:
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_split, input_split_sizes=send_split, group=group)
+    except RuntimeError:
+        if not mine.is_cuda or dist.get_backend(group) == "nccl":
+            raise
+        # a CPU backend rehearsing the N > 1 path with device tensors (gloo on a 1-GPU box) and no device all-to-all: staged through the host
+        recv_h = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(recv_h, send.cpu(), output_split_sizes=recv_split, input_split_sizes=send_split, group=group)
+        recv.copy_(recv_h)
+    above = recv[:n].view(mine[0].shape) if rank > 0 else None
+    below = recv[(n if rank > 0 else 0):][:n].view(mine[0].shape) if rank + 1 < world else None
+    return above, below, recv.numel() * recv.element_size()
+
+
 class _ExchangeHalos(torch.autograd.Function):
-    """Band mode: ONE all-gather of every rank's 2 x BAND_HALO boundary rows (2 x 10 x W x 4 floats = 0.38 MB per rank at W = 1200, against the 13.7 MB
-    image of the round-robin mode), torch slicing around it (the same code on CPU and GPU; all sizes static: capturable).  Backward: identity —
-    every rank's loss kernel produces the full gradient of its own pixels, and the rasteriser backward consumes only those."""
+    """Band mode: every rank exchanges its 2 x BAND_HALO boundary rows with its TWO NEIGHBOURS only (`exchange_band_halos`: 2 x 10 x W x 4 floats = 0.38 MB
+    sent and received per rank at W = 1200 whatever the world size, against the 13.7 MB image of the round-robin mode), torch slicing around it (the same
+    code on CPU and GPU; all sizes static: capturable).  Backward: identity — every rank's loss kernel produces the full gradient of its own pixels, and the
+    rasteriser backward consumes only those."""
 
     @staticmethod
     def forward(ctx, depth, color, group, holder, rank, world, bounds):
         mine = band_halo_chunk(color, depth, bounds, rank)
-        gathered = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-        _all_gather_flat(gathered.view(world, -1), mine.view(-1), group)
+        above, below, received = exchange_band_halos(mine, rank, world, group)
         holder.last_image_bytes = mine.numel() * mine.element_size()
-        c, d = band_apply_halos(color, depth, gathered, bounds, rank)
+        holder.last_halo_bytes_received = received
+        c, d = band_apply_halos(color, depth, above, below, bounds, rank)
         return d, c
 
     @staticmethod
@@ -364,6 +400,7 @@ class _Holder:
     radii = None
     last_volume_bytes = 0
     last_image_bytes = 0
+    last_halo_bytes_received = 0     # band mode: bytes this rank RECEIVED in the halo exchange (2 neighbours' rows; 1 at the image's top / bottom)
     table = None
     vis_capacity = 0
     guard = None          # (int32[1] device tensor: this rank's duplicate count, its capacity) or None

@@ -288,11 +288,13 @@ def test_band_sharding_with_halo_exchange_on_emulated_ranks(hip_lib, world, W, H
     assert torch.stack([b["own"] for b in bands]).sum(0).eq(1).all()
     chunks = [band_halo_chunk(b["color"], b["depth"], bounds, r) for r, b in enumerate(bands)]
     assert all(ch.numel() * 4 == 2 * 4 * BAND_HALO * W * 4 for ch in chunks)
-    gathered = torch.stack(chunks)                                                                # what all_gather_into_tensor delivers
+    # what the neighbour exchange (sharded.exchange_band_halos) delivers to rank r: the LAST rows of band r - 1 and the FIRST rows of band r + 1
+    above = [chunks[r - 1][1] if r > 0 else None for r in range(len(chunks))]
+    below = [chunks[r + 1][0] if r + 1 < len(chunks) else None for r in range(len(chunks))]
     part_sum = torch.zeros(4, device="cuda")
     grad_sum = {k: torch.zeros_like(v) for k, v in full["grads"].items()}
     for r, b in enumerate(bands):
-        out = run(rs._replace(tile_mod=b["code"][0], tile_rem=b["code"][1]), halos=lambda c, d, r=r: band_apply_halos(c.contiguous(), d.contiguous(), gathered, bounds, r),
+        out = run(rs._replace(tile_mod=b["code"][0], tile_rem=b["code"][1]), halos=lambda c, d, r=r: band_apply_halos(c.contiguous(), d.contiguous(), above[r], below[r], bounds, r),
                   shard=b["code"])
         y0, y1 = 32 * bounds[r], min(H, 32 * bounds[r + 1])
         lo, hi = max(0, y0 - BAND_HALO), min(H, y1 + BAND_HALO)
