@@ -447,8 +447,9 @@ def _trained_poses(hip_lib):
             longest.append(int((s["ranges"][:, 1].astype(np.int64) - s["ranges"][:, 0]).max()))
         n = len(t["poses"])
         pick = []
-        for k in (0, n // 2, n - 1, int(np.argmax(longest))):
-            if k not in pick:
+        # first, middle, last, then the keyframes with the longest tile lists (longest first) until four DISTINCT views are picked
+        for k in [0, n // 2, n - 1] + [int(j) for j in np.argsort(-np.asarray(longest), kind="stable")]:
+            if k not in pick and len(pick) < 4:
                 pick.append(k)
         t["pick"], t["longest"] = pick, longest
     return t["pick"]
@@ -467,7 +468,7 @@ def test_trained_map_forward_and_backward(hip_lib, which):
     t = _trained_map()
     pick = _trained_poses(hip_lib)
     if which >= len(pick):
-        pytest.skip("the longest-list keyframe is one of the other three")
+        pytest.skip("the trained map holds fewer than four keyframe poses")
     k = pick[which]
     cfg = synth.REPLICA
     cam = synth.make_camera(cfg["W"], cfg["H"], cfg["fx"], cfg["fy"], t["poses"][k])
