@@ -56,6 +56,8 @@ SIGNATURES = {
     "gsicp_mapper_select_view": (c_int, [c_void_p] * 10),
     "gsicp_mapper_loss_indirect": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
+    "gsicp_mapper_loss_indirect_bump": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_void_p, c_void_p]),
     "gsicp_mapper_activations_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_activations_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_void_p, c_void_p, c_void_p]),
@@ -67,6 +69,8 @@ SIGNATURES = {
                                         c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_adam_step_masked": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                        c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsicp_adam_step_sparse": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
+                                       c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_gicp_create": (c_void_p, []),
     "gsicp_gicp_destroy": (None, [c_void_p]),
     "gsicp_gicp_set_max_correspondence_distance": (c_int, [c_void_p, c_double]),
@@ -133,7 +137,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.gsicp_abi_version() != 4:
+        if lib.gsicp_abi_version() != 5:
             raise ImportError("libgsicp_hip.so ABI version mismatch")
         if os.environ.get("GSICP_ANNOUNCE"):   # tools/run_reference_slam.py: show which processes of the reference run loaded the library
             print(f"GSICP_LOADED {LIB_PATH} pid={os.getpid()}", flush=True)

@@ -223,7 +223,13 @@ __global__ __launch_bounds__(256) void loss_pass1_kernel(const float* __restrict
 // one-workgroup kernel below (loss value only) or by ONE workgroup of pass 2 (value + gradients: the reduction then costs no launch of its
 // own — 4.6 us of a 0.36 ms iteration) — same thread count and order, so both give the same bits.
 struct LossReduceArgs { const float2* partial; int n_tiles; float inv_n_img, inv_n_depth, lambda_dssim, depth_weight; float* out;
-                        float lambda_const; };   // the loss's constant term lambda * 1: lambda on one GPU; lambda / N per rank when N ranks each sum their own blocks
+                        float lambda_const;      // the loss's constant term lambda * 1: lambda on one GPU; lambda / N per rank when N ranks each sum their own blocks
+                        // STEP BUMP (round 6; gsicp_mapper_loss_indirect_bump): the optimiser's device step counter is advanced HERE, by the one thread
+                        // that finishes the loss value — after the forward (whose duplicate count is the overflow guard) and before the Adam launch
+                        // of the same captured iteration, which then reads the already advanced count (torch's own order: step += 1, then the update)
+                        // and needs no one-thread bump kernel behind it (4.1 us of launch floor per iteration).  Under a tripped guard the step is
+                        // void: the skipped-steps counter advances instead.
+                        int* bump_step; const unsigned* bump_guard; unsigned bump_limit; unsigned* bump_skipped; };
 __device__ inline void loss_reduce_body(const LossReduceArgs& q, const int tid) {
     __shared__ double s_acc[3][4];
     const int lane = tid & 63, wave = tid >> 6;
@@ -254,6 +260,10 @@ __device__ inline void loss_reduce_body(const LossReduceArgs& q, const int tid) 
         q.out[0] = q.lambda_const == q.lambda_dssim ? (1.f - q.lambda_dssim) * L1 + q.lambda_dssim * (1.f - SS) + q.depth_weight * LD
                                                     : ((1.f - q.lambda_dssim) * L1 + (q.lambda_const - q.lambda_dssim * SS)) + q.depth_weight * LD;
         q.out[1] = L1; q.out[2] = SS; q.out[3] = LD;
+        if (q.bump_step) {
+            if (q.bump_guard && *q.bump_guard > q.bump_limit) { if (q.bump_skipped) *q.bump_skipped += 1u; }
+            else *q.bump_step += 1;
+        }
     }
 }
 __global__ __launch_bounds__(256) void loss_reduce_kernel(LossReduceArgs q) { loss_reduce_body(q, (int)threadIdx.x); }
@@ -667,6 +677,7 @@ struct AdamTable {
     int src[ADAM_MAX_GROUPS];          // index of the group in the caller's arrays (empty tensors are squeezed out)
     int row_width[ADAM_MAX_GROUPS];    // elements per map row (live-row mode), 0 = whole tensor
     int frozen[ADAM_MAX_GROUPS];       // 1: rows with row_freeze[row] != 0 of this tensor are left alone (parameter and both moments)
+    int step_offset;                   // capturable path: the update uses step = *step_dev + step_offset (1: the bump follows; 0: it has already happened)
     int n;
 };
 
@@ -692,12 +703,12 @@ __device__ inline AdamPMV adam_update(float p, float m, float v, float g, float 
 template <bool CAPTURABLE>
 __device__ __forceinline__ void adam_tensor_body(const AdamTable& t, const double* __restrict__ lr_dev, const int* step_dev, float beta1, float beta2,
                                                  float eps, float inv_bc2_sqrt_host, const int* __restrict__ live_rows, double* s_bc1_p,
-                                                 float* s_inv_bc2_sqrt_p, const int* __restrict__ row_freeze) {
+                                                 float* s_inv_bc2_sqrt_p, const int* __restrict__ row_freeze, const int* __restrict__ grad_rows) {
     double& s_bc1 = *s_bc1_p;
     float& s_inv_bc2_sqrt = *s_inv_bc2_sqrt_p;
     if (CAPTURABLE) {
         if (threadIdx.x == 0) {   // two double pow() per BLOCK, not per thread
-            const int step = *step_dev + 1;
+            const int step = *step_dev + t.step_offset;
             s_bc1 = 1.0 - pow((double)beta1, (double)step);
             s_inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
         }
@@ -723,6 +734,49 @@ __device__ __forceinline__ void adam_tensor_body(const AdamTable& t, const doubl
     // ROW FREEZE (round 5; refglue's default policy): a tensor flagged in t.frozen skips the rows whose row_freeze word is non-zero — parameter
     // and both moments stay as they are, exactly as if the row were no parameter at all.
     const unsigned rw = (row_freeze && t.frozen[gidx] && t.row_width[gidx] > 0) ? (unsigned)t.row_width[gidx] : 0u;
+    // SPARSE GRADIENTS (round 6): `grad_rows` = the forward's radii.  A row with grad_rows[row] <= 0 is a culled Gaussian: its gradient is ZERO by
+    // definition and was not written by the backward (PreprocessBwdArgs.sparse_grads) — it is not read here either; the update is torch.optim.Adam's on
+    // g = 0 (the moments decay, the parameter follows its momentum), the same arithmetic the zero-filled rows took.
+    const unsigned gw = (grad_rows && t.row_width[gidx] > 0) ? (unsigned)t.row_width[gidx] : 0u;
+    if (gw) {
+        // rows of the four elements of a 16-byte unit: gw = 4 -> row i; gw = 1 -> rows 4i .. 4i + 3; gw = 3 -> (4i + k) / 3 by a multiply-high
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+            const unsigned e = 4u * (unsigned)i;
+            unsigned r0, r1, r2, r3;
+            if (gw == 4u) { r0 = r1 = r2 = r3 = (unsigned)i; }
+            else if (gw == 1u) { r0 = e; r1 = e + 1u; r2 = e + 2u; r3 = e + 3u; }
+            else if (gw == 3u) { r0 = __umulhi(e, 0xAAAAAAABu) >> 1; r1 = __umulhi(e + 1u, 0xAAAAAAABu) >> 1; r2 = __umulhi(e + 2u, 0xAAAAAAABu) >> 1; r3 = __umulhi(e + 3u, 0xAAAAAAABu) >> 1; }
+            else { r0 = e / gw; r1 = (e + 1u) / gw; r2 = (e + 2u) / gw; r3 = (e + 3u) / gw; }
+            const bool l0 = grad_rows[r0] > 0, l3 = grad_rows[r3] > 0;
+            const bool l1 = r1 == r0 ? l0 : (r1 == r3 ? l3 : grad_rows[r1] > 0), l2 = r2 == r3 ? l3 : (r2 == r0 ? l0 : grad_rows[r2] > 0);
+            float4 p = ((float4*)P)[i], m = ((float4*)M)[i], v = ((float4*)V)[i];
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l0 | l1 | l2 | l3) {
+                const float4 gl = ((const float4*)G)[i];
+                g = make_float4(l0 ? gl.x : 0.f, l1 ? gl.y : 0.f, l2 ? gl.z : 0.f, l3 ? gl.w : 0.f);
+            }
+            AdamPMV a0 = adam_update(p.x, m.x, v.x, g.x, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+            AdamPMV a1 = adam_update(p.y, m.y, v.y, g.y, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+            AdamPMV a2 = adam_update(p.z, m.z, v.z, g.z, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+            AdamPMV a3 = adam_update(p.w, m.w, v.w, g.w, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+            if (rw) {
+                if (row_freeze[r0] != 0) { a0.p = p.x; a0.m = m.x; a0.v = v.x; }
+                if (row_freeze[r1] != 0) { a1.p = p.y; a1.m = m.y; a1.v = v.y; }
+                if (row_freeze[r2] != 0) { a2.p = p.z; a2.m = m.z; a2.v = v.z; }
+                if (row_freeze[r3] != 0) { a3.p = p.w; a3.m = m.w; a3.v = v.w; }
+            }
+            ((float4*)M)[i] = make_float4(a0.m, a1.m, a2.m, a3.m);
+            ((float4*)V)[i] = make_float4(a0.v, a1.v, a2.v, a3.v);
+            ((float4*)P)[i] = make_float4(a0.p, a1.p, a2.p, a3.p);
+        }
+        for (long long j = 4 * nvec + (long long)blockIdx.x * 256 + threadIdx.x; j < numel; j += stride) {
+            const unsigned row = (unsigned)j / gw;
+            if (rw && row_freeze[row] != 0) continue;
+            const AdamPMV a0 = adam_update(P[j], M[j], V[j], grad_rows[row] > 0 ? G[j] : 0.f, beta1, beta2, eps, inv_bc2_sqrt, step_size);
+            M[j] = a0.m; V[j] = a0.v; P[j] = a0.p;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
         float4 p = ((float4*)P)[i], m = ((float4*)M)[i], v = ((float4*)V)[i];
         const float4 g = ((const float4*)G)[i];
@@ -756,11 +810,11 @@ __global__ __launch_bounds__(256) void adam_tensor_kernel(AdamTable t, const dou
                                                           float beta1, float beta2, float eps, float inv_bc2_sqrt_host,
                                                           const unsigned* __restrict__ guard_count, unsigned guard_limit,
                                                           const int* __restrict__ live_rows, int* step_rw, unsigned* done, unsigned* skipped_dev,
-                                                          const int* __restrict__ row_freeze) {
+                                                          const int* __restrict__ row_freeze, const int* __restrict__ grad_rows) {
     __shared__ double s_bc1;
     __shared__ float s_inv_bc2_sqrt;
     const bool skip = CAPTURABLE && guard_count && *guard_count > guard_limit;   // grid-uniform (one scalar load)
-    if (!skip) adam_tensor_body<CAPTURABLE>(t, lr_dev, step_dev, beta1, beta2, eps, inv_bc2_sqrt_host, live_rows, &s_bc1, &s_inv_bc2_sqrt, row_freeze);
+    if (!skip) adam_tensor_body<CAPTURABLE>(t, lr_dev, step_dev, beta1, beta2, eps, inv_bc2_sqrt_host, live_rows, &s_bc1, &s_inv_bc2_sqrt, row_freeze, grad_rows);
     if (CAPTURABLE && done) {
         __syncthreads();
         if (threadIdx.x == 0) {      // no fence: only the counter and the step word are shared, and a workgroup reads the step word before it counts itself in
@@ -941,7 +995,8 @@ size_t gsicp_mapper_loss_scratch_bytes(int width, int height) {
 
 static int mapper_loss_impl(const float* image, const float* depth, const float* gt_image, const float* gt_depth, int width, int height,
                             float lambda_dssim, float depth_weight, float d_max, float* loss_out, float* dL_dimage, float* dL_ddepth,
-                            char* scratch, int tile_mod, int tile_rem, void* stream_v, const float* const* gt_slots = nullptr) {
+                            char* scratch, int tile_mod, int tile_rem, void* stream_v, const float* const* gt_slots = nullptr,
+                            int* bump_step = nullptr, const unsigned* bump_guard = nullptr, unsigned bump_limit = 0u, unsigned* bump_skipped = nullptr) {
     hipStream_t stream = (hipStream_t)stream_v;
     if (tile_mod < 1 || tile_rem < 0 || tile_rem >= tile_mod) { g_last_error = "gsicp_mapper_loss_sharded: bad tile_mod / tile_rem"; return -2; }
     if (width <= 0 || height <= 0 || !image || !depth || (!gt_slots && (!gt_image || !gt_depth)) || !loss_out || !scratch) {
@@ -969,7 +1024,8 @@ static int mapper_loss_impl(const float* image, const float* depth, const float*
     float* abc = (float*)scratch;
     float* partial = (float*)(scratch + align_up(9 * HW * sizeof(float)));
     const float n_img = 3.f * (float)HW;
-    const LossReduceArgs red{(const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim, depth_weight, loss_out, lambda_dssim};
+    const LossReduceArgs red{(const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim, depth_weight, loss_out, lambda_dssim,
+                             bump_step, bump_guard, bump_limit, bump_skipped};
     const bool with_grads = dL_dimage && dL_ddepth;
     if (tile_mod > 1) {
         // Multi-GPU (tile_mod ranks): THIS rank's 32x32 blocks only, in ONE kernel — the fused form needs no derivative maps of blocks other
@@ -977,7 +1033,7 @@ static int mapper_loss_impl(const float* image, const float* depth, const float*
         // 70 us / N against 33 + 33 us replicated (on one GPU the two passes are faster: csrc/experiments/README.md).  loss_out receives this
         // rank's SHARE {loss, L1, SSIM mean, depth L1}: the sum over the ranks is the loss (the constant lambda is split N ways).
         const LossReduceArgs red_n{(const float2*)partial, n_tiles, 1.f / n_img, 1.f / (float)HW, lambda_dssim, depth_weight, loss_out,
-                                   lambda_dssim / (float)tile_world(tile_mod, tile_rem)};
+                                   lambda_dssim / (float)tile_world(tile_mod, tile_rem), bump_step, bump_guard, bump_limit, bump_skipped};
         { ProfileScope ps(ST_LOSS_PASS1, stream);
           hipLaunchKernelGGL(loss_fused_kernel, grid, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                              -lambda_dssim / n_img, (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), dL_dimage, dL_ddepth, partial,
@@ -1019,6 +1075,15 @@ int gsicp_mapper_loss_indirect(const float* image, const float* depth, const flo
     if (!gt_slots) { g_last_error = "gsicp_mapper_loss_indirect: gt_slots is NULL"; return -2; }
     return mapper_loss_impl(image, depth, nullptr, nullptr, width, height, lambda_dssim, depth_weight, d_max, loss_out, dL_dimage, dL_ddepth, scratch,
                             tile_mod < 1 ? 1 : tile_mod, tile_rem, stream, gt_slots);
+}
+
+int gsicp_mapper_loss_indirect_bump(const float* image, const float* depth, const float* const* gt_slots, int width, int height, float lambda_dssim,
+                                    float depth_weight, float d_max, int tile_mod, int tile_rem, float* loss_out, float* dL_dimage, float* dL_ddepth,
+                                    char* scratch, int* step_dev, const unsigned int* guard_count, unsigned int guard_limit, unsigned int* skipped_dev,
+                                    void* stream) {
+    if (!gt_slots || !step_dev) { g_last_error = "gsicp_mapper_loss_indirect_bump: gt_slots / step_dev is NULL"; return -2; }
+    return mapper_loss_impl(image, depth, nullptr, nullptr, width, height, lambda_dssim, depth_weight, d_max, loss_out, dL_dimage, dL_ddepth, scratch,
+                            tile_mod < 1 ? 1 : tile_mod, tile_rem, stream, gt_slots, step_dev, guard_count, guard_limit, skipped_dev);
 }
 
 size_t gsicp_store_compact_scratch_bytes(int n) { return ((size_t)(n > 0 ? (n + 255) / 256 : 1) + 1) * sizeof(unsigned); }
@@ -1197,6 +1262,7 @@ static long long adam_table(AdamTable& t, int n_groups, float* const* params, co
                             float* const* exp_avg_sq, const long long* numel, const float* lr, double bc1) {
     long long total = 0;
     t.n = 0;
+    t.step_offset = 1;
     for (int k = 0; k < n_groups; ++k) {
         if (numel[k] <= 0) continue;
         t.p[t.n] = params[k]; t.g[t.n] = grads[k]; t.m[t.n] = exp_avg[k]; t.v[t.n] = exp_avg_sq[k];
@@ -1234,7 +1300,7 @@ int gsicp_adam_step(int n_groups, float* const* params, const float* const* grad
     if (total == 0) return 0;
     hipLaunchKernelGGL(adam_tensor_kernel<false>, adam_grid(t), dim3(256), 0, stream, t, (const double*)nullptr, (const int*)nullptr, beta1, beta2, eps,
                        (float)(1.0 / std::sqrt(bc2)), (const unsigned*)nullptr, 0u, (const int*)nullptr, (int*)nullptr, (unsigned*)nullptr,
-                       (unsigned*)nullptr, (const int*)nullptr);
+                       (unsigned*)nullptr, (const int*)nullptr, (const int*)nullptr);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_adam_step: kernel launch failed"; return -1; }
     return 0;
 }
@@ -1252,15 +1318,29 @@ int gsicp_adam_step_masked(int n_groups, float* const* params, const float* cons
                            float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
                            unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, const int* row_freeze_dev,
                            const int* group_frozen, void* stream_v) {
+    return gsicp_adam_step_sparse(n_groups, params, grads, exp_avg, exp_avg_sq, numel, lr_dev, beta1, beta2, eps, step_dev, bump_step, guard_count,
+                                  guard_limit, skipped_dev, live_rows_dev, row_width, row_freeze_dev, group_frozen, nullptr, stream_v);
+}
+
+int gsicp_adam_step_sparse(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                           float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
+                           float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
+                           unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, const int* row_freeze_dev,
+                           const int* group_frozen, const int* grad_rows_dev, void* stream_v) {
     hipStream_t stream = (hipStream_t)stream_v;
+    if (grad_rows_dev && !row_width) { g_last_error = "gsicp_adam_step_sparse: grad_rows needs row_width"; return -2; }
+    if (bump_step < 0 || bump_step > 2) { g_last_error = "gsicp_adam_step_sparse: bump_step is 0 (none), 1 (bump after the update) or 2 (already bumped)"; return -2; }
     if (row_freeze_dev && (!row_width || !group_frozen)) { g_last_error = "gsicp_adam_step_masked: row_freeze needs row_width and group_frozen"; return -2; }
     if (n_groups < 0 || n_groups > ADAM_MAX_GROUPS || !lr_dev || !step_dev) {
         g_last_error = "gsicp_adam_step_capturable: 1..8 tensors, device lr array and device step counter"; return -2;
     }
     AdamTable t;
     const long long total = adam_table(t, n_groups, params, grads, exp_avg, exp_avg_sq, numel, nullptr, 1.0);
-    if ((live_rows_dev || row_freeze_dev) && row_width)
+    if ((live_rows_dev || row_freeze_dev || grad_rows_dev) && row_width)
         for (int k = 0; k < t.n; ++k) t.row_width[k] = row_width[t.src[k]];
+    // bump_step 2: the step counter was advanced BEFORE this launch, inside the same stream order (gsicp_mapper_loss_indirect_bump): use it as it is
+    t.step_offset = bump_step == 2 ? 0 : 1;
+    if (bump_step == 2) bump_step = 0;
     if (row_freeze_dev)
         for (int k = 0; k < t.n; ++k) t.frozen[k] = group_frozen[t.src[k]] ? 1 : 0;
     // the word the workgroups of the bumping launch count themselves into (see adam_tensor_kernel): one per (device, step counter), zeroed once.
@@ -1272,7 +1352,7 @@ int gsicp_adam_step_masked(int n_groups, float* const* params, const float* cons
         if (total > 0)
             hipLaunchKernelGGL(adam_tensor_kernel<true>, adam_grid(t), dim3(256), 0, stream, t, lr_dev, (const int*)step_dev, beta1, beta2, eps, 0.f,
                                guard_count, guard_limit, (live_rows_dev && row_width) ? live_rows_dev : (const int*)nullptr, step_dev, done, skipped_dev,
-                               row_freeze_dev);
+                               row_freeze_dev, grad_rows_dev);
         if (bump_step && !done)
             hipLaunchKernelGGL(adam_bump_step_kernel, dim3(1), dim3(1), 0, stream, step_dev, guard_count, guard_limit, skipped_dev);
     }

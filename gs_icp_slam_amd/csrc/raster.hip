@@ -987,7 +987,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     int num_rendered = 0;
     if (P > 0) {
         PreprocessArgs pa;
-        pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.live_rows = live_rows; pa.raw_params = raw_params;
+        pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.live_rows = live_rows; pa.raw_params = raw_params & 1;
         pa.means3D = means3D; pa.shs = shs; pa.colors_precomp = colors_precomp; pa.opacities = opacities; pa.scales = scales;
         pa.rotations = rotations; pa.cov3D_precomp = cov3D_precomp; pa.scale_modifier = scale_modifier;
         pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos; pa.tanfovx = tan_fovx; pa.tanfovy = tan_fovy;
@@ -1172,7 +1172,8 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     }
 
     PreprocessBwdArgs pb;
-    pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.live_rows = live_rows_dev; pb.raw_params = raw_params;
+    pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.live_rows = live_rows_dev; pb.raw_params = raw_params & 1;
+    pb.sparse_grads = (raw_params >> 1) & 1;
     pb.means3D = means3D; pb.shs = shs; pb.colors_precomp = colors_precomp; pb.scales = scales; pb.rotations = rotations;
     pb.cov3D_precomp = cov3D_precomp; pb.scale_modifier = scale_modifier; pb.view = viewmatrix; pb.proj = projmatrix;
     pb.campos = cam_pos; pb.tanfovx = tan_fovx; pb.tanfovy = tan_fovy; pb.radii = radii;

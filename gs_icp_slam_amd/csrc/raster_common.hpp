@@ -132,6 +132,8 @@ struct PreprocessBwdArgs {
     int P, D, M, W, H;
     const int* live_rows;      // DEVICE, optional (see PreprocessArgs)
     int raw_params;            // 1: scales / rotations are raw and dL_dopacity / dL_dscales / dL_drots are gradients w.r.t. the RAW parameters
+    int sparse_grads;          // 1 (round 6): the gradient rows of CULLED Gaussians (radii == 0, or behind the live count) are NOT written — their value is zero
+                               //    by definition and the consumer takes it from radii (FusedAdam's row mask); 0: every row of every output is written
     const float *means3D, *shs, *colors_precomp, *scales, *rotations, *cov3D_precomp;
     float scale_modifier;
     const float *view, *proj, *campos;

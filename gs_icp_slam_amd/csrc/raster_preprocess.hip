@@ -689,13 +689,14 @@ __global__ __launch_bounds__(256) void entry_run_sum_kernel(const uint32_t* __re
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void preprocess_backward_kernel(PreprocessBwdArgs a) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= a.P) return;
-    // capacity-backed map (live_rows): the rows behind the live count are no Gaussians — nothing reads their gradient rows (FusedAdam updates the live
-    // rows only), so they are not even zeroed: at a capacity of 2 M rows and 250 k live ones that is 120 MB of stores per iteration not made
-    if (a.live_rows != nullptr && t >= *a.live_rows) return;
+    // SPARSE gradients (a.sparse_grads, round 6: the captured mapper iteration, whose only consumer is FusedAdam with the forward's radii as its row
+    // mask): the rows of culled Gaussians and the rows behind the live count of a capacity-backed map are not written at all — on the S-map that is
+    // 26 MB of zero stores per launch (82 % of the Gaussians are culled) which the optimiser then read back; at a capacity of 2 M rows and 250 k live
+    // ones 120 MB.  Every other caller (autograd owns those tensors: torch.optim.Adam, grad hooks, dense all-reduces) gets every row written.
     SplatRec r0;
     r0.px = r0.py = r0.depth = r0.hx = r0.ca = r0.cb = r0.cc = r0.opacity = 0.f;
     r0.r = r0.g = r0.b = r0.hy = 0.f;
-    {   // Gaussian t, if it is not visible: its zeros (the algebra of an invisible Gaussian IS the zero fill)
+    if (!a.sparse_grads) {   // Gaussian t, if it is not visible: its zeros (the algebra of an invisible Gaussian IS the zero fill)
         const bool visible_t = a.radii[t] > 0 && (a.live_rows == nullptr || t < *a.live_rows);
         if (!visible_t) {
             float gs[NGRAD];

@@ -19,6 +19,7 @@ Several GPUs: pass `rasterizer_factory=lambda rs: ShardedGaussianRasterizer(rs, 
 have static sizes and are captured with everything else; the overflow guard then is the all-reduced flag, identical on every rank.
 """
 import ctypes
+import os
 import time
 
 import torch
@@ -47,7 +48,6 @@ def drain_process_group_watchdog(dev, seconds=None):
         return
     torch.cuda.synchronize(dev)
     if seconds is None:
-        import os
         seconds = float(os.environ.get("GSICP_CAPTURE_DRAIN_S", "0.5"))
     time.sleep(max(0.0, seconds))
     torch.cuda.synchronize(dev)
@@ -120,6 +120,17 @@ class MapperIterationGraph:
         # of the captured iteration changes, so ONE capture serves the whole run [REF mp_Mapper.py:161-195, 244-245 append / prune].
         self.live_count = live_count
         self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
+        # SPARSE gradients (round 6): this object owns every reader of the parameter gradients (the optimiser step inside the captured iteration), so the
+        # backward need not write — nor FusedAdam read — the zero rows of culled Gaussians: the rasteriser gets `sparse_grads`, the optimiser the forward's
+        # radii as its row mask.  Needs the in-kernel activations (raw parameters: no separate activation backward reading those rows) and a rasteriser
+        # whose own gradient handling touches visible rows only (plain; tile-sharded with the static exchange — NOT the dense keyframe-parallel
+        # all-reduce).  GSICP_SPARSE_GRADS=0 switches it off (A/B).  A grad_hook sees undefined values in culled rows: mask by `radii > 0`.
+        self._sparse = bool(fused and os.environ.get("GSICP_SPARSE_GRADS", "1") != "0"
+                            and (rasterizer_factory is None or getattr(self.rasterizer, "sparse_grads_ok", lambda: False)()))
+        if self._sparse:
+            rs = rs._replace(sparse_grads=True)
+            self._rs = rs
+            self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
         self._warmup = int(warmup)
         # device-side overflow guard: a replay whose duplicate count exceeds the capacity renders nothing; the Adam kernels
         # read the count and skip that step entirely (no stale-momentum drift, step count not advanced), counting it in a sticky counter
@@ -131,6 +142,10 @@ class MapperIterationGraph:
         shared_guard = self.rasterizer.overflow_guard() if hasattr(self.rasterizer, "overflow_guard") else None
         if shared_guard is not None:     # tile-sharded across GPUs (sharded.py, static exchange): 1 when ANY rank overflowed, so all ranks skip alike
             self._guard_count, self._guard_limit = shared_guard
+        # STEP BUMP inside the loss (round 6): the guard is this rank's duplicate count, final after the forward — the loss kernel's finishing thread
+        # advances the step counter and the Adam launch runs `step_already_bumped` (no one-thread bump launch: 4.1 us per iteration).  The shared guard
+        # of the multi-GPU exchange is only known after the backward: there the bump launch stays.  GSICP_STEP_BUMP_IN_LOSS=0 switches it off (A/B).
+        self._bump_in_loss = shared_guard is None and os.environ.get("GSICP_STEP_BUMP_IN_LOSS", "1") != "0"
         # The guard and the live-row count are bound to the optimiser only WHILE this graph's launches are issued (capture(), warm-up included)
         # and what was bound before is restored afterwards: an eager step() on the same optimiser later is gated by whatever ITS
         # caller bound (GaussianStore.attach binds the store's live count), not by the count the last replay happened to leave behind.
@@ -186,8 +201,13 @@ class MapperIterationGraph:
         # the loss kernels produce dL/dimage and dL/ddepth directly: no autograd node, no ones_like / multiply launches.  Tile-sharded over several
         # GPUs the loss is sharded with the tiles: this rank's 32x32 blocks only; its share of the four values travels inside the gradient exchange
         shard = self.rasterizer.loss_shard() if hasattr(self.rasterizer, "loss_shard") else (1, 0)
+        step_bump = None
+        if self._bump_in_loss:
+            step_t = self.optimizer.shared_step_tensor()      # None before the optimiser's first step (the first warm-up iteration): the bump launch then
+            if step_t is not None:
+                step_bump = (step_t, self._guard_count, self._guard_limit, self.optimizer.skipped_steps)
         parts, g_color, g_depth = mapper_loss_and_grads(color, depth, None, None, lambda_dssim=self.lambda_dssim, depth_weight=self.depth_weight,
-                                                        d_max=self.d_max, tile_mod=shard[0], tile_rem=shard[1], gt_slots=self.gt_slots)
+                                                        d_max=self.d_max, tile_mod=shard[0], tile_rem=shard[1], gt_slots=self.gt_slots, step_bump=step_bump)
         if shard[0] > 1:
             self.rasterizer.attach_loss_share(parts)
         torch.autograd.backward((color, depth), (g_color, g_depth))
@@ -197,7 +217,12 @@ class MapperIterationGraph:
         self._means2D.grad = None
         if self._grad_hook is not None:
             self._grad_hook(self.params)
-        self.optimizer.step()
+        if self._sparse:
+            self.optimizer.set_grad_row_mask(radii)      # culled rows: g = 0, not read (the backward did not write them)
+        try:
+            self.optimizer.step(step_already_bumped=step_bump is not None)
+        finally:
+            self.optimizer.set_grad_row_mask(None)       # an eager step() on this optimiser by somebody else reads every gradient element again
         self.optimizer.zero_grad(set_to_none=True)
         return parts, radii, used
 
@@ -306,7 +331,7 @@ class MapperIterationGraph:
         if not grow:
             return 0
         self.capacity = max(int(self.capacity * growth) + 1, int(1.25 * need) + 4096)
-        self._rs = self._rs._replace(capacity=self.capacity)
+        self._rs = self._rs._replace(capacity=self.capacity)   # (carries sparse_grads)
         dev = self.params["means3D"].device
         self.rasterizer = self._rasterizer_factory(self._rs) if self._rasterizer_factory is not None else GaussianRasterizer(self._rs)
         inner = self.rasterizer.inner if hasattr(self.rasterizer, "inner") else self.rasterizer

@@ -61,7 +61,8 @@ def mapper_loss_parts(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_
     return _MapperLoss.apply(image, depth, gt_image, gt_depth, lambda_dssim, depth_weight, d_max)
 
 
-def mapper_loss_and_grads(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_weight=0.1, d_max=10.0, tile_mod=1, tile_rem=0, gt_slots=None):
+def mapper_loss_and_grads(image, depth, gt_image, gt_depth, lambda_dssim=0.2, depth_weight=0.1, d_max=10.0, tile_mod=1, tile_rem=0, gt_slots=None,
+                          step_bump=None):
     """No-autograd form for callers that drive the backward themselves (gs_icp_slam_amd/graph.py):
     -> (tensor([loss, L1, SSIM mean, depth L1]), dL/dimage (3,H,W), dL/ddepth (1,H,W)), the gradients being those of `loss`
     itself, so no ones_like / multiply launches are needed before `torch.autograd.backward((image, depth), (g_image, g_depth))`.
@@ -69,7 +70,10 @@ def mapper_loss_and_grads(image, depth, gt_image, gt_depth, lambda_dssim=0.2, de
     (their sum over the ranks is the loss) and the gradients are defined on the rank's own blocks (zero elsewhere).
     gt_slots (int64[2] DEVICE tensor holding the addresses of the ground-truth image and depth, written by gsicp_mapper_select_view): the kernels
     read the two pointers on the device when they start (gsicp_mapper_loss_indirect) — a captured iteration then follows the keyframe selection
-    without any image being copied; gt_image / gt_depth are ignored (may be None)."""
+    without any image being copied; gt_image / gt_depth are ignored (may be None).
+    step_bump (with gt_slots; round 6): (step int32 device tensor, guard count tensor or None, guard limit, skipped-steps tensor or None) — the thread that
+    finishes the loss value also advances the optimiser's device step counter (or, under a tripped guard, the skipped counter): the Adam launch that
+    follows in the same stream order is then issued with `FusedAdam.step(step_already_bumped=True)` and no one-thread bump launch (gsicp_mapper_loss_indirect_bump)."""
     lib = _lib.load()
     if not image.is_cuda:
         raise RuntimeError("mapper_loss (gfx950): tensors must live on the HIP device; there is no CPU path")
@@ -91,7 +95,14 @@ def mapper_loss_and_grads(image, depth, gt_image, gt_depth, lambda_dssim=0.2, de
         g_img, g_dep = (torch.zeros_like(image_c), torch.zeros_like(depth_c)) if sharded else (torch.empty_like(image_c), torch.empty_like(depth_c))
         scratch = torch.empty(int(lib.gsicp_mapper_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        if gt_slots is not None:
+        if step_bump is not None:
+            if gt_slots is None:
+                raise RuntimeError("mapper_loss: step_bump needs gt_slots (the captured iteration's loss)")
+            step_t, guard_t, guard_lim, skipped_t = step_bump
+            _lib.check(lib.gsicp_mapper_loss_indirect_bump(_p(image_c), _p(depth_c), _p(gt_slots), W, H, float(lambda_dssim), float(depth_weight), float(d_max),
+                                                           int(tile_mod), int(tile_rem), _p(out), _p(g_img), _p(g_dep), _p(scratch), _p(step_t), _p(guard_t),
+                                                           int(guard_lim), _p(skipped_t), stream), "gsicp_mapper_loss_indirect_bump")
+        elif gt_slots is not None:
             _lib.check(lib.gsicp_mapper_loss_indirect(_p(image_c), _p(depth_c), _p(gt_slots), W, H, float(lambda_dssim), float(depth_weight), float(d_max),
                                                       int(tile_mod), int(tile_rem), _p(out), _p(g_img), _p(g_dep), _p(scratch), stream),
                        "gsicp_mapper_loss_indirect")

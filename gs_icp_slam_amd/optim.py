@@ -28,6 +28,29 @@ class FusedAdam(torch.optim.Optimizer):
         self.skipped_steps = None   # device int32[1], sticky: steps skipped by the guard since construction (read it whenever convenient)
         self._live_rows = None      # device int32[1]: parameters are capacity-backed, only this many leading rows are updated
         self._row_freeze = None     # (device int32[rows] mask, names of the param groups it applies to): rows with a non-zero word are left alone
+        self._grad_rows = None      # device int32[rows] (the rasteriser's radii): rows with a word <= 0 take g = 0 and their gradient is not read
+        self._prebumped = False     # the NEXT capturable step() finds its step counter already advanced (mapper_loss_and_grads(step_bump=...))
+
+    def set_grad_row_mask(self, radii):
+        """Capturable path, SPARSE gradients (round 6): `radii` = the int32 (P,) output of the rasteriser forward whose backward produced the gradients of
+        the next step().  Rows with radii <= 0 are culled Gaussians: their gradient is zero by definition, the backward (GaussianRasterizationSettings.
+        sparse_grads) did not write it and this step does not read it — the update is torch.optim.Adam's on g = 0.  Applies to every tensor with P rows;
+        `None` removes it (every gradient element is read again).  Read at every step, so call it with the forward's radii before each step()."""
+        if radii is not None and (not radii.is_cuda or radii.dtype != torch.int32 or not radii.is_contiguous()):
+            raise RuntimeError("FusedAdam.set_grad_row_mask: expected the contiguous int32 device tensor `radii` of the rasteriser forward")
+        self._grad_rows = radii
+
+    def shared_step_tensor(self):
+        """The ONE device step counter every parameter of this optimiser shares (capturable path, after the first step), or None when the parameters
+        do not all share one — what mapper_loss_and_grads(step_bump=...) advances ahead of a step(step_already_bumped=True)."""
+        steps = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p, {})
+                if not torch.is_tensor(st.get("step")):
+                    return None
+                steps[st["step"].data_ptr()] = st["step"]
+        return next(iter(steps.values())) if len(steps) == 1 else None
 
     def set_row_freeze(self, mask, group_names):
         """Capturable path: the param groups named in `group_names` (their "name" key, as GaussianModel sets it [REF scene/gaussian_model.py:222-229])
@@ -87,7 +110,7 @@ class FusedAdam(torch.optim.Optimizer):
                 entry[0].copy_(torch.tensor(new, dtype=torch.float64))
                 entry[1] = new
 
-    def _step_capturable(self, lib):
+    def _step_capturable(self, lib, prebumped=False):
         # bucket = tensors that share (betas, eps, step counter); identified by (param-group index, position) pairs, which stay valid when
         # a map store re-binds fresh Parameter objects into the same groups [REF scene/gaussian_model.py:409-492] (ids of dead objects
         # can be reused by CPython, group positions cannot)
@@ -147,7 +170,10 @@ class FusedAdam(torch.optim.Optimizer):
                 N = (ctypes.c_longlong * n)(*[t[0].numel() for t in items])
                 live_ptr, RW, freeze_ptr, FR = None, None, None, None
                 freeze = self._row_freeze if (self._row_freeze is not None and self._row_freeze[0].device == dev) else None
-                if (self._live_rows is not None and self._live_rows.device == dev) or freeze is not None:
+                rows = self._grad_rows if (self._grad_rows is not None and self._grad_rows.device == dev) else None
+                if rows is not None and any(t[0].dim() == 0 or t[0].shape[0] != rows.numel() for t in items):
+                    raise RuntimeError("FusedAdam.set_grad_row_mask: every parameter must have one row per entry of the mask")
+                if (self._live_rows is not None and self._live_rows.device == dev) or freeze is not None or rows is not None:
                     RW = (ctypes.c_int * n)(*[(t[0].numel() // t[0].shape[0]) if t[0].dim() > 0 and t[0].shape[0] > 0 else 0 for t in items])
                 if self._live_rows is not None and self._live_rows.device == dev:
                     live_ptr = ctypes.c_void_p(self._live_rows.data_ptr())
@@ -158,23 +184,29 @@ class FusedAdam(torch.optim.Optimizer):
                             raise RuntimeError("FusedAdam.set_row_freeze: the mask has fewer words than the tensor has rows")
                     if any(flags):
                         freeze_ptr, FR = ctypes.c_void_p(freeze[0].data_ptr()), (ctypes.c_int * n)(*flags)
-                _lib.check(lib.gsicp_adam_step_masked(n, P, G, M, V, N, ctypes.c_void_p(lr_dev.data_ptr()), b1, b2, eps,
-                                                      ctypes.c_void_p(items[0][5].data_ptr()), int(last_of[sp] == li), guard_ptr, guard_lim,
-                                                      skip_ptr, live_ptr, RW, freeze_ptr, FR, stream), "gsicp_adam_step_masked")
+                bump = 2 if prebumped else int(last_of[sp] == li)       # 2: the counter was advanced ahead of this launch, in stream order
+                _lib.check(lib.gsicp_adam_step_sparse(n, P, G, M, V, N, ctypes.c_void_p(lr_dev.data_ptr()), b1, b2, eps,
+                                                      ctypes.c_void_p(items[0][5].data_ptr()), bump, guard_ptr, guard_lim,
+                                                      skip_ptr, live_ptr, RW, freeze_ptr, FR, ctypes.c_void_p(rows.data_ptr()) if rows is not None else None,
+                                                      stream), "gsicp_adam_step_sparse")
         # Device lr arrays are NEVER freed: a captured MapperIterationGraph holds their addresses, and an eager step() that happens
         # to see fewer gradients (zero_grad(set_to_none=True), different chunking) must not hand that memory back to the caching allocator
         # while a graph may still replay.  One entry is <= 8 doubles; the number of distinct buckets an optimiser ever sees is a handful.
         del live_keys
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, step_already_bumped=False):
+        """step_already_bumped (capturable path): the device step counter was advanced ahead of this call, in stream order, by
+        mapper_loss_and_grads(step_bump=(self.shared_step_tensor(), ...)) — the update uses the counter as it is and no bump launch follows."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        if step_already_bumped and not self.capturable:
+            raise RuntimeError("FusedAdam.step(step_already_bumped=True) needs capturable=True (a device step counter)")
         if self.capturable:
-            self._step_capturable(lib)
+            self._step_capturable(lib, prebumped=bool(step_already_bumped))
             return loss
         buckets = {}   # (beta1, beta2, eps, step, device) -> list of (p, g, m, v, lr)
         for group in self.param_groups:

@@ -48,6 +48,10 @@ class GaussianRasterizationSettings(NamedTuple):
     # Extension: opacities / scales / rotations are GaussianModel's RAW parameters (_opacity, _scaling, _rotation); sigmoid / exp / normalize
     # [REF scene/gaussian_model.py:44-56] and their chain rule run inside the preprocess kernels.  Needs capacity > 0.
     raw_params: bool = False
+    # Extension (round 6): SPARSE gradients — the backward does not write the gradient rows of culled Gaussians (radii == 0, or behind live_count);
+    # they are zero by definition and the consumer takes that from `radii` (FusedAdam.set_grad_row_mask; gs_icp_slam_amd/graph.py sets both).  Only for
+    # callers that own every reader of the gradients: with the default (False) every row of every gradient is written, as the reference's backward does.
+    sparse_grads: bool = False
 
 
 def _ptr(t):
@@ -177,7 +181,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_ddepths), _ptr(dL_dmeans3D),
                 _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drots), int(rs.tile_mod), int(rs.tile_rem),
                 int(bool(rs.debug)), ctx.depth_mode, _ptr(depth_out.detach() if depth_out is not None else None),
-                _ptr(getattr(rs, "live_count", None)), int(bool(getattr(rs, "raw_params", False))), stream)
+                _ptr(getattr(rs, "live_count", None)), int(bool(getattr(rs, "raw_params", False))) | (2 if getattr(rs, "sparse_grads", False) else 0), stream)
             _lib.check(rc, "gsicp_raster_backward")
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors if col_c is not None else None, dL_dopacity, dL_dscales, dL_drots,
                 dL_dcov3D if cov_c is not None else None, None, None)

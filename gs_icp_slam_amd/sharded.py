@@ -451,6 +451,11 @@ class ShardedGaussianRasterizer(nn.Module):
     def collective(self):
         return self.world > 1 or self.force_collectives
 
+    def sparse_grads_ok(self):
+        """May the inner backward leave the gradient rows of culled Gaussians unwritten (GaussianRasterizationSettings.sparse_grads)?  Yes when nothing
+        here reads them: no collective at all, or the static exchange on the device (gsicp_rows_pack / _unpack move the rows with radii > 0 only)."""
+        return (not self.collective) or bool(self.holder.vis_capacity and self.raster_settings.viewmatrix.is_cuda)
+
     def loss_shard(self):
         """(tile_mod, tile_rem) for `mapper_loss_and_grads`: this rank computes the loss on the 32x32 blocks (= 2x2 super-tiles) it blends."""
         if self.bands is not None:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define GSICP_ABI_VERSION 4
+#define GSICP_ABI_VERSION 5
 
 int gsicp_abi_version(void);
 const char* gsicp_last_error(void);
@@ -89,6 +89,9 @@ int gsicp_raster_forward(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resi
  *   quaternion) and the activation getters [REF scene/gaussian_model.py:44-56, 105-125] — sigmoid, exp, x / max(||x||, 1e-12) — are applied
  *   inside the preprocess kernel; gsicp_raster_backward with the same flag then returns dL_dopacity / dL_dscales / dL_drots with respect
  *   to the raw parameters (two element-wise launches and 64 B per Gaussian of traffic less per iteration).
+ *   gsicp_raster_backward only (ABI 5): raw_params bit 1 (value 2) = SPARSE gradients — the rows of culled Gaussians (radii == 0, or behind the
+ *   live count) are NOT written to any dL_d* output; their value is zero by definition and the consumer masks by `radii`
+ *   (gsicp_adam_step_sparse).  Without the bit every row of every output is written (zeros for culled rows), as the reference's backward does.
  * Returns `capacity`; pass that value as `num_rendered` to gsicp_raster_backward_scratch_bytes / gsicp_raster_backward. */
 int gsicp_raster_forward_async(gsicp_resize_fn geom_alloc, void* geom_user, gsicp_resize_fn binning_alloc, void* binning_user,
                                gsicp_resize_fn img_alloc, void* img_user, int P, int D, int M, const float* background,
@@ -300,6 +303,16 @@ int gsicp_mapper_loss_indirect(const float* image, const float* depth, const flo
                                float depth_weight, float d_max, int tile_mod, int tile_rem, float* loss_out, float* dL_dimage, float* dL_ddepth,
                                char* scratch, void* stream);
 
+/* gsicp_mapper_loss_indirect that also ADVANCES the optimiser's device step counter (ABI 5): the one thread that finishes the loss value does
+ * `if (guard_count && *guard_count > guard_limit) ++*skipped_dev; else ++*step_dev;` — after the forward of the captured iteration (whose
+ * duplicate count is the guard) and before its Adam launch, which is then called with bump_step = 2 (gsicp_adam_step_sparse: "already bumped",
+ * torch's own order: step += 1, then the update [REF mp_Mapper.py:247 optimizer.step()]) and needs no one-thread bump launch behind it.
+ * guard_count / skipped_dev may be NULL. */
+int gsicp_mapper_loss_indirect_bump(const float* image, const float* depth, const float* const* gt_slots, int width, int height, float lambda_dssim,
+                                    float depth_weight, float d_max, int tile_mod, int tile_rem, float* loss_out, float* dL_dimage, float* dL_ddepth,
+                                    char* scratch, int* step_dev, const unsigned int* guard_count, unsigned int guard_limit, unsigned int* skipped_dev,
+                                    void* stream);
+
 /* GaussianModel's activation getters in one launch each way [REF scene/gaussian_model.py:44-56, 105-125], reached from
  * render_3 at [REF gaussian_renderer/__init__.py:263, 273-274]: opacity = sigmoid(opacity_raw) (P), scaling =
  * exp(scaling_raw) (P,3), rotation = rotation_raw / max(||rotation_raw||, 1e-12) (P,4).  All DEVICE float arrays. */
@@ -349,6 +362,18 @@ int gsicp_adam_step_masked(int n_groups, float* const* params, const float* cons
                            float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
                            unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, const int* row_freeze_dev,
                            const int* group_frozen, void* stream);
+
+/* gsicp_adam_step_masked with SPARSE GRADIENTS (ABI 5): when grad_rows_dev (DEVICE int[rows]; the rasteriser forward's `radii`) is non-NULL, a row
+ * with grad_rows_dev[row] <= 0 is a culled Gaussian — its gradient is zero by definition, is NOT read from `grads` (the backward called with
+ * raw_params bit 1 does not write it: 26 MB of zero stores and 17 MB of reads per iteration at 300 k Gaussians, 82 % culled) and the update is
+ * torch.optim.Adam's on g = 0 (moments decay, the parameter follows its momentum) — the arithmetic the zero-filled rows took (row_width is then
+ * required).  bump_step: 0 = leave *step_dev alone, 1 = apply step *step_dev + 1 and advance the counter afterwards, 2 = the counter has ALREADY
+ * been advanced in stream order (gsicp_mapper_loss_indirect_bump): apply step *step_dev, no bump. */
+int gsicp_adam_step_sparse(int n_groups, float* const* params, const float* const* grads, float* const* exp_avg,
+                           float* const* exp_avg_sq, const long long* numel, const double* lr_dev, float beta1, float beta2,
+                           float eps, int* step_dev, int bump_step, const unsigned int* guard_count, unsigned int guard_limit,
+                           unsigned int* skipped_dev, const int* live_rows_dev, const int* row_width, const int* row_freeze_dev,
+                           const int* group_frozen, const int* grad_rows_dev, void* stream);
 
 /* Map pruning without reallocation: GaussianModel.prune_points / _prune_optimizer
  * [REF scene/gaussian_model.py:409-447] apply one boolean mask to every parameter, both Adam moments and the per-Gaussian

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/gsicp_hip.h but not exported"
     assert set(_lib.SIGNATURES) == set(syms), set(_lib.SIGNATURES) ^ set(syms)
-    assert _lib.load().gsicp_abi_version() == 4
+    assert _lib.load().gsicp_abi_version() == 5
 
 
 def test_drop_in_packages_expose_reference_names():

@@ -459,3 +459,125 @@ def test_one_capture_survives_map_growth_and_pruning():
             continue
         torch.testing.assert_close(store.live(name), ref.params[name].detach(), rtol=1e-4, atol=1e-6, msg=lambda m, n=name: f"{n}: {m}")
         torch.testing.assert_close(store._sets[0][("m", name)][: store.n], ref.view("m", name), rtol=1e-3, atol=1e-9)
+
+
+def test_sparse_gradient_rows_and_prebumped_step_equal_the_zero_filled_step():
+    """Round 6.  (a) FusedAdam.set_grad_row_mask(radii): rows with radii <= 0 take g = 0 WITHOUT their gradient being read — the
+    gradient tensors here hold NaN in those rows — and every tensor ends bit for bit where the same optimiser ends on zero-filled gradients (xyz rows of 3
+    floats straddle the 16-byte units, opacity rows are single floats, quaternions whole units: all three row widths of the kernel).  (b) step(
+    step_already_bumped=True) after the counter was advanced ahead of it, in stream order, equals the step that bumps behind itself; a tripped guard
+    skips both alike."""
+    from gs_icp_slam_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    P = 4099
+    shapes = [(P, 3), (P, 1, 3), (P, 1), (P, 3), (P, 4)]
+    lrs = [4e-6, 2.5e-3, 0.05, 5e-3, 1e-3]
+    p_a = [torch.randn(s, device="cuda", requires_grad=True) for s in shapes]
+    p_b = [p.detach().clone().requires_grad_(True) for p in p_a]
+    oa = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(p_a, lrs)], lr=0.0, eps=1e-15, capturable=True)
+    ob = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(p_b, lrs)], lr=0.0, eps=1e-15, capturable=True)
+    guard = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for o in (oa, ob):
+        o.set_overflow_guard(guard, 10)
+    assert ob.shared_step_tensor() is None                      # no state before the first step
+    for it in range(7):
+        radii = (torch.rand(P, device="cuda") < (0.2 if it % 2 else 0.7)).to(torch.int32) * 5
+        if it == 3:
+            radii.zero_()                                       # nothing visible at all: no gradient element is read
+        vis = radii > 0
+        for pa, pb in zip(p_a, p_b):
+            gr = torch.randn_like(pa)
+            dense = gr.clone()
+            dense[~vis] = 0.0
+            sparse = gr.clone()
+            sparse[~vis] = float("nan")
+            pa.grad, pb.grad = dense, sparse
+        if it == 5:
+            guard.fill_(11)                                     # tripped: both skip, neither counts the step
+        oa.step()
+        ob.set_grad_row_mask(radii)
+        st = ob.shared_step_tensor()
+        if st is None:                                          # first step: the counter does not exist yet
+            ob.step()
+        else:
+            if it != 5:
+                st += 1                                         # what the loss kernel's finishing thread does under an untripped guard
+            ob.step(step_already_bumped=True)
+        ob.set_grad_row_mask(None)
+        guard.zero_()
+    assert int(oa.state[p_a[0]]["step"].item()) == 6 and int(ob.state[p_b[0]]["step"].item()) == 6
+    assert int(oa.skipped_steps.item()) == 1
+    for pa, pb in zip(p_a, p_b):
+        assert torch.isfinite(pb).all()
+        assert torch.equal(pa, pb)
+        for name in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa.state[pa][name], ob.state[pb][name]), name
+    with pytest.raises(RuntimeError):
+        FusedAdam([p_a[0]], lr=1e-3).step(step_already_bumped=True)
+    with pytest.raises(RuntimeError):
+        ob.set_grad_row_mask(torch.zeros(P, device="cuda"))     # not int32
+
+
+def test_sparse_backward_leaves_the_visible_rows_bit_identical():
+    """GaussianRasterizationSettings.sparse_grads: the backward skips the zero rows of culled Gaussians; every visible row of every gradient is the same
+    bits as without the flag (and without it every culled row is written with zeros, as the reference's backward does)."""
+    g, cam = _scene()
+    rs = make_settings(cam, [0.1, 0.2, 0.3])
+    raw = {"means3D": torch.from_numpy(g["means3D"]), "scales": torch.log(torch.from_numpy(g["scales"])), "rotations": torch.from_numpy(g["rotations"]),
+           "opacities": torch.logit(torch.from_numpy(g["opacities"]).clamp(1e-4, 1 - 1e-4)), "shs": torch.from_numpy(g["shs"])}
+    out = {}
+    for sparse in (False, True):
+        t = {k: v.cuda().contiguous().requires_grad_(True) for k, v in raw.items()}
+        d, c, radii, u, grads, rast = _render(rs._replace(capacity=2_000_000, raw_params=True, sparse_grads=sparse), t)
+        out[sparse] = (radii.clone(), grads)
+    vis = out[False][0] > 0
+    assert torch.equal(out[False][0], out[True][0]) and 0 < int(vis.sum()) < vis.numel()
+    for k, v in out[False][1].items():
+        assert torch.all(v[~vis] == 0), f"{k}: culled rows of the dense backward must be zero"
+        assert torch.equal(v[vis], out[True][1][k][vis]), f"{k}: visible rows differ under sparse_grads"
+
+
+def test_captured_iteration_is_bit_identical_with_and_without_sparse_gradients_and_the_bump_in_the_loss(monkeypatch):
+    """The captured mapper iteration of round 6 (sparse gradient rows, the step bump inside the loss kernel: 15 kernel nodes) against the same iteration with
+    both switched off (GSICP_SPARSE_GRADS=0, GSICP_STEP_BUMP_IN_LOSS=0: zero-filled gradients, the one-thread bump launch): identical parameters, moments,
+    step counts and losses after replays over two views, one of them with the guard tripped."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from gs_icp_slam_amd.graph import MapperIterationGraph
+    P, W, H = 20000, 320, 200
+    views = None
+    res = {}
+    for mode in ("new", "old"):
+        for k in ("GSICP_SPARSE_GRADS", "GSICP_STEP_BUMP_IN_LOSS"):
+            if mode == "old":
+                monkeypatch.setenv(k, "0")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        g, cam, params, opt = _mapper_setup(P, W, H, capturable=True)
+        if views is None:
+            views = []
+            for pose in (synth.DEFAULT_POSE_A, synth.se3((12.5, 27.0, 0.5), (-0.88, -0.22, -1.08))):
+                cam_k = synth.make_camera(W, H, cam["fx"], cam["fy"], pose)
+                rs_k = make_settings(cam_k, [0.0, 0.0, 0.0])
+                t2 = torch_inputs(synth.s_map(P, seed=5, perturb_seed=7))
+                with torch.no_grad():
+                    d, c, _, _ = GaussianRasterizer(rs_k)(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"],
+                                                          opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
+                views.append((rs_k, c.clone(), d.clone()))
+        mg = MapperIterationGraph(params, opt, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=2_000_000, warmup=2)
+        assert mg._sparse == (mode == "new") and mg._bump_in_loss == (mode == "new")
+        mg.set_view(views[0][0].viewmatrix, views[0][0].projmatrix, views[0][0].campos, views[0][1], views[0][2])
+        mg.capture()
+        losses = []
+        for k in (0, 1, 1, 0, 1):
+            rs_k, gt_c, gt_d = views[k]
+            mg.set_view(rs_k.viewmatrix, rs_k.projmatrix, rs_k.campos, gt_c, gt_d)
+            losses.append(float(mg.step()))
+        torch.cuda.synchronize()
+        res[mode] = (losses, {k: v.detach().clone() for k, v in params.items()},
+                     {k: (opt.state[v]["exp_avg"].clone(), opt.state[v]["exp_avg_sq"].clone()) for k, v in params.items()},
+                     int(opt.state[params["means3D"]]["step"].item()), mg.skipped_steps())
+        mg.release()
+    assert res["new"][0] == res["old"][0] and res["new"][3] == res["old"][3] == 5 and res["new"][4] == res["old"][4] == 0
+    for k in res["new"][1]:
+        assert torch.equal(res["new"][1][k], res["old"][1][k]), k
+        assert torch.equal(res["new"][2][k][0], res["old"][2][k][0]) and torch.equal(res["new"][2][k][1], res["old"][2][k][1]), k
