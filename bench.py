@@ -362,7 +362,7 @@ def compact_line(full, legs_path):
     line["metric"] = cut(line["metric"], 200)
     line["config"] = {"workload": cut(cfg.get("workload_short") or cfg.get("workload"), 300)}
     line["config"].update({k: cut(cfg.get(k), 200) for k in ("gaussians", "width", "height", "duplicates_per_rank", "visible_gaussians", "keyframe_views", "tracker_workload",
-                                                             "lm_iterations", "tracker_target_gaussians", "mapper_iteration", "mp_mode", "parallelism", "world_size", "backend")
+                                                             "lm_iterations", "tracker_target_gaussians", "mapper_iteration", "mp_mode", "parallelism", "world_size", "backend", "cu_split")
                            if cfg.get(k) is not None})
     if cfg.get("mp_bands"):
         line["config"]["mp_bands"] = cfg["mp_bands"].get("mode")
@@ -445,6 +445,9 @@ def main():
                     "letting the two halves run their --steps steps at their own pace inside the timed block")
     ap.add_argument("--no-graph", action="store_true", help="drive the mapper iteration eagerly from Python instead of replaying the captured HIP graph")
     ap.add_argument("--only", choices=["tracker", "mapper", "trained"], default=None, help="diagnostics: run only one half (the JSON line is then NOT the contract metric)")
+    ap.add_argument("--cu-split", type=int, default=0, help="EXPERIMENT (round 6): the tracker's stream on this many dedicated compute units "
+                    "(hipExtStreamCreateWithCUMask, mask bits 0..N-1: spread evenly over the 8 XCDs) and the mapper's stream on the remaining ones, instead of a "
+                    "high-priority tracker stream sharing all 256; 0 = off")
     ap.add_argument("--mp-bands", choices=["off", "equal", "balanced"], default="off",
                     help="N > 1, --mp-mode tiles: `off` = super-tiles dealt round-robin + all-gather of the image (rounds 3-4, the rehearsed default); `equal` / "
                          "`balanced` (round 5) = contiguous bands of 32-pixel rows per rank + a halo exchange of 2 x 10 rows (0.4 MB instead of 13.7 MB per rank); "
@@ -553,6 +556,15 @@ def main():
                           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": leg["ms_per_iteration"], "higher_is_better": True,
                           "dtype": "f32", "data": "synthetic", "legs": {"mapper_trained_map": leg}}))
         return 0
+    cu_split = None
+    if args.cu_split > 0:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        os.environ["GSICP_TRACKER_CU_MASK"] = f"0:{args.cu_split}"            # read by gsicp_gicp_create
+        h = _lib.load().gsicp_stream_create_cu_mask(args.cu_split, n_cu - args.cu_split)
+        if not h:
+            raise RuntimeError("--cu-split: " + _lib.last_error())
+        torch.cuda.set_stream(torch.cuda.ExternalStream(h, device=dev))         # the mapper half (this thread): every launch and graph replay from here on
+        cu_split = {"tracker_cus": args.cu_split, "mapper_cus": n_cu - args.cu_split, "device_cus": n_cu}
     cfg = synth.REPLICA if args.res == "replica" else synth.TUM
     W, H = cfg["W"], cfg["H"]
     P = args.gaussians
@@ -1488,7 +1500,7 @@ def main():
                        "tracker_mapper_overlap": worker is not None,
                        "step_coupling": ("free-running: K tracker frames and K mapper iterations run concurrently, each at its own pace; the block ends when both are done"
                                          if free_running else ("lockstep: both halves joined after every step" if worker is not None else "one half after the other")),
-                       "mapper_iterations_in_flight": args.mapper_inflight,
+                       "mapper_iterations_in_flight": args.mapper_inflight, "cu_split": cu_split,
                        "mapper_iteration": (("one hipGraph replay per iteration" + (" (tile all-gather + gradient all-reduce captured inside)" if (world > 1 or force_coll) else ""))
                                             if mg is not None else "eager launches from Python"),
                        "rccl_graph_probe": rccl_graph_probe,

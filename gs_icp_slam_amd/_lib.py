@@ -58,6 +58,7 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_loss_indirect_bump": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_void_p, c_void_p]),
+    "gsicp_mapper_loss_set_tile3": (c_int, [c_int]),
     "gsicp_mapper_activations_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_activations_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_void_p, c_void_p, c_void_p]),
@@ -71,6 +72,8 @@ SIGNATURES = {
                                        c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_adam_step_sparse": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float,
                                        c_void_p, c_int, c_void_p, ctypes.c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gsicp_stream_create_cu_mask": (c_void_p, [c_int, c_int]),
+    "gsicp_stream_destroy": (c_int, [c_void_p]),
     "gsicp_gicp_create": (c_void_p, []),
     "gsicp_gicp_destroy": (None, [c_void_p]),
     "gsicp_gicp_set_max_correspondence_distance": (c_int, [c_void_p, c_double]),

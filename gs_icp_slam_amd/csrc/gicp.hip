@@ -2587,6 +2587,28 @@ int fetch_floats(gsicp_gicp* g, const float* dev, int n_pts, int width, float* o
 
 extern "C" {
 
+void* gsicp_stream_create_cu_mask(int first_cu, int n_cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { g_last_error = "gsicp_stream_create_cu_mask: no HIP device"; return nullptr; }
+    const int total = prop.multiProcessorCount;
+    if (first_cu < 0 || n_cus <= 0 || first_cu + n_cus > total) { g_last_error = "gsicp_stream_create_cu_mask: mask bits outside the device's compute units"; return nullptr; }
+    std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+    for (int b = first_cu; b < first_cu + n_cus; ++b) mask[(size_t)b >> 5] |= 1u << (b & 31);
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        g_last_error = "hipExtStreamCreateWithCUMask failed";
+        return nullptr;
+    }
+    return (void*)s;
+}
+int gsicp_stream_destroy(void* stream) {
+    if (!stream) return 0;
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? 0 : -1;
+}
+
 gsicp_gicp* gsicp_gicp_create(void) {
     gsicp_gicp* g = new gsicp_gicp();
     // The tracker is the latency-critical half (one frame = a short dependent chain of small kernels); the mapper it shares the GPU
@@ -2595,7 +2617,16 @@ gsicp_gicp* gsicp_gicp_create(void) {
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     const char* pe = std::getenv("GSICP_TRACKER_PRIORITY");   // "0" = default priority (A/B switch for measurements)
     if (pe && pe[0] == '0') prio_hi = prio_lo = 0;
-    if (hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+    // GSICP_TRACKER_CU_MASK="first:count" (round 6 experiment, default off): the tracker's stream on `count` dedicated compute units starting at mask bit
+    // `first` (hipExtStreamCreateWithCUMask; on a multi-XCD part consecutive mask bits go round the XCDs, so a prefix is spread evenly over the eight) —
+    // its 33 workgroups then never queue behind mapper waves on those CUs when the mapper's stream carries the complement (gsicp_stream_create_cu_mask).
+    // A masked stream has no priority argument: the two are alternatives.
+    const char* cm = std::getenv("GSICP_TRACKER_CU_MASK");
+    int cu_first = 0, cu_count = 0;
+    if (cm && std::sscanf(cm, "%d:%d", &cu_first, &cu_count) == 2 && cu_count > 0) {
+        g->stream = (hipStream_t)gsicp_stream_create_cu_mask(cu_first, cu_count);
+        if (!g->stream) { delete g; return nullptr; }
+    } else if (hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
         g_last_error = "hipStreamCreate failed (no HIP device?)";
         delete g;
         return nullptr;

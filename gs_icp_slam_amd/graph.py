@@ -119,18 +119,20 @@ class MapperIterationGraph:
         # live_count[0] rows are Gaussians.  Growth and pruning then change that number and rows in place — no pointer, shape or launch grid
         # of the captured iteration changes, so ONE capture serves the whole run [REF mp_Mapper.py:161-195, 244-245 append / prune].
         self.live_count = live_count
-        self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
         # SPARSE gradients (round 6): this object owns every reader of the parameter gradients (the optimiser step inside the captured iteration), so the
         # backward need not write — nor FusedAdam read — the zero rows of culled Gaussians: the rasteriser gets `sparse_grads`, the optimiser the forward's
         # radii as its row mask.  Needs the in-kernel activations (raw parameters: no separate activation backward reading those rows) and a rasteriser
         # whose own gradient handling touches visible rows only (plain; tile-sharded with the static exchange — NOT the dense keyframe-parallel
         # all-reduce).  GSICP_SPARSE_GRADS=0 switches it off (A/B).  A grad_hook sees undefined values in culled rows: mask by `radii > 0`.
-        self._sparse = bool(fused and os.environ.get("GSICP_SPARSE_GRADS", "1") != "0"
-                            and (rasterizer_factory is None or getattr(self.rasterizer, "sparse_grads_ok", lambda: False)()))
+        self._sparse = bool(fused and os.environ.get("GSICP_SPARSE_GRADS", "1") != "0")
         if self._sparse:
             rs = rs._replace(sparse_grads=True)
-            self._rs = rs
-            self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
+        self.rasterizer = rasterizer_factory(rs) if rasterizer_factory is not None else GaussianRasterizer(rs)
+        if self._sparse and rasterizer_factory is not None and not getattr(self.rasterizer, "sparse_grads_ok", lambda: False)():
+            self._sparse = False           # this rasteriser reads every gradient row itself (e.g. the dense keyframe-parallel all-reduce): build it again, dense
+            rs = rs._replace(sparse_grads=False)
+            self.rasterizer = rasterizer_factory(rs)
+        self._rs = rs
         self._warmup = int(warmup)
         # device-side overflow guard: a replay whose duplicate count exceeds the capacity renders nothing; the Adam kernels
         # read the count and skip that step entirely (no stale-momentum drift, step count not advanced), counting it in a sticky counter
@@ -159,7 +161,8 @@ class MapperIterationGraph:
         self.loss_parts = None      # tensor([loss, L1, SSIM mean, depth L1]) of the last replay
         self.radii = None
         self.is_used = None
-        self.screenspace_grad = None
+        self.screenspace_grad = None    # (P,3); with sparse gradients (the default here) only the rows with radii > 0 are defined — mask as the
+        #                                 reference does with its visibility_filter [REF gaussian_renderer/__init__.py:307-308]
         self.num_rendered = None    # int32[1]: true duplicate count of the last replay
 
     # ------------------------------------------------------------------------------------------------------------

@@ -144,6 +144,14 @@ int gsicp_raster_layout(int P, int num_rendered, int width, int height, size_t o
  * same gradients; the order in which a Gaussian's per-tile records are added differs (tests/test_raster_gpu.py compares them). */
 int gsicp_raster_set_legacy_backward(int legacy);
 
+/* A HIP stream restricted to `n_cus` compute units starting at CU-mask bit `first_cu` (hipExtStreamCreateWithCUMask; MI355X: 256 CUs in 8 XCDs, consecutive
+ * mask bits go round the XCDs, so a contiguous range is spread evenly over them).  Round 6 experiment (default off): the tracker on dedicated CUs
+ * (GSICP_TRACKER_CU_MASK="first:count" at gsicp_gicp_create) and the mapper's stream on the complement, instead of a high-priority tracker stream sharing
+ * all CUs.  Returns the hipStream_t (NULL on failure); wrap it with torch.cuda.ExternalStream.  No reference counterpart (the reference runs two processes
+ * on one GPU and leaves the sharing to the hardware scheduler [REF gs_icp_slam.py:121-131]). */
+void* gsicp_stream_create_cu_mask(int first_cu, int n_cus);
+int gsicp_stream_destroy(void* stream);
+
 /* --------------------------------------------------------------------------------------------------------
  * 2. simple_knn — replaces simple_knn._C.distCUDA2 [REF scene/gaussian_model.py:20 (import site)].
  *    out[i] = mean squared distance from point i to its 3 nearest other points (f32).  Asynchronous.
@@ -302,6 +310,11 @@ int gsicp_mapper_select_view(const float* viewmatrix, const float* projmatrix, c
 int gsicp_mapper_loss_indirect(const float* image, const float* depth, const float* const* gt_slots, int width, int height, float lambda_dssim,
                                float depth_weight, float d_max, int tile_mod, int tile_rem, float* loss_out, float* dL_dimage, float* dL_ddepth,
                                char* scratch, void* stream);
+
+/* Test / A-B hook: which form of the two loss passes gsicp_mapper_loss* launches on one GPU.  1 (default) = round 6's kernels — one workgroup per 32x32
+ * tile looping over the three colour channels with the next channel's loads in flight; 0 = the per-(tile, channel) kernels of rounds 2-5.  Process-wide; also
+ * GSICP_LOSS_TILE3=0 at load.  Returns the previous value.  Both produce the same bits (tests/test_mapper_ops_gpu.py). */
+int gsicp_mapper_loss_set_tile3(int tile3);
 
 /* gsicp_mapper_loss_indirect that also ADVANCES the optimiser's device step counter (ABI 5): the one thread that finishes the loss value does
  * `if (guard_count && *guard_count > guard_limit) ++*skipped_dev; else ++*step_dev;` — after the forward of the captured iteration (whose

@@ -156,3 +156,39 @@ def test_raw_parameter_rasteriser_equals_activations_plus_rasteriser():
         mx = float(g0[k].abs().max())
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * mx + 1e-12, (k, float((g0[k] - g1[k]).abs().max()), mx)
     assert float((m0 - m1).abs().max()) <= 2e-5 * float(m0.abs().max())
+
+
+@pytest.mark.parametrize("res", [(1200, 680), (640, 480), (75, 53)])
+def test_loss_tile_loop_kernels_equal_the_per_channel_kernels_bit_for_bit(res):
+    """Round 6: loss_pass1_tile3_kernel / loss_pass2_tile3_kernel — one workgroup per 32x32 tile looping over the three channels with the
+    next channel's loads in flight — against the per-(tile, channel) kernels of rounds 2-5 (gsicp_mapper_loss_set_tile3): the four loss values and both
+    gradient images are the SAME BITS, with and without gradients being asked for, at both benchmark resolutions and on a ragged image (partial tiles on both
+    edges, masked holes)."""
+    from gs_icp_slam_amd import _lib
+    from gs_icp_slam_amd.loss import mapper_loss_and_grads, mapper_loss_parts
+    lib = _lib.load()
+    W, H = res
+    rng = np.random.default_rng(W + H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    gt = np.stack([0.5 + 0.4 * np.sin(xx / (9.0 + c) + yy / 17.0) for c in range(3)]).astype(np.float32)
+    img = np.clip(gt + rng.normal(0, 0.05, gt.shape), 0, 1).astype(np.float32)
+    gtd = (2.0 + np.sin(xx / 31.0)).astype(np.float32)[None]
+    gtd[:, H // 2: H // 2 + 9, W // 3: W // 2] = 0
+    dep = (gtd + rng.normal(0, 0.03, gtd.shape)).astype(np.float32)
+    t = [torch.tensor(a, device="cuda") for a in (img, dep, gt, gtd)]
+    out = {}
+    prev = lib.gsicp_mapper_loss_set_tile3(1)
+    try:
+        for form in (1, 0, 2, 3):      # 2: the tile-loop kernels without the register cap; 3: the per-channel pass 2 with its pixel loads hoisted (A/B forms)
+            lib.gsicp_mapper_loss_set_tile3(form)
+            parts, g_img, g_dep = mapper_loss_and_grads(*t)
+            with torch.no_grad():
+                value_only = mapper_loss_parts(*t)[1]
+            out[form] = (parts.clone(), g_img.clone(), g_dep.clone(), value_only.clone())
+    finally:
+        lib.gsicp_mapper_loss_set_tile3(prev)
+    for form in (1, 2, 3):
+        for a, b in zip(out[form], out[0]):
+            assert torch.equal(a, b), form
+    assert torch.equal(out[1][0], out[1][3])          # the value-only call (reduce kernel) gives the same four values
+    assert float(out[1][0][0]) > 0 and bool(out[1][1].abs().sum() > 0) and bool(out[1][2].abs().sum() > 0)
