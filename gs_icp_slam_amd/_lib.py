@@ -58,7 +58,7 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_loss_indirect_bump": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_uint, c_void_p, c_void_p]),
-    "gsicp_mapper_loss_set_tile3": (c_int, [c_int]),
+    "gsicp_mapper_loss_set_hoist": (c_int, [c_int]),
     "gsicp_mapper_activations_forward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_activations_backward": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_void_p, c_void_p, c_void_p]),

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
         if (blockIdx.x == 0 && blockIdx.y == 0 && red.out) loss_reduce_body(red, tid);   // pass 1's partial sums are complete: finish the loss value here
         return;
     }
-    // HOIST (round 6 A/B, GSICP_LOSS_TILE3=3): this thread's mask / target / image values, needed after the convolutions, are requested HERE, with the
+    // HOIST (round 6, default; GSICP_LOSS_HOIST=0 for the A/B partner): this thread's mask / target / image values, needed after the convolutions, are requested HERE, with the
     // staging loads — the kernel otherwise ends every workgroup with an exposed round trip to memory
     float h_gd[4] = {0.f, 0.f, 0.f, 0.f}, h_gt[4] = {0.f, 0.f, 0.f, 0.f}, h_im[4] = {0.f, 0.f, 0.f, 0.f};
     if (HOIST) {
@@ -378,295 +378,6 @@ __global__ __launch_bounds__(256) void loss_pass2_kernel(const float* __restrict
         __syncthreads();
         loss_reduce_body(red, tid);   // pass 1's partial sums are complete: finish the loss value here (same 256 threads, same order: same bits)
     }
-}
-
-// ------------------------------------------------------------------------------------------------ round 6: one workgroup per SPATIAL tile, three channels in a loop
-// pass 1 / pass 2 ran at 57 % / 38 % of their instruction floors with 37 % / 58 % of their wave-cycles waiting: a workgroup staged its halo
-// tile (a burst of loads), waited for it, computed, and left; 3 344 workgroups per launch took 3.3 rounds of the chip's 1 024 slots.  Here a workgroup owns a
-// 32x32 tile for ALL THREE channels (836 workgroups at 1200x680: one resident round): the ground-truth depth mask is loaded once, and while channel c is being
-// convolved the loads of channel c + 1 are already in flight INTO REGISTERS (the second buffer is the register file: no extra LDS, the same four
-// workgroups per CU) — they are written to LDS when channel c's last reader has passed its barrier.  The tile's depth term is done by the same workgroup
-// (round 5's `depth in channel 0` form).  Per (tile, channel) the arithmetic, its order and the partial-sum slots are those of loss_pass1_kernel /
-// loss_pass2_kernel: results are bit-identical (tests/test_mapper_ops_gpu.py compares the two forms).  GSICP_LOSS_TILE3=0 selects the per-channel kernels.
-__device__ __forceinline__ void loss_pass1_tile3_body(const float* __restrict__ image, const float* __restrict__ depth,
-                                                      const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
-                                                      const Win& win, float d_max, float dS_scale, float* __restrict__ abc,
-                                                      float* __restrict__ partial, const float* const* __restrict__ gt_slots) {
-    if (gt_slots) { gt_image = gt_slots[0]; gt_depth = gt_slots[1]; }
-    __shared__ __attribute__((aligned(16))) float s_x[LW][LWS];
-    __shared__ __attribute__((aligned(16))) float s_y[LW][LWS];
-    __shared__ __attribute__((aligned(16))) float s_hb[4][LW][LHS];
-    float (*const s_h[5])[LHS] = {s_hb[0], (float (*)[LHS])&s_x[0][0], s_hb[1], s_hb[3], s_hb[2]};
-    __shared__ float s_red[4][2];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
-    const size_t HW = (size_t)W * H;
-    const int n_tiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
-    const int lx = tid & 31, ry = tid >> 5;
-    constexpr int NST = (LW * LWS + 255) / 256;
-    // staged element u of this thread: its (clamped) pixel — recomputed where needed (a few integer operations) rather than held in registers across
-    // the channel loop — and the mask bit `inside the image and gt_depth > 0`, the same for the three channels
-    auto stage_pix = [&](int u) -> int {
-        const int i = tid + u * 256, r = i / LWS, c = i % LWS;
-        int px = x0 + c - HALO, py = y0 + r - HALO;
-        px = px < 0 ? 0 : (px >= W ? W - 1 : px);
-        py = py < 0 ? 0 : (py >= H ? H - 1 : py);
-        return py * W + px;
-    };
-    float gi[NST], im[NST];
-    unsigned live = 0u;
-    {
-        float gd[NST];
-#pragma unroll
-        for (int u = 0; u < NST; ++u) { const int q = stage_pix(u); gd[u] = gt_depth[q]; gi[u] = gt_image[q]; im[u] = image[q]; }
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int i = tid + u * 256, r = i / LWS, c = i % LWS;
-            const int px = x0 + c - HALO, py = y0 + r - HALO;
-            const bool in = c < LW && px >= 0 && px < W && py >= 0 && py < H;
-            if (in && gd[u] > 0.f) live |= 1u << u;
-        }
-    }
-    // the tile's depth term (loads in flight with the staging loads)
-    float l1d = 0.f;
-    {
-        const int px = x0 + lx;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int py = y0 + 4 * ry + j;
-            if (px < W && py < H) {
-                const float g = gt_depth[(size_t)py * W + px] / d_max;
-                const float d = depth[(size_t)py * W + px] / d_max;
-                if (g != 0.f) l1d += fabsf(d - g);
-            }
-        }
-    }
-#pragma unroll 1
-    for (int ch = 0; ch < 3; ++ch) {
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int i = tid + u * 256, r = i / LWS, c = i % LWS;
-            if (i < LW * LWS) {
-                const float yv = ((live >> u) & 1u) ? gi[u] : 0.f;
-                s_x[r][c] = yv != 0.f ? im[u] : 0.f;
-                s_y[r][c] = yv;
-            }
-        }
-        if (ch < 2) {   // the next channel's loads: in flight during this channel's convolutions
-#pragma unroll
-            for (int u = 0; u < NST; ++u) { const size_t q = (size_t)(ch + 1) * HW + stage_pix(u); gi[u] = gt_image[q]; im[u] = image[q]; }
-        }
-        __syncthreads();
-        float l1 = 0.f, ssum = 0.f;
-        float xc[4], yc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { xc[j] = s_x[4 * ry + j + HALO][lx + HALO]; yc[j] = s_y[4 * ry + j + HALO][lx + HALO]; }
-#pragma unroll 1
-        for (int it = tid; it < LW * HSEG; it += 256) {
-            const int r = it / HSEG, c0 = 4 * (it % HSEG);
-            float xv[16], yv[16], pr[16];
-            lds_load16(&s_x[r][c0], xv);
-            lds_load16(&s_y[r][c0], yv);
-            *(float4*)&s_h[0][r][c0] = conv4(xv, win);
-#pragma unroll
-            for (int i = 0; i < 14; ++i) pr[i] = xv[i] * xv[i];
-            *(float4*)&s_h[2][r][c0] = conv4(pr, win);
-#pragma unroll
-            for (int i = 0; i < 14; ++i) pr[i] = xv[i] * yv[i];
-            *(float4*)&s_h[4][r][c0] = conv4(pr, win);
-        }
-        __syncthreads();   // x is consumed: mu_y may land on it
-#pragma unroll 1
-        for (int it = tid; it < LW * HSEG; it += 256) {
-            const int r = it / HSEG, c0 = 4 * (it % HSEG);
-            float yv[16], pr[16];
-            lds_load16(&s_y[r][c0], yv);
-            *(float4*)&s_h[1][r][c0] = conv4(yv, win);
-#pragma unroll
-            for (int i = 0; i < 14; ++i) pr[i] = yv[i] * yv[i];
-            *(float4*)&s_h[3][r][c0] = conv4(pr, win);
-        }
-        __syncthreads();
-        float mom[5][4];
-#pragma unroll
-        for (int m = 0; m < 5; ++m) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 14; ++i) v[i] = s_h[m][4 * ry + i][lx];
-            const float4 o = conv4(v, win);
-            mom[m][0] = o.x; mom[m][1] = o.y; mom[m][2] = o.z; mom[m][3] = o.w;
-        }
-        const int px = x0 + lx;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int py = y0 + 4 * ry + j;
-            if (px < W && py < H) {
-                const float mu1 = mom[0][j], mu2 = mom[1][j], e11 = mom[2][j], e22 = mom[3][j], e12 = mom[4][j];
-                const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-                const float a = 2.f * mu12 + C1, b = 2.f * (e12 - mu12) + C2;
-                const float c = mu1_sq + mu2_sq + C1, d = (e11 - mu1_sq) + (e22 - mu2_sq) + C2;
-                const float inv_d = __builtin_amdgcn_rcpf(d);
-                const float inv_cd = __builtin_amdgcn_rcpf(c) * inv_d;
-                const float S = a * b * inv_cd;
-                ssum += S;
-                const float dS_dmu1 = 2.f * mu2 * (b - a) * inv_cd - 2.f * mu1 * S * (d - c) * inv_cd;
-                const float dS_de11 = -S * inv_d;
-                const float dS_de12 = 2.f * a * inv_cd;
-                const size_t pix = (size_t)py * W + px;
-                abc[(ch * 3 + 0) * HW + pix] = dS_scale * dS_dmu1;
-                abc[(ch * 3 + 1) * HW + pix] = dS_scale * dS_de11;
-                abc[(ch * 3 + 2) * HW + pix] = dS_scale * dS_de12;
-                if (yc[j] != 0.f) l1 += fabsf(xc[j] - yc[j]);
-            }
-        }
-        l1 = wave_sum_f(l1); ssum = wave_sum_f(ssum);
-        if ((tid & 63) == 0) { s_red[tid >> 6][0] = l1; s_red[tid >> 6][1] = ssum; }
-        __syncthreads();   // also: every reader of this channel's maps has passed — the next channel may be staged
-        if (tid == 0) {
-            partial[((size_t)ch * n_tiles + tile) * 2 + 0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
-            partial[((size_t)ch * n_tiles + tile) * 2 + 1] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
-        }
-        __syncthreads();   // s_red is read: the next channel (or the depth sum) may write it
-    }
-    l1d = wave_sum_f(l1d);
-    if ((tid & 63) == 0) { s_red[tid >> 6][0] = l1d; s_red[tid >> 6][1] = 0.f; }
-    __syncthreads();
-    if (tid == 0) {
-        partial[((size_t)3 * n_tiles + tile) * 2 + 0] = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
-        partial[((size_t)3 * n_tiles + tile) * 2 + 1] = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
-    }
-}
-
-#define GSICP_P1_ARGS const float* __restrict__ image, const float* __restrict__ depth, const float* __restrict__ gt_image, const float* __restrict__ gt_depth, \
-                      int W, int H, Win win, float d_max, float dS_scale, float* __restrict__ abc, float* __restrict__ partial, const float* const* __restrict__ gt_slots
-// two register budgets of the same body (A/B; GSICP_LOSS_TILE3=1: four waves per SIMD = four workgroups per CU, 836 tiles in ONE resident round, the prefetch
-// registers partly spilled; =2: whatever the body asks for — 177 registers, two workgroups per CU)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void loss_pass1_tile3_kernel(GSICP_P1_ARGS) {
-    loss_pass1_tile3_body(image, depth, gt_image, gt_depth, W, H, win, d_max, dS_scale, abc, partial, gt_slots);
-}
-__global__ __launch_bounds__(256) void loss_pass1_tile3_wide_kernel(GSICP_P1_ARGS) {
-    loss_pass1_tile3_body(image, depth, gt_image, gt_depth, W, H, win, d_max, dS_scale, abc, partial, gt_slots);
-}
-
-__device__ __forceinline__ void loss_pass2_tile3_body(const float* __restrict__ image, const float* __restrict__ depth,
-                                                      const float* __restrict__ gt_image, const float* __restrict__ gt_depth, int W, int H,
-                                                      const Win& win, float d_max, float l1_scale, float depth_scale, const float* __restrict__ abc,
-                                                      float* __restrict__ dL_dimage, float* __restrict__ dL_ddepth, const LossReduceArgs& red,
-                                                      const float* const* __restrict__ gt_slots) {
-    if (gt_slots) { gt_image = gt_slots[0]; gt_depth = gt_slots[1]; }
-    __shared__ __attribute__((aligned(16))) float s_in[3][LW][LWS];
-    __shared__ __attribute__((aligned(16))) float s_h0[LW][LHS];
-    float (*const s_hm[3])[LHS] = {s_h0, (float (*)[LHS])&s_in[0][0][0], (float (*)[LHS])&s_in[1][0][0]};
-    const int tid = threadIdx.x, lx = tid & 31, ry = tid >> 5;
-    const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
-    const size_t HW = (size_t)W * H;
-    const int px = x0 + lx;
-    constexpr int NST = (LW * LWS + 255) / 256;
-    auto stage_pix = [&](int u) -> int {
-        const int i = tid + u * 256, r = i / LWS, c = i % LWS;
-        int qx = x0 + c - HALO, qy = y0 + r - HALO;
-        qx = qx < 0 ? 0 : (qx >= W ? W - 1 : qx);
-        qy = qy < 0 ? 0 : (qy >= H ? H - 1 : qy);
-        return qy * W + qx;
-    };
-    float va[NST], vb[NST], vc[NST];
-#pragma unroll
-    for (int u = 0; u < NST; ++u) { const int q = stage_pix(u); va[u] = abc[0 * HW + q]; vb[u] = abc[1 * HW + q]; vc[u] = abc[2 * HW + q]; }
-    // this thread's four pixels: mask, target and image values of channel 0, the depth pair — all in flight with the staging loads (the per-channel
-    // kernel fetched them AFTER its convolutions: an exposed round trip at the end of every workgroup)
-    float gdp[4], gtp[4], imp[4], dp[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int py = y0 + 4 * ry + j;
-        const bool ok = px < W && py < H;
-        const size_t pix = ok ? (size_t)py * W + px : 0;
-        gdp[j] = gt_depth[pix]; gtp[j] = gt_image[pix]; imp[j] = image[pix]; dp[j] = depth[pix];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {   // the tile's depth gradient
-        const int py = y0 + 4 * ry + j;
-        if (px < W && py < H) {
-            const float g = gdp[j] / d_max, d = dp[j] / d_max;
-            float gr = 0.f;
-            if (g != 0.f) gr = d > g ? depth_scale : (d < g ? -depth_scale : 0.f);
-            dL_ddepth[(size_t)py * W + px] = gr;
-        }
-    }
-#pragma unroll 1
-    for (int ch = 0; ch < 3; ++ch) {
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int i = tid + u * 256, r = i / LWS, c = i % LWS;
-            const int qx = x0 + c - HALO, qy = y0 + r - HALO;
-            if (i < LW * LWS) {
-                const bool in = c < LW && qx >= 0 && qx < W && qy >= 0 && qy < H;
-                s_in[0][r][c] = in ? va[u] : 0.f; s_in[1][r][c] = in ? vb[u] : 0.f; s_in[2][r][c] = in ? vc[u] : 0.f;
-            }
-        }
-        const float gt_c[4] = {gtp[0], gtp[1], gtp[2], gtp[3]}, im_c[4] = {imp[0], imp[1], imp[2], imp[3]};
-        if (ch < 2) {   // the next channel's derivative maps and pixel values: in flight during this channel's convolutions
-#pragma unroll
-            for (int u = 0; u < NST; ++u) {
-                const size_t q = (size_t)((ch + 1) * 3) * HW + stage_pix(u);
-                va[u] = abc[q]; vb[u] = abc[q + HW]; vc[u] = abc[q + 2 * HW];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int py = y0 + 4 * ry + j;
-                const size_t pix = (px < W && py < H) ? (size_t)py * W + px : 0;
-                gtp[j] = gt_image[(ch + 1) * HW + pix]; imp[j] = image[(ch + 1) * HW + pix];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-    #pragma unroll 1
-        for (int it = tid; it < LW * HSEG; it += 256) {
-                const int r = it / HSEG, c0 = 4 * (it % HSEG);
-                float v[16];
-                lds_load16(&s_in[m][r][c0], v);
-                *(float4*)&s_hm[m][r][c0] = conv4(v, win);
-            }
-            __syncthreads();
-        }
-        float acc[3][4];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 14; ++i) v[i] = s_hm[m][4 * ry + i][lx];
-            const float4 o = conv4(v, win);
-            acc[m][0] = o.x; acc[m][1] = o.y; acc[m][2] = o.z; acc[m][3] = o.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int py = y0 + 4 * ry + j;
-            if (px < W && py < H) {
-                const size_t pix = (size_t)py * W + px;
-                const float yv = gdp[j] > 0.f ? gt_c[j] : 0.f;
-                float gr = 0.f;
-                if (yv != 0.f) {
-                    const float xv = im_c[j];
-                    gr = acc[0][j] + 2.f * xv * acc[1][j] + yv * acc[2][j];
-                    gr += xv > yv ? l1_scale : (xv < yv ? -l1_scale : 0.f);
-                }
-                dL_dimage[ch * HW + pix] = gr;
-            }
-        }
-        __syncthreads();   // every reader of this channel's filtered maps has passed: the next channel may be staged over them
-    }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && red.out) loss_reduce_body(red, tid);   // pass 1's partial sums are complete: finish the loss value here
-}
-
-#define GSICP_P2_ARGS const float* __restrict__ image, const float* __restrict__ depth, const float* __restrict__ gt_image, const float* __restrict__ gt_depth, \
-                      int W, int H, Win win, float d_max, float l1_scale, float depth_scale, const float* __restrict__ abc, float* __restrict__ dL_dimage, \
-                      float* __restrict__ dL_ddepth, LossReduceArgs red, const float* const* __restrict__ gt_slots
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void loss_pass2_tile3_kernel(GSICP_P2_ARGS) {
-    loss_pass2_tile3_body(image, depth, gt_image, gt_depth, W, H, win, d_max, l1_scale, depth_scale, abc, dL_dimage, dL_ddepth, red, gt_slots);
-}
-__global__ __launch_bounds__(256) void loss_pass2_tile3_wide_kernel(GSICP_P2_ARGS) {
-    loss_pass2_tile3_body(image, depth, gt_image, gt_depth, W, H, win, d_max, l1_scale, depth_scale, abc, dL_dimage, dL_ddepth, red, gt_slots);
 }
 
 // ------------------------------------------------------------------------------------------------ fused loss (value parts + gradient)
@@ -1286,14 +997,14 @@ __global__ __launch_bounds__(256) void tiles_move_kernel(int W, int H, int gx, i
 
 using namespace gsicp;
 
-static std::atomic<int>& loss_tile3_flag() {
-    static std::atomic<int> v([] { const char* e = getenv("GSICP_LOSS_TILE3"); return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1; }());
+static std::atomic<int>& loss_hoist_flag() {
+    static std::atomic<int> v([] { const char* e = getenv("GSICP_LOSS_HOIST"); return (e && e[0] == '0') ? 0 : 1; }());
     return v;
 }
 
 extern "C" {
 
-int gsicp_mapper_loss_set_tile3(int tile3) { return loss_tile3_flag().exchange(tile3 < 0 ? 0 : (tile3 > 3 ? 3 : tile3)); }
+int gsicp_mapper_loss_set_hoist(int hoist) { return loss_hoist_flag().exchange(hoist ? 1 : 0); }
 
 size_t gsicp_mapper_loss_scratch_bytes(int width, int height) {
     const size_t HW = (size_t)width * height;
@@ -1351,30 +1062,16 @@ static int mapper_loss_impl(const float* image, const float* depth, const float*
         if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_loss_sharded: kernel launch failed"; return -1; }
         return 0;
     }
-    // round 6: one workgroup per spatial tile looping over the three channels with the next channel's loads in flight (GSICP_LOSS_TILE3=0: the
-    // per-channel kernels of rounds 2-5).  Same bits either way.
-    const int tile3 = loss_tile3_flag().load();
-    const dim3 grid_t3(grid.x, grid.y, 1);
+    // round 6: pass 2 requests the pixel values it needs AFTER its convolutions together with its staging loads (GSICP_LOSS_HOIST=0 / gsicp_mapper_loss_set_hoist:
+    // the kernel of rounds 2-5, which ended every workgroup with an exposed round trip to memory: 30.9 -> 27.8 us).  Same bits either way.
+    const bool hoist = loss_hoist_flag().load() != 0;
     { ProfileScope ps(ST_LOSS_PASS1, stream);
-      if (tile3 == 2)
-          hipLaunchKernelGGL(loss_pass1_tile3_wide_kernel, grid_t3, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
-                             -lambda_dssim / n_img, abc, partial, gt_slots);
-      else if (tile3 == 1)
-          hipLaunchKernelGGL(loss_pass1_tile3_kernel, grid_t3, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
-                             -lambda_dssim / n_img, abc, partial, gt_slots);
-      else
-          hipLaunchKernelGGL(loss_pass1_kernel, grid2p, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
-                             -lambda_dssim / n_img, abc, partial, gt_slots);
+      hipLaunchKernelGGL(loss_pass1_kernel, grid2p, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
+                         -lambda_dssim / n_img, abc, partial, gt_slots);
       if (!with_grads) hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, stream, red); }
     if (with_grads) {   // one workgroup of pass 2 finishes the loss value (no launch of its own)
         ProfileScope ps(ST_LOSS_PASS2, stream);
-        if (tile3 == 2)
-            hipLaunchKernelGGL(loss_pass2_tile3_wide_kernel, grid_t3, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
-                               (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth, red, gt_slots);
-        else if (tile3 == 1)
-            hipLaunchKernelGGL(loss_pass2_tile3_kernel, grid_t3, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
-                               (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth, red, gt_slots);
-        else if (tile3 == 3)
+        if (hoist)
             hipLaunchKernelGGL(loss_pass2_kernel<true>, grid2p, dim3(256), 0, stream, image, depth, gt_image, gt_depth, width, height, win, d_max,
                                (1.f - lambda_dssim) / n_img, depth_weight / ((float)HW * d_max), abc, dL_dimage, dL_ddepth, red, gt_slots);
         else

@@ -706,9 +706,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void p
             prebwd_finish(a, t, false, gs, r0, p0, s1, q1);
         }
     }
-    const uint32_t n_vis = *a.vis_counter;
+    // The forward bumps the slot count (low word) and the visible count (high word) with ONE 64-bit atomic: a duplicate total of 2^32 or more — degenerate
+    // near-camera splats over a multi-million-row map; the lists overflowed long before and nothing was rendered — would carry into the visible count
+    // (ADVICE r5).  The count is therefore clamped to P and every list entry checked against P before it indexes anything.
+    const uint32_t n_vis_raw = *a.vis_counter;
+    const uint32_t n_vis = n_vis_raw < (uint32_t)a.P ? n_vis_raw : (uint32_t)a.P;
     if ((uint32_t)t >= n_vis) return;
-    const int i = (int)a.vis_list[t];
+    const uint32_t iu = a.vis_list[t];
+    if (iu >= (uint32_t)a.P) return;
+    const int i = (int)iu;
     if (a.live_rows != nullptr && i >= *a.live_rows) return;      // cannot happen (rows behind the live count are culled in the forward); cheap
     SplatRec r_early = r0;
     float p_early[3] = {0.f, 0.f, 0.f}, sc_early[3] = {1.f, 1.f, 1.f}, q_early[4] = {0.f, 0.f, 0.f, 1.f};

@@ -105,6 +105,7 @@ class MapperIterationGraph:
         self._H, self._W = H, W
         self.gt_slots = torch.zeros(2, dtype=torch.int64, device=dev)
         self._gt_refs = None
+        self._gt_ring, self._gt_ring_depth = [], max(1, int(os.environ.get("GSICP_VIEW_REFS", "8")))
         self._gt_stage = None
         self.bg = torch.zeros(3, **f32) if bg is None else bg.to(**f32)
         rs = GaussianRasterizationSettings(
@@ -166,10 +167,13 @@ class MapperIterationGraph:
         self.num_rendered = None    # int32[1]: true duplicate count of the last replay
 
     # ------------------------------------------------------------------------------------------------------------
-    def set_view(self, viewmatrix, projmatrix, campos, gt_image, gt_depth):
+    def set_view(self, viewmatrix, projmatrix, campos, gt_image, gt_depth, copy=False):
         """Select the keyframe of the next step(): ONE 64-thread launch writes the camera into the graph's static inputs and the addresses of the two
         ground-truth images into the slot pair the captured loss kernels read.  The images are used IN PLACE: they must not be modified until the
-        replay has finished (this object holds references to them until the next set_view)."""
+        replay that reads them has finished.  This object keeps references to the tensors of the last `GSICP_VIEW_REFS` (8) selections — more than any
+        caller here keeps replays in flight (bench.py / refglue: 2) — and marks them as in use on the replay's stream, so freeing them early is safe;
+        an in-place EDIT of a selected image while its replay is queued is not detectable: pass `copy=True` (the images go through this object's own
+        staging buffers: two copies per selection, rounds 2-4's behaviour) when the caller cannot guarantee that."""
         dev = self.gt_slots.device
         HW = self._H * self._W
         f32 = lambda t, n: t.is_cuda and t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n   # noqa: E731
@@ -178,7 +182,7 @@ class MapperIterationGraph:
             viewmatrix = viewmatrix.to(device=dev, dtype=torch.float32).contiguous()
             projmatrix = projmatrix.to(device=dev, dtype=torch.float32).contiguous()
             campos = campos.to(device=dev, dtype=torch.float32).reshape(3).contiguous()
-        if not (f32(gt_image, 3 * HW) and f32(gt_depth, HW) and gt_image.data_ptr() % 16 == 0 and gt_depth.data_ptr() % 16 == 0):
+        if copy or not (f32(gt_image, 3 * HW) and f32(gt_depth, HW) and gt_image.data_ptr() % 16 == 0 and gt_depth.data_ptr() % 16 == 0):
             if self._gt_stage is None:
                 self._gt_stage = (torch.zeros((3, self._H, self._W), dtype=torch.float32, device=dev),
                                   torch.zeros((1, self._H, self._W), dtype=torch.float32, device=dev))
@@ -192,6 +196,12 @@ class MapperIterationGraph:
             _lib.check(lib.gsicp_mapper_select_view(p(viewmatrix), p(projmatrix), p(campos), p(gt_image), p(gt_depth), p(self.viewmatrix),
                                                     p(self.projmatrix), p(self.campos), p(self.gt_slots), stream), "gsicp_mapper_select_view")
         self._gt_refs = (viewmatrix, projmatrix, campos, gt_image, gt_depth)
+        cur = torch.cuda.current_stream(dev)
+        for t in self._gt_refs:
+            t.record_stream(cur)            # the caching allocator must not hand this memory to another stream while the replay may still read it
+        self._gt_ring.append(self._gt_refs)
+        if len(self._gt_ring) > self._gt_ring_depth:
+            self._gt_ring.pop(0)
 
     def _iteration(self):
         if self._fused_activations:

@@ -311,10 +311,10 @@ int gsicp_mapper_loss_indirect(const float* image, const float* depth, const flo
                                float depth_weight, float d_max, int tile_mod, int tile_rem, float* loss_out, float* dL_dimage, float* dL_ddepth,
                                char* scratch, void* stream);
 
-/* Test / A-B hook: which form of the two loss passes gsicp_mapper_loss* launches on one GPU.  1 (default) = round 6's kernels — one workgroup per 32x32
- * tile looping over the three colour channels with the next channel's loads in flight; 0 = the per-(tile, channel) kernels of rounds 2-5.  Process-wide; also
- * GSICP_LOSS_TILE3=0 at load.  Returns the previous value.  Both produce the same bits (tests/test_mapper_ops_gpu.py). */
-int gsicp_mapper_loss_set_tile3(int tile3);
+/* Test / A-B hook: 1 (default) = loss pass 2 requests its per-pixel mask / target / image values together with its staging loads (round 6); 0 = after its
+ * convolutions, as rounds 2-5 did.  Process-wide; also GSICP_LOSS_HOIST=0 at load.  Returns the previous value.  Same bits either way
+ * (tests/test_mapper_ops_gpu.py). */
+int gsicp_mapper_loss_set_hoist(int hoist);
 
 /* gsicp_mapper_loss_indirect that also ADVANCES the optimiser's device step counter (ABI 5): the one thread that finishes the loss value does
  * `if (guard_count && *guard_count > guard_limit) ++*skipped_dev; else ++*step_dev;` — after the forward of the captured iteration (whose

@@ -159,11 +159,10 @@ def test_raw_parameter_rasteriser_equals_activations_plus_rasteriser():
 
 
 @pytest.mark.parametrize("res", [(1200, 680), (640, 480), (75, 53)])
-def test_loss_tile_loop_kernels_equal_the_per_channel_kernels_bit_for_bit(res):
-    """Round 6: loss_pass1_tile3_kernel / loss_pass2_tile3_kernel — one workgroup per 32x32 tile looping over the three channels with the
-    next channel's loads in flight — against the per-(tile, channel) kernels of rounds 2-5 (gsicp_mapper_loss_set_tile3): the four loss values and both
-    gradient images are the SAME BITS, with and without gradients being asked for, at both benchmark resolutions and on a ragged image (partial tiles on both
-    edges, masked holes)."""
+def test_loss_pass2_with_hoisted_pixel_loads_equals_the_late_loads_bit_for_bit(res):
+    """Round 6: loss pass 2 requests the mask / target / image values of its own pixels together with its staging loads instead of after
+    its convolutions (gsicp_mapper_loss_set_hoist): the four loss values and both gradient images are the SAME BITS as the late-load kernel's, with and
+    without gradients being asked for, at both benchmark resolutions and on a ragged image (partial tiles on both edges, masked holes)."""
     from gs_icp_slam_amd import _lib
     from gs_icp_slam_amd.loss import mapper_loss_and_grads, mapper_loss_parts
     lib = _lib.load()
@@ -177,18 +176,17 @@ def test_loss_tile_loop_kernels_equal_the_per_channel_kernels_bit_for_bit(res):
     dep = (gtd + rng.normal(0, 0.03, gtd.shape)).astype(np.float32)
     t = [torch.tensor(a, device="cuda") for a in (img, dep, gt, gtd)]
     out = {}
-    prev = lib.gsicp_mapper_loss_set_tile3(1)
+    prev = lib.gsicp_mapper_loss_set_hoist(1)
     try:
-        for form in (1, 0, 2, 3):      # 2: the tile-loop kernels without the register cap; 3: the per-channel pass 2 with its pixel loads hoisted (A/B forms)
-            lib.gsicp_mapper_loss_set_tile3(form)
+        for form in (1, 0):
+            lib.gsicp_mapper_loss_set_hoist(form)
             parts, g_img, g_dep = mapper_loss_and_grads(*t)
             with torch.no_grad():
                 value_only = mapper_loss_parts(*t)[1]
             out[form] = (parts.clone(), g_img.clone(), g_dep.clone(), value_only.clone())
     finally:
-        lib.gsicp_mapper_loss_set_tile3(prev)
-    for form in (1, 2, 3):
-        for a, b in zip(out[form], out[0]):
-            assert torch.equal(a, b), form
+        lib.gsicp_mapper_loss_set_hoist(prev)
+    for a, b in zip(out[1], out[0]):
+        assert torch.equal(a, b)
     assert torch.equal(out[1][0], out[1][3])          # the value-only call (reduce kernel) gives the same four values
     assert float(out[1][0][0]) > 0 and bool(out[1][1].abs().sum() > 0) and bool(out[1][2].abs().sum() > 0)

@@ -10,7 +10,7 @@ tail -6 $OUT/pytest.log | cut -c1-300
 cd /tmp
 M="python $ROOT/bench.py --only mapper --steps 50 --warmup 5 --repeats 2 --no-cpu-baseline --no-legs"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_mapper -o bench -- $M > $OUT/mapper_only.json 2> $OUT/kt_mapper.err
-GSICP_LOSS_DEPTH_SLICE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_mapper_depth_slice -o bench -- $M > $OUT/mapper_only_depth_slice.json 2> $OUT/kt_mapper_d.err
+GSICP_LOSS_DEPTH_IN_CH0=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_mapper_depth_slice -o bench -- $M > $OUT/mapper_only_depth_slice.json 2> $OUT/kt_mapper_d.err
 $M > $OUT/mapper_only_plain.json 2>> $OUT/kt_mapper.err
 cd $ROOT
 find $OUT -name '*kernel_trace.csv' -delete
