@@ -755,9 +755,6 @@ __device__ inline float wave_sum10_banked(float v0, float v1, float v2, float v3
     return t;
 }
 
-// PREFETCH (round 6 A/B, GSICP_BWD_PREFETCH=1): the list words of the NEXT batch are requested before the current batch is evaluated — a batch otherwise
-// opens with two dependent round trips (list word -> Gaussian record) that only the other resident workgroups hide.
-template <bool PREFETCH>
 __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
     const int tl = (int)blockIdx.x;            // tiles are dispatched longest list first (LPT), see the forward
     if (tl >= a.n_tiles_local) return;
@@ -813,17 +810,10 @@ __global__ __launch_bounds__(256) void blend_backward_tile_kernel(BlendArgs a) {
         top0 = o > top0 ? o : top0;
     }
     const int total = (int)(range.y - range.x);
-    uint32_t e_nx = 0, gid_nx = 0;
-    if (PREFETCH && total - 1 - lane >= 0) { e_nx = a.point_list[range.x + (uint32_t)(total - 1 - lane)]; gid_nx = a.list_gauss[range.x + (uint32_t)(total - 1 - lane)]; }
     for (int top = total; top > 0; top -= 64) {   // entries [top-64, top) back-to-front; lane 0 holds the last one
         const int posn = top - 1 - lane;          // 0-based list position of this lane's entry
         uint32_t e = 0, gid = 0;
-        if (PREFETCH) {
-            e = e_nx; gid = gid_nx;
-            const int pn = posn - 64;
-            e_nx = 0; gid_nx = 0;
-            if (pn >= 0) { e_nx = a.point_list[range.x + (uint32_t)pn]; gid_nx = a.list_gauss[range.x + (uint32_t)pn]; }
-        } else if (posn >= 0) { e = a.point_list[range.x + (uint32_t)posn]; gid = a.list_gauss[range.x + (uint32_t)posn]; }
+        if (posn >= 0) { e = a.point_list[range.x + (uint32_t)posn]; gid = a.list_gauss[range.x + (uint32_t)posn]; }
         if (wave == 0) s_e[lane] = e;
         const bool keep = (e & strip_bit) != 0;
         const unsigned long long m = __ballot(keep);
@@ -1178,9 +1168,7 @@ int gsicp_raster_backward(int P, int D, int M, int num_rendered, const float* ba
     ba.entry_sum = entry_sum;
     if (num_rendered > 0 && ba.n_tiles_local > 0) {
         ProfileScope ps(ST_BLEND_BWD, stream);
-        static const bool prefetch = [] { const char* e = getenv("GSICP_BWD_PREFETCH"); return e && e[0] == '1'; }();
-        if (prefetch) hipLaunchKernelGGL(blend_backward_tile_kernel<true>, dim3(ba.n_tiles_local), dim3(256), 0, stream, ba);
-        else hipLaunchKernelGGL(blend_backward_tile_kernel<false>, dim3(ba.n_tiles_local), dim3(256), 0, stream, ba);
+        hipLaunchKernelGGL(blend_backward_tile_kernel, dim3(ba.n_tiles_local), dim3(256), 0, stream, ba);
     }
 
     PreprocessBwdArgs pb;

@@ -172,6 +172,44 @@ class GaussianStore:
         self._rebind()
         return self.params
 
+    def grow(self, new_capacity):
+        """Re-house the map in buffers of `new_capacity` rows (the reference's map grows without bound [REF scene/gaussian_model.py:474-492]; its shared
+        buffers are sized for 10 M points [REF gs_icp_slam.py:86]).  Every live row of every array — parameters, both Adam moments, statistics, masks —
+        is copied; the Parameter OBJECTS and the optimiser's state entries stay (their storage is swapped), so param groups, learning rates and the step
+        count carry over.  Every device ADDRESS changes: a hipGraph captured over the old buffers is void — the caller drops it and captures again
+        (refglue.add_from_pcd2_tensor does) — and a row-freeze mask bound to the old trackable mask must be bound again (returned flag).  Synchronises."""
+        new_capacity = int(new_capacity)
+        if new_capacity <= self.capacity:
+            return False
+        torch.cuda.synchronize(self.device)
+        old_sets, old_cur, n = self._sets, self._cur, self.n
+        self.capacity = new_capacity
+        f32 = dict(dtype=torch.float32, device=self.device)
+        new_sets = []
+        for _ in range(2):
+            s = {}
+            for key, t in old_sets[0].items():
+                s[key] = torch.zeros((new_capacity,) + tuple(t.shape[1:]), dtype=t.dtype, device=self.device)
+            new_sets.append(s)
+        with torch.no_grad():
+            src = old_sets[old_cur]
+            for key, t in src.items():
+                if n > 0 and t[0].numel() > 0:
+                    new_sets[0][key][:n].copy_(t[:n])
+        self._sets, self._cur = new_sets, 0
+        if self.params:
+            if self.stable:
+                for k in PARAM_NAMES:
+                    self.params[k].data = self._sets[0][("p", k)]
+                    if self.optimizer is not None and self.params[k] in self.optimizer.state:
+                        st = self.optimizer.state[self.params[k]]
+                        st["exp_avg"], st["exp_avg_sq"] = self._sets[0][("m", k)], self._sets[0][("v", k)]
+            else:
+                self._rebind()
+        del old_sets, f32
+        torch.cuda.synchronize(self.device)
+        return True
+
     # ------------------------------------------------------------------------------------------------ pruning
     def prune(self, remove_mask):
         """Equivalent of prune_points(mask) [REF scene/gaussian_model.py:426-447]: rows with remove_mask True disappear from every

@@ -48,8 +48,8 @@ def patch_gaussian_model(cls):
     def create_from_pcd2_tensor(self, points, colors, rots_, scales_, z_vals_, trackable_idxs):
         # rows of the capacity-backed map (376 B each: parameters, both Adam moments and statistics in two buffer sets: 2 M rows = 0.75 GB of 288 GB;
         # the per-row kernels run their grids over the capacity, so it is not made larger than a run needs).  The reference's map grows without
-        # bound [REF scene/gaussian_model.py:474-492]; whole-room Replica maps reach 1-2 M Gaussians: when the capacity is exhausted the new
-        # keyframe's Gaussians are dropped with a message naming this variable (add_from_pcd2_tensor below), the run goes on.
+        # bound [REF scene/gaussian_model.py:474-492]; whole-room Replica maps reach 1-2 M Gaussians: when the capacity is exhausted the store moves
+        # into buffers of twice the size (GaussianStore.grow; add_from_pcd2_tensor below) and the mapper iteration is captured again.
         capacity = int(os.environ.get("GSICP_FUSED_CAPACITY", "2000000"))
         n_rest = (self.max_sh_degree + 1) ** 2 - 1
         self._store = GaussianStore(capacity, n_rest=n_rest, device=points.device, stable=True)
@@ -62,13 +62,19 @@ def patch_gaussian_model(cls):
         rows, mask = rows_from_gicp(points.float(), colors.float(), rots_.float(), scales_.float(), z_vals_.float(),
                                     trackable_idxs if len(trackable_idxs) != 0 else None, self.max_sh_degree)
         if self._store.n + rows["xyz"].shape[0] > self._store.capacity:
-            # say what to do instead of dying with a bare RuntimeError deep inside the mapper process (the tracker would wait on the
-            # shared flags until its timeout).  The keyframe's Gaussians are dropped; mapping and tracking go on with the map as it is.
-            if not self.__dict__.get("_gsicp_capacity_warned"):
-                print(f"GSICP: map capacity {self._store.capacity} rows exhausted ({self._store.n} live + {rows['xyz'].shape[0]} new): the new keyframe's "
-                      f"Gaussians are DROPPED.  Raise GSICP_FUSED_CAPACITY.", flush=True)
-                self.__dict__["_gsicp_capacity_warned"] = True
-            return
+            # The reference's map grows without bound [REF scene/gaussian_model.py:474-492]: so does this one (round 5 dropped the keyframe).
+            # The store moves into buffers of twice the capacity; every address changes, so the captured iterations are released and captured again on
+            # the next mapping iteration (one capture ~ three iterations of time), and the row-freeze mask (policy `freeze`) is bound to the new buffer.
+            new_cap = max(2 * self._store.capacity, self._store.n + int(rows["xyz"].shape[0]))
+            print(f"GSICP: map capacity {self._store.capacity} rows exhausted ({self._store.n} live + {rows['xyz'].shape[0]} new): growing to {new_cap} rows "
+                  f"(one re-capture of the mapper iteration; start with a larger GSICP_FUSED_CAPACITY to avoid it)", flush=True)
+            for mg in self.__dict__.get("_gsicp_graphs", {}).values():
+                mg.release()
+            self.__dict__.get("_gsicp_graphs", {}).clear()
+            self._store.grow(new_cap)
+            pol = fused_policy()
+            if pol["freeze_groups"] and self.optimizer is not None:
+                self.optimizer.set_row_freeze(self._store._sets[0][("aux", "trackable_mask")], pol["freeze_groups"])
         self._store.append(rows, mask)          # rows written in place, live count bumped on the device: the captured iteration keeps replaying
         _refresh_views(self)
 

@@ -135,3 +135,55 @@ def test_store_with_fused_adam_and_edge_masks():
     store.append(_rows(10, 0, gen))
     _step(store.params, opt, 6)
     assert store.n == 10
+
+
+@pytest.mark.parametrize("stable", [True, False])
+def test_store_grows_beyond_its_capacity_like_the_references_unbounded_map(stable):
+    """GaussianStore.grow (the fused in-system map dropped a keyframe's Gaussians once its capacity was exhausted; the reference's map grows
+    without bound [REF scene/gaussian_model.py:474-492]).  A store that starts at 1 000 rows and is re-housed at 4 000 mid-run ends, after the same appends
+    and optimiser steps, on the SAME BITS — parameters, both moments, masks, step count — as a store that had the room from the start; the Parameter objects
+    and the optimiser's groups are the same objects before and after (only their storage moved), so learning rates and state carry over."""
+    from gs_icp_slam_amd.gaussian_store import GaussianStore
+    from gs_icp_slam_amd.optim import FusedAdam
+    out = {}
+    for name, cap0 in (("roomy", 4000), ("grown", 1000)):
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        st = GaussianStore(cap0, stable=stable)
+        st.append(_rows(600, 0, gen), trackable_mask=torch.rand(600, device="cuda", generator=gen) < 0.5)
+        opt = st.attach(FusedAdam, LRS, lr=0.0, eps=1e-15, capturable=stable)
+        ids = {k: id(v) for k, v in st.params.items()} if stable else None
+
+        def step(seed):
+            g = torch.Generator(device="cuda").manual_seed(seed)
+            for k in NAMES:
+                p = st.params[k]
+                full = torch.zeros_like(p)
+                if p.numel():
+                    full[: st.n] = torch.randn((st.n,) + tuple(p.shape[1:]), device="cuda", generator=g)
+                p.grad = full
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        for s_ in (1, 2, 3):
+            step(s_)
+        more = _rows(800, 0, gen)
+        tm = torch.rand(800, device="cuda", generator=gen) < 0.5
+        if st.n + 800 > st.capacity:
+            with pytest.raises(RuntimeError):
+                st.append(more, trackable_mask=tm)
+            ptr_before = st.params["xyz"].data_ptr()
+            assert st.grow(4000) and st.capacity == 4000 and not st.grow(2000)
+            assert st.params["xyz"].data_ptr() != ptr_before
+            if stable:
+                assert {k: id(v) for k, v in st.params.items()} == ids            # the same Parameter objects: the optimiser's groups are untouched
+                assert opt.state[st.params["xyz"]]["exp_avg"].data_ptr() == st._sets[0][("m", "xyz")].data_ptr()
+        st.append(more, trackable_mask=tm)
+        for s_ in (4, 5, 6):
+            step(s_)
+        torch.cuda.synchronize()
+        out[name] = ({k: st.live(k).clone() for k in NAMES}, {k: (st.view("m", k).clone(), st.view("v", k).clone()) for k in NAMES},
+                     st.trackable_mask.clone(), int(opt.state[st.params["xyz"]]["step"]), st.n)
+    assert out["roomy"][4] == out["grown"][4] == 1400 and out["roomy"][3] == out["grown"][3] == 6
+    assert torch.equal(out["roomy"][2], out["grown"][2])
+    for k in NAMES:
+        assert torch.equal(out["roomy"][0][k], out["grown"][0][k]), k
+        assert torch.equal(out["roomy"][1][k][0], out["grown"][1][k][0]) and torch.equal(out["roomy"][1][k][1], out["grown"][1][k][1]), k
