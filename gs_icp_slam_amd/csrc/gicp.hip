@@ -405,8 +405,10 @@ __device__ inline int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v
 // query falls back to scanning every point.  The result does not depend on the visiting order (total order on (d2, index)).
 constexpr int KNN_MAX_CELLS = 1 << 18;
 #ifndef KNN_H_AREA
-#define KNN_H_AREA 2.5f                     // cell edge in units of the estimated point spacing (surface / volume model)
-#define KNN_H_VOL 1.4f
+#define KNN_H_AREA 2.25f                    // cell edge in units of the estimated point spacing (surface / volume model).  Round 6 sweep on the steady-state frame
+                                            // (profiles/r06_knn_cell_size_sweep.json; the search is exact for any value): 1.0 .. 1.75 = 174 / 112 / 89 / 84 us of
+                                            // k-NN + covariances (second rings), 2.0 = 45.3, 2.25 = 45.8, 2.5 = 47.3 (rounds 1-5), 3.0 = 50.3: 2.25 keeps a margin to the cliff
+#define KNN_H_VOL 1.26f                     // (the same ratio to KNN_H_AREA as rounds 1-5: 1.4 / 2.5)
 #endif
 struct KnnGrid {
     float ox, oy, oz, h, inv_h;
