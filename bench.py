@@ -1078,7 +1078,7 @@ def main():
         traffic, traffic_src, note = None, None, ("working set (~60 MB) sits in the 256 MiB Infinity Cache: the HBM fraction is a formality; the kernel runs "
                                                   "~80 % VALU-busy and tracks the per-entry dependent chain (DESIGN 3.3)")
         if world == 1 and args.res == "replica" and P == 300_000:
-            for tag in ("r05", "r04", "r03", "r02", "r01"):   # PMC passes of this command, collected by tools/capture_profiles.sh (counters cannot be read in-process)
+            for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):   # PMC passes of this command, collected by tools/capture_profiles.sh (counters cannot be read in-process)
                 tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
                 if os.path.exists(tp):
                     tj = json.load(open(tp)).get("blend_backward")

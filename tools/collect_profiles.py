@@ -90,6 +90,8 @@ def main():
                  "bench_pair_survey", "bench_pair_basin", "bench_driver_cmd", "tracker_vs_map", "reference_run_fused_unlimit400", "reference_run_fused_limit30_300",
                  "reference_run_unlimit1500", "reference_run_fused_unlimit1500", "bench_trained_leg", "fused_pacing_sweep", "fused_pacing_sweep_v2",
                  "bench_mapper_only_emit_walk", "bench_mapper_only_legacy_backward", "bench_mapper_only_inkernel_bump"):
+        if name == "bench_trained_leg" and not os.path.exists(os.path.join(src, name + ".json")):
+            continue
         j = last_json_line(os.path.join(src, name + ".json"))
         if j is not None:
             json.dump(j, open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
