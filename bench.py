@@ -834,6 +834,7 @@ def main():
     rast = rasts[0]
 
     mg = None
+    capture_error = None
     mapper_iteration = eager_iteration
     if use_graph:
         # Single GPU: the whole iteration is one hipGraph launch (gs_icp_slam_amd/graph.py); the keyframe (camera + targets) is
@@ -845,13 +846,33 @@ def main():
         mg = MapperIterationGraph(params, optimizer, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=capacity,
                                   lambda_dssim=0.2, warmup=2, rasterizer_factory=factory)
         mg.set_view(rs.viewmatrix, rs.projmatrix, rs.campos, gt_color, gt_depth)
-        mg.capture()
-
-        def mapper_iteration():   # noqa: F811
-            v = views[view_i[0] % n_views]
-            view_i[0] += 1
-            mg.set_view(v["rs"].viewmatrix, v["rs"].projmatrix, v["rs"].campos, v["gt_color"], v["gt_depth"])
-            return mg.step(), mg.radii
+        # A capture that FAILS (round 5's took the whole process down from the process group's watchdog thread; graph.py now captures
+        # thread-locally behind a drained watchdog) must cost the graph, not the benchmark line: every rank falls back to the eager iteration together.
+        capture_error = None
+        try:
+            if os.environ.get("GSICP_BENCH_FAIL_CAPTURE") == "1":      # test hook (tests/test_bench_gpu.py): the fallback below, without a real failure
+                raise RuntimeError("GSICP_BENCH_FAIL_CAPTURE=1")
+            mg.capture()
+        except Exception as e:   # noqa: BLE001
+            capture_error = f"{type(e).__name__}: {e}"[:160]
+        if world > 1:
+            okc = torch.tensor([0.0 if capture_error else 1.0], device=dev)
+            dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+            if okc.item() != 1.0 and capture_error is None:
+                capture_error = "another rank's capture failed"
+        if capture_error is not None:
+            try:
+                mg.release()
+            except Exception:   # noqa: BLE001
+                pass
+            mg = None
+            torch.cuda.synchronize()
+        else:
+            def mapper_iteration():   # noqa: F811
+                v = views[view_i[0] % n_views]
+                view_i[0] += 1
+                mg.set_view(v["rs"].viewmatrix, v["rs"].projmatrix, v["rs"].campos, v["gt_color"], v["gt_depth"])
+                return mg.step(), mg.radii
 
     def step():
         if args.only == "tracker":
@@ -1502,7 +1523,7 @@ def main():
                                          if free_running else ("lockstep: both halves joined after every step" if worker is not None else "one half after the other")),
                        "mapper_iterations_in_flight": args.mapper_inflight, "cu_split": cu_split,
                        "mapper_iteration": (("one hipGraph replay per iteration" + (" (tile all-gather + gradient all-reduce captured inside)" if (world > 1 or force_coll) else ""))
-                                            if mg is not None else "eager launches from Python"),
+                                            if mg is not None else ("eager launches from Python" if capture_error is None else f"eager (capture failed: {capture_error})")),
                        "rccl_graph_probe": rccl_graph_probe,
                        "exchange_bytes_per_rank": ({"image_all_gather_chunk": mg.rasterizer.holder.last_image_bytes,
                                                     "gradient_all_reduce_block": mg.rasterizer.holder.last_volume_bytes}

@@ -45,3 +45,10 @@ def test_keyframes_mode_as_the_headline_on_a_one_rank_rccl_group_captured_in_the
     res = _bench(["--mp-mode", "keyframes", "--only", "mapper"], {"GSICP_BENCH_FORCE_COLLECTIVES": "1"})
     assert res["config"]["mp_mode"] == "keyframes" and res["legs"]["tile_sharded"]["value"] > 0 and res["value"] > 0
     assert "hipGraph" in res["config"]["mapper_iteration"]
+
+
+def test_a_failed_graph_capture_costs_the_graph_not_the_benchmark_line():
+    """a capture that fails must fall back to the eager iteration and say so in the line (round 5's aborted the process from the
+    process group's watchdog thread).  The failure is injected (GSICP_BENCH_FAIL_CAPTURE=1); the run completes, times eager iterations and names the reason."""
+    res = _bench(["--only", "mapper"], {"GSICP_BENCH_FAIL_CAPTURE": "1"})
+    assert res["config"]["mapper_iteration"].startswith("eager (capture failed: RuntimeError: GSICP_BENCH_FAIL_CAPTURE=1") and res["value"] > 0
