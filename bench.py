@@ -431,7 +431,7 @@ def main():
     ap.add_argument("--mapper-inflight", type=int, default=2, help="mapper iterations the host may have in flight (queued graph launches) inside a timed block")
     ap.add_argument("--no-reference-leg", action="store_true", help="skip the run of the reference's own two-process system (System FPS / ATE / PSNR keys)")
     ap.add_argument("--system-legs", action="store_true", help="all four runs of the reference's own two-process system on the drop-ins (400 frames clean + 300 frames "
-                    "noisy, each untouched and with SURVEY 8(f)'s rows applied: ~80 s); the default runs ONE 200-frame clean run of the untouched system")
+                    "noisy, each untouched and with SURVEY 8(f)'s rows applied: ~120 s); the default runs ONE 400-frame clean run of the untouched system")
     ap.add_argument("--all-legs", action="store_true", help="every diagnostic leg (lockstep, tracker call profile, both S-pairs, tracker vs map sizes, mapper across "
                     "keyframes, the TUM-shaped child run): minutes; the default runs the core legs only")
     ap.add_argument("--legs-file", default=os.environ.get("GSICP_BENCH_LEGS_FILE", os.path.join(ROOT, "bench_legs.json")),
@@ -439,7 +439,7 @@ def main():
     ap.add_argument("--full-line", action="store_true", help="print the full record on stdout instead of the compact contract line (tools; NOT for the driver)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (tracker-only, mapper-only, eager, drop-in reference loop)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--serial", action="store_true", help="run tracker and mapper back-to-back on one thread (default: concurrently)")
     ap.add_argument("--lockstep", action="store_true", help="join the tracker frame and the mapper iteration after EVERY step (round 1's timing loop) instead of "
                     "letting the two halves run their --steps steps at their own pace inside the timed block")
@@ -1338,7 +1338,7 @@ def main():
             lap("mapper_trained_map")
         # -- BASELINE configs[3]'s proxy: the same steady-state step at TUM's shape (640x480, 12 416-point noisy frames, gate 0.03, opacity threshold
         #    0.09 [REF tum.sh:135-142]) — a child run of this script, its contract line kept as the leg
-        if args.res == "replica" and os.environ.get("GSICP_BENCH_CHILD") != "1" and os.environ.get("GSICP_BENCH_TUM_LEG", "1") != "0" and (args.all_legs or os.environ.get("GSICP_BENCH_TUM_LEG") == "1"):
+        if args.res == "replica" and os.environ.get("GSICP_BENCH_CHILD") != "1" and os.environ.get("GSICP_BENCH_TUM_LEG", "1") != "0":
             import subprocess
             try:
                 pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--res", "tum", "--no-legs", "--no-cpu-baseline", "--full-line", "--legs-file", "/tmp/gsicp_bench_legs_tum_child.json", "--steps", str(args.steps),
@@ -1367,7 +1367,7 @@ def main():
             oc.reg.set_num_threads(thr)
             oc.step()
             n, t0c = 0, time.perf_counter()
-            while time.perf_counter() - t0c < 0.6:
+            while time.perf_counter() - t0c < 0.4:
                 oc.step()
                 n += 1
             r_ = n / (time.perf_counter() - t0c)
@@ -1425,7 +1425,8 @@ def main():
             rj["leg_wall_s"] = round(time.perf_counter() - t0r, 1)
             return rj
         if not args.system_legs:
-            ref_run = system_run(200)       # default: ONE short clean run of the untouched system (System FPS / ATE / PSNR of the compact line)
+            ref_run = system_run(400)       # default: ONE clean run of the untouched system (System FPS / ATE / PSNR of the compact line; the same 400-frame
+            #                                 sequence rounds 3-5 reported: a 200-frame run is dominated by the start-up of the three processes, 111 against 178 FPS)
         else:
             ref_run = system_run(400)
             # the same run with SURVEY 8(f)'s rows applied to the reference's files (oracle/make_refpy.py --fused; gs_icp_slam_amd/refglue.py)
