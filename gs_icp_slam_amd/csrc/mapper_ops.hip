@@ -677,6 +677,22 @@ __global__ __launch_bounds__(64) void select_view_kernel(const float* __restrict
     else if (t == 36) d_slots[1] = gt_depth;
 }
 
+// Round 6: the same launch also clears the per-call counter region of the CAPTURED rasteriser forward that follows it (`zero_words` 4-byte words at `zero`: per-tile counts,
+// cursors, the slot / visible counters — 6.5 k words at 1200x680), so that the forward inside the graph needs no zero-fill launch of its own (4.9 us of launch floor per
+// iteration; its is_used array is cleared by the preprocess kernel).  One 256-thread workgroup.
+__global__ __launch_bounds__(256) void select_view_zero_kernel(const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+                                                              const float* gt_image, const float* gt_depth, float* __restrict__ d_view,
+                                                              float* __restrict__ d_proj, float* __restrict__ d_campos, const float** __restrict__ d_slots,
+                                                              uint32_t* __restrict__ zero, size_t zero_words) {
+    const int t = threadIdx.x;
+    if (t < 16) d_view[t] = view[t];
+    else if (t < 32) d_proj[t - 16] = proj[t - 16];
+    else if (t < 35) d_campos[t - 32] = campos[t - 32];
+    else if (t == 35) d_slots[0] = gt_image;
+    else if (t == 36) d_slots[1] = gt_depth;
+    for (size_t i = (size_t)t; i < zero_words; i += 256) zero[i] = 0u;
+}
+
 // ------------------------------------------------------------------------------------------------ Adam
 constexpr int ADAM_MAX_GROUPS = 8;
 struct AdamTable {
@@ -1238,6 +1254,20 @@ int gsicp_mapper_select_view(const float* viewmatrix, const float* projmatrix, c
     hipLaunchKernelGGL(select_view_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, viewmatrix, projmatrix, campos, gt_image, gt_depth, dst_viewmatrix,
                        dst_projmatrix, dst_campos, dst_gt_slots);
     if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_select_view: kernel launch failed"; return -1; }
+    return 0;
+}
+
+int gsicp_mapper_select_view_zero(const float* viewmatrix, const float* projmatrix, const float* campos, const float* gt_image, const float* gt_depth,
+                                  float* dst_viewmatrix, float* dst_projmatrix, float* dst_campos, const float** dst_gt_slots, void* zero_region,
+                                  size_t zero_words, void* stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (!viewmatrix || !projmatrix || !campos || !gt_image || !gt_depth || !dst_viewmatrix || !dst_projmatrix || !dst_campos || !dst_gt_slots || (zero_words && !zero_region)) {
+        g_last_error = "gsicp_mapper_select_view_zero: NULL argument"; return -2;
+    }
+    if (zero_words > (size_t)1 << 22) { g_last_error = "gsicp_mapper_select_view_zero: zero region above 16 MB (not a rasteriser counter region)"; return -2; }
+    hipLaunchKernelGGL(select_view_zero_kernel, dim3(1), dim3(256), 0, stream, viewmatrix, projmatrix, campos, gt_image, gt_depth, dst_viewmatrix, dst_projmatrix,
+                       dst_campos, dst_gt_slots, (uint32_t*)zero_region, zero_words);
+    if (hipGetLastError() != hipSuccess) { g_last_error = "gsicp_mapper_select_view_zero: kernel launch failed"; return -1; }
     return 0;
 }
 

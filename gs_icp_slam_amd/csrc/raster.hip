@@ -39,6 +39,9 @@
 namespace gsicp {
 
 thread_local std::string g_last_error;
+// the counter region (inside the caller's img scratch) of this thread's LAST forward call: gsicp_raster_last_zero_region (pre-zeroed forward, round 6)
+static thread_local void* g_last_zero_ptr = nullptr;
+static thread_local size_t g_last_zero_words = 0;
 
 // ------------------------------------------------------------------------------------------------ profiler
 namespace {
@@ -901,6 +904,11 @@ using namespace gsicp;
 extern "C" {
 
 int gsicp_abi_version(void) { return GSICP_ABI_VERSION; }
+int gsicp_raster_last_zero_region(void** ptr, size_t* words) {
+    if (!ptr || !words) return -2;
+    *ptr = g_last_zero_ptr; *words = g_last_zero_words;
+    return g_last_zero_ptr ? 0 : -1;
+}
 const char* gsicp_last_error(void) { return g_last_error.c_str(); }
 int gsicp_device_count(void) {
     int n = 0;
@@ -943,9 +951,13 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
                          float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii,
                          int* is_used, int tile_mod, int tile_rem, int debug, int depth_mode, int capacity, unsigned int* num_rendered_dev,
                          const int* live_rows, int raw_params, void* stream_v) {
-    (void)prefiltered; (void)debug;
+    (void)prefiltered;
     if (depth_mode < 0 || depth_mode > 1) { g_last_error = "depth_mode: 0 = sum z alpha T, 1 = alpha-normalised"; return -2; }
     const bool async = capacity > 0 && P > 0;   // capacity given: no host round trip, R stays on the device
+    // PRE-ZEROED forward (round 6; `debug` bit 1, sync-free path only): the caller guarantees that this call's counter region — the one the previous call with the
+    // same buffers reported through gsicp_raster_last_zero_region — has been cleared in stream order ahead of this call (gsicp_mapper_select_view_zero: the
+    // keyframe-selection launch of a captured mapper iteration does it); no zero-fill launch here, and the preprocess kernel clears is_used.
+    const bool prezeroed = async && (debug & 2) != 0;
     if (capacity > (int)ID_MASK) { g_last_error = "capacity above 2^28 duplicates is not supported"; return -2; }
     hipStream_t stream = (hipStream_t)stream_v;
     if (width <= 0 || height <= 0 || P < 0) { g_last_error = "gsicp_raster_forward: bad sizes"; return -2; }
@@ -977,7 +989,8 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
     uint32_t* tiles_touched = (uint32_t*)(geom + GL.tiles_touched);
     uint32_t* slot_base = (uint32_t*)(geom + GL.slot_base);
 
-    {
+    g_last_zero_ptr = tile_count; g_last_zero_words = (size_t)2 * T + 64;
+    if (!prezeroed) {
         const size_t n_used = (is_used && P > 0) ? (size_t)P : 0;
         size_t blocks = (n_used + (size_t)2 * T + 64 + 255) / 256;
         if (blocks > 1024) blocks = 1024;
@@ -996,6 +1009,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
         pa.tiles_touched = tiles_touched; pa.slot_base = slot_base; pa.total_counter = total_counter;
         pa.vis_list = (uint32_t*)(geom + GL.vis_list); pa.vis_counter = total_counter + 1;
         pa.radii = radii;
+        pa.is_used_zero = prezeroed ? is_used : nullptr;
         { ProfileScope ps(ST_PREPROCESS, stream); launch_preprocess(pa, stream); }
         if (async) {
             num_rendered = capacity;   // buffer layouts and launch grids are sized by the capacity; kernels read the true R

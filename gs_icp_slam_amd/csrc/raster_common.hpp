@@ -125,6 +125,8 @@ struct PreprocessArgs {
     uint32_t* vis_list;        // optional: ids of the Gaussians with radii > 0, compacted ...
     uint32_t* vis_counter;     // ... and their number (zeroed with total_counter)
     int* radii;
+    int* is_used_zero;         // optional (pre-zeroed forward, round 6): thread i clears is_used[i] here — the blend kernel sets it later —, so that the forward needs no
+                               // zero-fill launch when its per-call counters were cleared ahead of it (gsicp_mapper_select_view_zero)
 };
 static_assert(sizeof(SplatRec) == 48, "SplatRec must stay 48 bytes");
 

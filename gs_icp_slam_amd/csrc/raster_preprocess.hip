@@ -161,6 +161,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreprocessArgs a) {
     // defaults for a culled Gaussian
     a.radii[idx] = 0;
     a.clamped[idx] = 0;
+    if (a.is_used_zero) a.is_used_zero[idx] = 0;
     SplatRec rec = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     const float p[3] = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};

@@ -149,6 +149,13 @@ class MapperIterationGraph:
         # advances the step counter and the Adam launch runs `step_already_bumped` (no one-thread bump launch: 4.1 us per iteration).  The shared guard
         # of the multi-GPU exchange is only known after the backward: there the bump launch stays.  GSICP_STEP_BUMP_IN_LOSS=0 switches it off (A/B).
         self._bump_in_loss = shared_guard is None and os.environ.get("GSICP_STEP_BUMP_IN_LOSS", "1") != "0"
+        # PRE-ZEROED forward (round 6): the captured forward replays with the same scratch buffers, so the counter region it would clear with a launch of its own is
+        # cleared by the keyframe-selection launch that precedes every replay anyway (gsicp_mapper_select_view_zero; 4.9 us of launch floor per iteration, 15 -> 14
+        # kernel nodes).  The region is read from the library right after the capture; step() re-issues the selection when no set_view() came since the last replay.
+        # GSICP_PREZERO=0 switches it off (A/B).
+        self._prezero = os.environ.get("GSICP_PREZERO", "1") != "0"
+        self._zero_region = None        # (pointer, 4-byte words) of the captured forward's counter region
+        self._view_fresh = False        # a selection launch has been issued since the last replay
         # The guard and the live-row count are bound to the optimiser only WHILE this graph's launches are issued (capture(), warm-up included)
         # and what was bound before is restored afterwards: an eager step() on the same optimiser later is gated by whatever ITS
         # caller bound (GaussianStore.attach binds the store's live count), not by the count the last replay happened to leave behind.
@@ -189,19 +196,31 @@ class MapperIterationGraph:
             self._gt_stage[0].copy_(gt_image.reshape(self._gt_stage[0].shape), non_blocking=True)
             self._gt_stage[1].copy_(gt_depth.reshape(self._gt_stage[1].shape), non_blocking=True)
             gt_image, gt_depth = self._gt_stage
-        lib = _lib.load()
-        p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
-        with torch.cuda.device(dev):
-            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.gsicp_mapper_select_view(p(viewmatrix), p(projmatrix), p(campos), p(gt_image), p(gt_depth), p(self.viewmatrix),
-                                                    p(self.projmatrix), p(self.campos), p(self.gt_slots), stream), "gsicp_mapper_select_view")
         self._gt_refs = (viewmatrix, projmatrix, campos, gt_image, gt_depth)
+        self._select()
         cur = torch.cuda.current_stream(dev)
         for t in self._gt_refs:
             t.record_stream(cur)            # the caching allocator must not hand this memory to another stream while the replay may still read it
         self._gt_ring.append(self._gt_refs)
         if len(self._gt_ring) > self._gt_ring_depth:
             self._gt_ring.pop(0)
+
+    def _select(self):
+        """The keyframe-selection launch for the tensors of the last set_view(); with a captured, pre-zeroed forward it also clears that forward's counter region."""
+        viewmatrix, projmatrix, campos, gt_image, gt_depth = self._gt_refs
+        dev = self.gt_slots.device
+        lib = _lib.load()
+        p = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if self._zero_region is not None:
+                _lib.check(lib.gsicp_mapper_select_view_zero(p(viewmatrix), p(projmatrix), p(campos), p(gt_image), p(gt_depth), p(self.viewmatrix), p(self.projmatrix),
+                                                             p(self.campos), p(self.gt_slots), ctypes.c_void_p(self._zero_region[0]), self._zero_region[1], stream),
+                           "gsicp_mapper_select_view_zero")
+            else:
+                _lib.check(lib.gsicp_mapper_select_view(p(viewmatrix), p(projmatrix), p(campos), p(gt_image), p(gt_depth), p(self.viewmatrix),
+                                                        p(self.projmatrix), p(self.campos), p(self.gt_slots), stream), "gsicp_mapper_select_view")
+        self._view_fresh = True
 
     def _iteration(self):
         if self._fused_activations:
@@ -287,14 +306,27 @@ class MapperIterationGraph:
         torch.cuda.synchronize(dev)
         drain_process_group_watchdog(dev)
         self.graph = torch.cuda.CUDAGraph()
+        self._zero_region = None
+        inner = self.rasterizer.inner if hasattr(self.rasterizer, "inner") else self.rasterizer
+        plain_settings = inner.raster_settings
         try:
+            if self._prezero:      # the CAPTURED forward only: the warm-up iterations above cleared their own (per-call) scratch
+                inner.raster_settings = plain_settings._replace(prezeroed=True)
             with torch.cuda.graph(self.graph, capture_error_mode=capture_mode()):
                 parts, radii, used = self._iteration()
+            if self._prezero:      # this thread's last forward call IS the captured one: its counter region keeps its address for the life of the graph
+                ptr, words = ctypes.c_void_p(), ctypes.c_size_t()
+                _lib.check(_lib.load().gsicp_raster_last_zero_region(ctypes.byref(ptr), ctypes.byref(words)), "gsicp_raster_last_zero_region")
+                self._zero_region = (int(ptr.value), int(words.value))
         except Exception:
             self.graph = None       # a failed capture leaves no half-built graph behind: the caller may fall back to eager iterations
+            self._zero_region = None
             self.optimizer.zero_grad(set_to_none=True)
             self._means2D.grad = None
             raise
+        finally:
+            inner.raster_settings = plain_settings
+        self._view_fresh = False     # the first replay needs a selection launch that also clears the region
         self.loss_parts, self.radii, self.is_used = parts, radii, used
         self.num_rendered = self.rasterizer.num_rendered if hasattr(self.rasterizer, "num_rendered") else None
         if self.num_rendered is None and hasattr(self.rasterizer, "inner"):
@@ -305,7 +337,10 @@ class MapperIterationGraph:
         """Replay one iteration (one graph launch).  Returns the static loss tensor (0-dim view; read it when needed)."""
         if self.graph is None:
             self.capture()
+        if self._zero_region is not None and not self._view_fresh:
+            self._select()          # no set_view() since the last replay: the same keyframe again — and the counter region cleared
         self.graph.replay()
+        self._view_fresh = False
         return self.loss_parts[0]
 
     def release(self):
@@ -315,6 +350,7 @@ class MapperIterationGraph:
             torch.cuda.synchronize(self.params["means3D"].device)
             self.graph.reset()
             self.graph = None
+            self._zero_region = None
 
     def overflowed(self):
         """True when the last replay produced more duplicates than the capacity (it then rendered nothing and its optimiser step was

@@ -52,6 +52,9 @@ class GaussianRasterizationSettings(NamedTuple):
     # they are zero by definition and the consumer takes that from `radii` (FusedAdam.set_grad_row_mask; gs_icp_slam_amd/graph.py sets both).  Only for
     # callers that own every reader of the gradients: with the default (False) every row of every gradient is written, as the reference's backward does.
     sparse_grads: bool = False
+    # Extension (round 6): the forward's per-call counter region has been cleared ahead of this call, in stream order (include/gsicp_hip.h "PRE-ZEROED forward"): no
+    # zero-fill launch.  Set by gs_icp_slam_amd/graph.py on the CAPTURED forward only; needs capacity > 0.
+    prezeroed: bool = False
 
 
 def _ptr(t):
@@ -119,8 +122,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             args = (geom.cb, None, binning.cb, None, img.cb, None, P, int(rs.sh_degree), int(M), _ptr(bg), W, H, _ptr(means3D),
                     _ptr(sh_c), _ptr(col_c), _ptr(op_c), _ptr(sc_c), float(rs.scale_modifier), _ptr(rot_c), _ptr(cov_c), _ptr(view),
                     _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)), _ptr(color),
-                    _ptr(depth), _ptr(radii), _ptr(is_used), int(rs.tile_mod), int(rs.tile_rem), int(bool(rs.debug)),
-                    int(getattr(rs, "depth_mode", 0) or 0))
+                    _ptr(depth), _ptr(radii), _ptr(is_used), int(rs.tile_mod), int(rs.tile_rem),
+                    int(bool(rs.debug)) | (2 if getattr(rs, "prezeroed", False) else 0), int(getattr(rs, "depth_mode", 0) or 0))
             capacity = int(getattr(rs, "capacity", 0) or 0)
             live = getattr(rs, "live_count", None)
             if live is not None and not (capacity > 0 and P > 0):

@@ -305,6 +305,18 @@ int gsicp_mapper_set_view(int width, int height, const float* viewmatrix, const 
  * [REF mp_Mapper.py:147, 175]. */
 int gsicp_mapper_select_view(const float* viewmatrix, const float* projmatrix, const float* campos, const float* gt_image, const float* gt_depth,
                              float* dst_viewmatrix, float* dst_projmatrix, float* dst_campos, const float** dst_gt_slots, void* stream);
+/* PRE-ZEROED forward (ABI 5, round 6): a captured mapper iteration replays the SAME rasteriser forward with the SAME scratch buffers, so the region the forward clears
+ * at its start (per-tile counts and cursors, the slot / visible counters) can be cleared ahead of it by the keyframe-selection launch that precedes every replay anyway:
+ *   gsicp_raster_last_zero_region   -> the counter region (pointer, 4-byte words) of this thread's last gsicp_raster_forward{,_async} call; the caller of a CAPTURE
+ *                                      reads it right after the captured forward call (the buffers of a hipGraph keep their addresses);
+ *   gsicp_mapper_select_view_zero   =  gsicp_mapper_select_view + a clear of that region, one 256-thread launch;
+ *   gsicp_raster_forward_async(debug | 2)  skips its zero-fill launch (the preprocess kernel clears `is_used`).  The caller guarantees that the clear is ordered,
+ *                                      on the same stream, between the previous use of the buffers and this call.
+ * gs_icp_slam_amd/graph.py does all three (15 -> 14 kernel nodes per captured iteration); every other caller keeps the self-contained forward. */
+int gsicp_raster_last_zero_region(void** ptr, size_t* words);
+int gsicp_mapper_select_view_zero(const float* viewmatrix, const float* projmatrix, const float* campos, const float* gt_image, const float* gt_depth,
+                                  float* dst_viewmatrix, float* dst_projmatrix, float* dst_campos, const float** dst_gt_slots, void* zero_region,
+                                  size_t zero_words, void* stream);
 /* gsicp_mapper_loss / gsicp_mapper_loss_sharded (tile_mod > 1) with the ground-truth images taken from gt_slots[0] (3,H,W) and gt_slots[1] (1,H,W),
  * read ON THE DEVICE when the kernels start. */
 int gsicp_mapper_loss_indirect(const float* image, const float* depth, const float* const* gt_slots, int width, int height, float lambda_dssim,

@@ -538,16 +538,17 @@ def test_sparse_backward_leaves_the_visible_rows_bit_identical():
 
 
 def test_captured_iteration_is_bit_identical_with_and_without_sparse_gradients_and_the_bump_in_the_loss(monkeypatch):
-    """The captured mapper iteration of round 6 (sparse gradient rows, the step bump inside the loss kernel: 15 kernel nodes) against the same iteration with
-    both switched off (GSICP_SPARSE_GRADS=0, GSICP_STEP_BUMP_IN_LOSS=0: zero-filled gradients, the one-thread bump launch): identical parameters, moments,
-    step counts and losses after replays over two views, one of them with the guard tripped."""
+    """The captured mapper iteration of round 6 (sparse gradient rows, the step bump inside the loss kernel, the forward's counters cleared by the keyframe-selection
+    launch: 14 kernel nodes) against the same iteration with all three switched off (GSICP_SPARSE_GRADS=0, GSICP_STEP_BUMP_IN_LOSS=0, GSICP_PREZERO=0: zero-filled
+    gradients, the one-thread bump launch, the forward's own zero fill): identical parameters, moments, step counts, losses, radii, is_used and duplicate counts after
+    replays over two views — one of them without a set_view() in front."""
     from diff_gaussian_rasterization import GaussianRasterizer
     from gs_icp_slam_amd.graph import MapperIterationGraph
     P, W, H = 20000, 320, 200
     views = None
     res = {}
     for mode in ("new", "old"):
-        for k in ("GSICP_SPARSE_GRADS", "GSICP_STEP_BUMP_IN_LOSS"):
+        for k in ("GSICP_SPARSE_GRADS", "GSICP_STEP_BUMP_IN_LOSS", "GSICP_PREZERO"):
             if mode == "old":
                 monkeypatch.setenv(k, "0")
             else:
@@ -564,20 +565,23 @@ def test_captured_iteration_is_bit_identical_with_and_without_sparse_gradients_a
                                                           opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
                 views.append((rs_k, c.clone(), d.clone()))
         mg = MapperIterationGraph(params, opt, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=2_000_000, warmup=2)
-        assert mg._sparse == (mode == "new") and mg._bump_in_loss == (mode == "new")
+        assert mg._sparse == (mode == "new") and mg._bump_in_loss == (mode == "new") and mg._prezero == (mode == "new")
         mg.set_view(views[0][0].viewmatrix, views[0][0].projmatrix, views[0][0].campos, views[0][1], views[0][2])
         mg.capture()
+        assert (mg._zero_region is not None) == (mode == "new")      # the captured forward's counter region, cleared by the selection launch instead of a launch of its own
         losses = []
         for k in (0, 1, 1, 0, 1):
             rs_k, gt_c, gt_d = views[k]
             mg.set_view(rs_k.viewmatrix, rs_k.projmatrix, rs_k.campos, gt_c, gt_d)
             losses.append(float(mg.step()))
+        losses.append(float(mg.step()))          # a replay WITHOUT a set_view() in front: the same keyframe again (the selection launch is re-issued)
         torch.cuda.synchronize()
         res[mode] = (losses, {k: v.detach().clone() for k, v in params.items()},
                      {k: (opt.state[v]["exp_avg"].clone(), opt.state[v]["exp_avg_sq"].clone()) for k, v in params.items()},
-                     int(opt.state[params["means3D"]]["step"].item()), mg.skipped_steps())
+                     int(opt.state[params["means3D"]]["step"].item()), mg.skipped_steps(), mg.is_used.clone(), mg.radii.clone(), int(mg.num_rendered.item()))
         mg.release()
-    assert res["new"][0] == res["old"][0] and res["new"][3] == res["old"][3] == 5 and res["new"][4] == res["old"][4] == 0
+    assert res["new"][0] == res["old"][0] and res["new"][3] == res["old"][3] == 6 and res["new"][4] == res["old"][4] == 0
+    assert torch.equal(res["new"][5], res["old"][5]) and torch.equal(res["new"][6], res["old"][6]) and res["new"][7] == res["old"][7] > 0    # is_used, radii, duplicate count
     for k in res["new"][1]:
         assert torch.equal(res["new"][1][k], res["old"][1][k]), k
         assert torch.equal(res["new"][2][k][0], res["old"][2][k][0]) and torch.equal(res["new"][2][k][1], res["old"][2][k][1]), k
