@@ -1355,7 +1355,7 @@ def main():
 
     # ---------------- CPU baseline: OpenMP GICP oracle (port), rank 0 only ----------------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and args.only != "mapper":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.only != "mapper":     # (N = 1 only: at N > 1 the other ranks would wait 20 s at the next collective)
         import oracle
         oc = SteadyTracker(oracle.OracleGICP(), host=True) if steady else TrackerCase(args.pair, oracle.OracleGICP())
         oc.step()  # warm-up (thread pool, first touch)
