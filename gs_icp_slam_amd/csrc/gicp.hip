@@ -1417,6 +1417,8 @@ struct AlignArgs {
     HostMailbox* mailbox;      // pinned host memory
     unsigned seq;              // this launch's sequence number
     unsigned long long* trace; // diagnostics (GSICP_ALIGN_TRACE): wall_clock64 stamps of workgroup 0 at phase boundaries, or NULL
+    int wave_prio;             // round 6 (GSICP_TRACKER_WAVE_PRIO): s_setprio level of this kernel's waves — next to the mapper's throughput waves on the same SIMDs the
+                               // tracker's 33 latency-critical workgroups win the issue arbitration (every grid-wide phase ends when the slowest workgroup arrives)
 };
 
 __device__ inline double wave_sum_d(double v) {
@@ -1863,6 +1865,9 @@ __device__ __forceinline__ void linearize_points(const AlignArgs& a, const doubl
 // zero; values 0..27 go through the same folds and adds as before, so every bit is unchanged.  Half the code (the search alone is
 // ~1 k instructions), which keeps the kernel inlined as a whole.
 __global__ __launch_bounds__(AL_T) void gicp_align_kernel(AlignArgs a) {
+    if (a.wave_prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (a.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
     __shared__ AlignShared sh;
     __shared__ uint2 s_queue[26 * AL_T];     // grid_nn's per-lane work list of non-empty neighbour cells: entry k of thread t at [k * AL_T + t]
     static_assert(AL_T == AL_T_CONST, "grid_nn's work-list stride");
@@ -2921,6 +2926,8 @@ int gsicp_gicp_align(gsicp_gicp* g, const double* init, double* out) {
     a.trace = nullptr;
     if (trace_on) { if (g->trace.ensure(512)) { g_last_error = "hipMalloc failed"; return -1; } a.trace = g->trace.p; }
     a.miss_counter = g->counters.p;
+    static const int wave_prio = [] { const char* v = std::getenv("GSICP_TRACKER_WAVE_PRIO"); const int p = v ? std::atoi(v) : 0; return p < 0 ? 0 : (p > 3 ? 3 : p); }();
+    a.wave_prio = wave_prio;
     a.mailbox = g->mailbox; a.seq = ++g->seq;
     int nwg = (s.n_track + AL_T - 1) / AL_T;
     if (nwg < 1) nwg = 1;
