@@ -408,10 +408,12 @@ __global__ __launch_bounds__(1024) void split_scatter_kernel(const uint32_t* __r
 template <int THREADS>
 __device__ inline void bitonic_pairs(unsigned long long* __restrict__ s_key, uint32_t* __restrict__ s_val, int npad, int tid) {
     const int half = npad >> 1;
-    for (int k = 2; k <= npad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    int lk = 1;                                   // log2(k)
+    for (int k = 2; k <= npad; k <<= 1, ++lk) {
+        int lj = lk - 1;                          // log2(j): j is a power of two, so p / j and p % j are a shift and a mask (round 6: the compiler cannot know
+        for (int j = k >> 1; j > 0; j >>= 1, --lj) {   // that and emitted a 32-bit integer division per compare-exchange: 24.2 -> 21.1 us S-map, 62.5 -> 52.8 trained)
             for (int p = tid; p < half; p += THREADS) {
-                const int i = 2 * j * (p / j) + (p % j), l = i + j;
+                const int i = ((p >> lj) << (lj + 1)) | (p & (j - 1)), l = i + j;
                 const unsigned long long a = s_key[i], b = s_key[l];
                 const bool up = (i & k) == 0;
                 if ((a > b) == up) {
