@@ -56,6 +56,7 @@ SIGNATURES = {
     "gsicp_mapper_select_view": (c_int, [c_void_p] * 10),
     "gsicp_mapper_select_view_zero": (c_int, [c_void_p] * 10 + [c_size_t, c_void_p]),
     "gsicp_raster_last_zero_region": (c_int, [c_void_p, c_void_p]),
+    "gsicp_raster_set_tile_sort_lds": (c_int, [c_int]),
     "gsicp_mapper_loss_indirect": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
     "gsicp_mapper_loss_indirect_bump": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p,

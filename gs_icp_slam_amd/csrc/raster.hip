@@ -39,6 +39,10 @@
 namespace gsicp {
 
 thread_local std::string g_last_error;
+static std::atomic<int>& tile_sort_lds_flag() {     // GSICP_TILE_SORT_LDS=1 / gsicp_raster_set_tile_sort_lds: the all-LDS sorting network of rounds 2-5
+    static std::atomic<int> v([] { const char* e = getenv("GSICP_TILE_SORT_LDS"); return (e && e[0] == '1') ? 1 : 0; }());
+    return v;
+}
 // the counter region (inside the caller's img scratch) of this thread's LAST forward call: gsicp_raster_last_zero_region (pre-zeroed forward, round 6)
 static thread_local void* g_last_zero_ptr = nullptr;
 static thread_local size_t g_last_zero_words = 0;
@@ -477,11 +481,48 @@ __device__ inline uint32_t refine_block_bits(const uint32_t word, const SplatRec
     return (word & ID_MASK) | (out << STRIP_SHIFT);
 }
 
+
+// ---- Round 6: the tile sort's wave-local steps IN REGISTERS ------------------------------------------------------------------------------------------
+// A wave owns 128-element blocks of the padded list; lane l holds elements 64 h + l (h = 0, 1) of a block as (64-bit key, list word).  Every compare-exchange
+// with partner distance j < 64 is then a lane exchange (quad permutes, bank-masked row rotates, gfx950's v_permlane16/32_swap — no LDS round trip, no barrier),
+// j = 64 is a swap between a lane's own two elements, and only the steps with j >= 128 (none for lists up to 128 entries, 1 / 3 / 6 of the 36 / 45 / 55 steps at
+// 256 / 512 / 1024) go through LDS.  Same network, same total order on (depth bits, Gaussian id): the lists are the same bits.
+typedef unsigned ts_uint2 __attribute__((ext_vector_type(2)));
+template <int J>
+__device__ __forceinline__ unsigned ts_lane_xor(unsigned v) {      // value of lane (l ^ J)
+    const int iv = (int)v;
+    if constexpr (J == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, iv, 0x12C, 0xF, 0xF, true);                            // row_ror 12: lane l <- (l + 4) mod 16, right for banks 0, 2
+        return (unsigned)__builtin_amdgcn_update_dpp(t, iv, 0x124, 0xF, 0xA, false);                        // banks 1, 3: row_ror 4, lane l <- l - 4
+    } else if constexpr (J == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, iv, 0x128, 0xF, 0xF, true);   // row_ror 8
+    else if constexpr (J == 16) {
+        const ts_uint2 r = __builtin_amdgcn_permlane16_swap(v, v, false, false);    // x: rows (0, 0, 2, 2) of v, y: rows (1, 1, 3, 3)
+        return __builtin_amdgcn_inverse_ballot_w64(0xFFFF0000FFFF0000ull) ? r.x : r.y;
+    } else {
+        static_assert(J == 32, "ts_lane_xor: unsupported pattern");
+        const ts_uint2 r = __builtin_amdgcn_permlane32_swap(v, v, false, false);    // x: lower half of v twice, y: upper half twice
+        return __builtin_amdgcn_inverse_ballot_w64(0xFFFFFFFF00000000ull) ? r.x : r.y;
+    }
+}
+// one compare-exchange of element (key, val) with the same element slot of lane (lane ^ J); `up`: this element's merge block sorts ascending
+template <int J>
+__device__ __forceinline__ void ts_cx_lane(unsigned long long& key, uint32_t& val, const bool up, const int lane) {
+    const unsigned long long pk = ((unsigned long long)ts_lane_xor<J>((unsigned)(key >> 32)) << 32) | (unsigned long long)ts_lane_xor<J>((unsigned)key);
+    const uint32_t pv = ts_lane_xor<J>(val);
+    const bool keep_min = (((lane & J) == 0) == up);
+    const bool take = keep_min ? (pk < key) : (pk > key);
+    key = take ? pk : key;
+    val = take ? pv : val;
+}
+
 template <int CAP, int THREADS, int MIN_N>
 __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uint32_t* __restrict__ s_val, const uint32_t tile,
                                      const uint2* __restrict__ ranges, const uint4* __restrict__ sc_pack,
                                      uint32_t* __restrict__ point_list,
-                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ list_gauss, const SplatRec* __restrict__ rec, const int gx) {
+                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ list_gauss, const SplatRec* __restrict__ rec, const int gx,
+                                     const int lds_only) {
     const uint2 range = ranges[tile];
     const float tile_x0 = (float)((int)(tile % (uint32_t)gx) * TILE), tile_y0 = (float)((int)(tile / (uint32_t)gx) * TILE);
     const int n = (int)(range.y - range.x);
@@ -540,6 +581,107 @@ __device__ inline void tile_sort_one(unsigned long long* __restrict__ s_key, uin
     }
     int npad = 64;
     while (npad < n) npad <<= 1;
+    if (THREADS == 256 && CAP == 1024 && !lds_only) {
+        // ---- register path (round 6): blocks of 128 elements per wave, block b = wave + 4 r (r = 0, 1); element e = 128 b + 64 h + lane
+        const int lane = tid & 63, wave = tid >> 6;
+        unsigned long long key[2][2];
+        uint32_t val[2][2];
+        bool act[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            act[r] = 128 * (wave + 4 * r) < npad;                 // wave-uniform
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 128 * (wave + 4 * r) + 64 * h + lane;
+                key[r][h] = ~0ull; val[r][h] = 0u;
+                if (act[r] && e < n) {
+                    const uint4 w = sc_pack[range.x + e];
+                    val[r][h] = w.y;
+                    key[r][h] = ((unsigned long long)w.x << 32) | w.z;
+                }
+            }
+        }
+        // compare-exchange steps with partner distance j = jmax, jmax / 2, .. 1 (jmax <= 64) at merge size k, on every active element
+        auto reg_steps = [&](const int k, const int jmax) {
+            if (jmax >= 64) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (!act[r]) continue;
+                    const bool up = ((128 * (wave + 4 * r)) & k) == 0;    // (k >= 128 here: the direction is the block's)
+                    const bool sw = (key[r][0] > key[r][1]) == up;
+                    const unsigned long long k0 = key[r][0]; const uint32_t v0 = val[r][0];
+                    key[r][0] = sw ? key[r][1] : k0; val[r][0] = sw ? val[r][1] : v0;
+                    key[r][1] = sw ? k0 : key[r][1]; val[r][1] = sw ? v0 : val[r][1];
+                }
+            }
+#define GSICP_TS_STEP(J)                                                                                              \
+            if (jmax >= J) {                                                                                          \
+                _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                       \
+                    if (!act[r]) continue;                                                                            \
+                    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                   \
+                        const int e = 128 * (wave + 4 * r) + 64 * h + lane;                                           \
+                        ts_cx_lane<J>(key[r][h], val[r][h], (e & k) == 0, lane);                                      \
+                    }                                                                                                 \
+                }                                                                                                     \
+            }
+            GSICP_TS_STEP(32) GSICP_TS_STEP(16) GSICP_TS_STEP(8) GSICP_TS_STEP(4) GSICP_TS_STEP(2) GSICP_TS_STEP(1)
+#undef GSICP_TS_STEP
+        };
+        const int kreg = npad < 128 ? npad : 128;
+        for (int k = 2; k <= kreg; k <<= 1) reg_steps(k, k >> 1);            // every 128-block sorted (alternating directions) without touching LDS
+        for (int k = 256; k <= npad; k <<= 1) {                              // merges across blocks: the steps with j >= 128 through LDS, the rest in registers again
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (!act[r]) continue;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 128 * (wave + 4 * r) + 64 * h + lane;
+                    s_key[e] = key[r][h]; s_val[e] = val[r][h];
+                }
+            }
+            __syncthreads();
+            const int half = npad >> 1;
+            int lj = 31 - __builtin_clz((unsigned)(k >> 1));
+            for (int j = k >> 1; j >= 128; j >>= 1, --lj) {
+                for (int p = tid; p < half; p += THREADS) {
+                    const int i = ((p >> lj) << (lj + 1)) | (p & (j - 1)), l = i + j;
+                    const unsigned long long a = s_key[i], b = s_key[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s_key[i] = b; s_key[l] = a;
+                        const uint32_t va = s_val[i]; s_val[i] = s_val[l]; s_val[l] = va;
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (!act[r]) continue;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 128 * (wave + 4 * r) + 64 * h + lane;
+                    key[r][h] = s_key[e]; val[r][h] = s_val[e];
+                }
+            }
+            __syncthreads();                                                 // the next merge level (or the next tile) stores into the arrays again
+            reg_steps(k, 64);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (!act[r]) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 128 * (wave + 4 * r) + 64 * h + lane;
+                if (e < n) {
+                    const uint32_t gid = (uint32_t)key[r][h];               // low word of the sort key = Gaussian id
+                    point_list[range.x + e] = refine_block_bits(val[r][h], rec[gid], tile_x0, tile_y0);
+                    tile_keys[range.x + e] = tile;
+                    list_gauss[range.x + e] = gid;
+                }
+            }
+        }
+        return;
+    }
     for (int i = tid; i < npad; i += THREADS) {
         if (i < n) {
             const uint4 e = sc_pack[range.x + i];
@@ -567,13 +709,14 @@ template <int CAP, int THREADS, int MIN_N>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int n_tiles, const uint32_t* __restrict__ limit_dev, const uint32_t* __restrict__ order,
                                                             const uint2* __restrict__ ranges, const uint4* __restrict__ sc_pack,
                                                             uint32_t* __restrict__ point_list, uint32_t* __restrict__ tile_keys,
-                                                            uint32_t* __restrict__ list_gauss, const SplatRec* __restrict__ rec, int gx) {
+                                                            uint32_t* __restrict__ list_gauss, const SplatRec* __restrict__ rec, int gx,
+                                                            int lds_only /* A/B + test hook: every step through LDS, as rounds 2-5 */) {
     __shared__ unsigned long long s_key[CAP];
     __shared__ uint32_t s_val[CAP];
     int limit = n_tiles;
     if (limit_dev) { const int l = (int)*limit_dev; limit = l < limit ? l : limit; }
     for (int bi = blockIdx.x; bi < limit; bi += gridDim.x) {
-        tile_sort_one<CAP, THREADS, MIN_N>(s_key, s_val, order[bi], ranges, sc_pack, point_list, tile_keys, list_gauss, rec, gx);
+        tile_sort_one<CAP, THREADS, MIN_N>(s_key, s_val, order[bi], ranges, sc_pack, point_list, tile_keys, list_gauss, rec, gx, lds_only);
         __syncthreads();   // the LDS arrays are reused by the next list
     }
 }
@@ -906,6 +1049,7 @@ using namespace gsicp;
 extern "C" {
 
 int gsicp_abi_version(void) { return GSICP_ABI_VERSION; }
+int gsicp_raster_set_tile_sort_lds(int lds_only) { return tile_sort_lds_flag().exchange(lds_only ? 1 : 0); }
 int gsicp_raster_last_zero_region(void** ptr, size_t* words) {
     if (!ptr || !words) return -2;
     *ptr = g_last_zero_ptr; *words = g_last_zero_words;
@@ -1090,7 +1234,7 @@ static int raster_forward_impl(gsicp_resize_fn geom_alloc, void* geom_user, gsic
         { ProfileScope ps(ST_TILE_SORT, stream);
           hipLaunchKernelGGL((tile_sort_kernel<SORT_SMALL, 256, 0>), dim3(n_local), dim3(256), 0, stream, n_local, (const uint32_t*)nullptr, order, ranges,
                              (const uint4*)(bin + BL.scatter_pack), point_list,
-                             (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss), (const SplatRec*)rec, gx); }
+                             (uint32_t*)(bin + BL.tile_keys), (uint32_t*)(bin + BL.list_gauss), (const SplatRec*)rec, gx, tile_sort_lds_flag().load()); }
     }
 
     BlendArgs ba;

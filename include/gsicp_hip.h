@@ -144,6 +144,12 @@ int gsicp_raster_layout(int P, int num_rendered, int width, int height, size_t o
  * same gradients; the order in which a Gaussian's per-tile records are added differs (tests/test_raster_gpu.py compares them). */
 int gsicp_raster_set_legacy_backward(int legacy);
 
+/* Test / A-B hook: which sorting network the per-tile sort of the forward runs.  0 (default) = round 6's — every compare-exchange with partner distance < 128 in
+ * REGISTERS (lane exchanges by DPP / v_permlane swaps; only the cross-block steps of lists above 128 entries go through LDS); 1 = every step through LDS, as rounds 2-5.
+ * Process-wide; also GSICP_TILE_SORT_LDS=1 at load.  Returns the previous value.  Same network, same total order: the lists are the same bits
+ * (tests/test_raster_gpu.py). */
+int gsicp_raster_set_tile_sort_lds(int lds_only);
+
 /* A HIP stream restricted to `n_cus` compute units starting at CU-mask bit `first_cu` (hipExtStreamCreateWithCUMask; MI355X: 256 CUs in 8 XCDs, consecutive
  * mask bits go round the XCDs, so a contiguous range is spread evenly over them).  Round 6 experiment (default off): the tracker on dedicated CUs
  * (GSICP_TRACKER_CU_MASK="first:count" at gsicp_gicp_create) and the mapper's stream on the complement, instead of a high-priority tracker stream sharing

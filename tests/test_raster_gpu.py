@@ -649,3 +649,41 @@ def test_sharded_wrapper_collectives_on_rccl_world1(hip_lib):
         assert torch.equal(outs[0][3], outs[1][3])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [3, 40, 64, 65, 100, 128, 129, 200, 256, 257, 400, 512, 513, 900, 1024, 1025, 2500])
+def test_register_tile_sort_equals_the_lds_network_and_the_oracle(hip_lib, n):
+    """Round 6: the per-tile sort keeps every compare-exchange with partner distance < 128 in REGISTERS (lane exchanges; LDS only for the cross-block steps
+    of lists above 128 entries).  One list length per size class of the network — 64, 128, 256, 512, 1024 padded entries, their edges, and the chunked path
+    beyond 1024 — with exact depth TIES (the Gaussian id must break them): block bits, Gaussian ids, tile keys and images are the same
+    bits as the all-LDS network of rounds 2-5 (gsicp_raster_set_tile_sort_lds), and the lists equal the oracle's stable 64-bit sort."""
+    cam = synth.make_camera(48, 32, 40.0, 40.0)                    # 3 x 2 tiles
+    g = synth.random_gaussians(n, seed=100 + n, spread=0.2, zmin=2.0, zmax=6.0)
+    g["scales"] = (g["scales"] * 6.0).astype(np.float32)          # every Gaussian covers the whole image: every tile's list has n entries
+    g["opacities"] = (g["opacities"] * 0.02 + 0.01).astype(np.float32)
+    if n >= 8:
+        g["means3D"][: n // 4, 2] = g["means3D"][n // 4: 2 * (n // 4), 2]      # a quarter of the depths tied pairwise
+    out = {}
+    prev = hip_lib.gsicp_raster_set_tile_sort_lds(0)
+    try:
+        for lds in (0, 1):
+            hip_lib.gsicp_raster_set_tile_sort_lds(lds)
+            p = run_product(g, cam, [0, 0, 0])
+            geom, binning, img = p["scratch"]
+            lay = (__import__("ctypes").c_size_t * 12)()
+            hip_lib.gsicp_raster_layout(n, p["num_rendered"], 48, 32, lay)
+            b8 = binning.cpu().numpy()
+            R = p["num_rendered"]
+            raw = b8[lay[4]: lay[4] + 4 * R].view(np.uint32).copy()
+            s = util.read_scratch(hip_lib, p["scratch"], n, R, 48, 32)
+            # (the raw words carry EMISSION SLOTS, whose allocation order across the preprocess workgroups differs from run to run above 256 Gaussians: the block
+            # bits on top of them and the Gaussian ids behind them are what must agree)
+            out[lds] = (raw >> np.uint32(28), s["point_list"].copy(), s["tile_keys"].copy(), s["ranges"].copy(), p["color"].copy())
+    finally:
+        hip_lib.gsicp_raster_set_tile_sort_lds(prev)
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    longest = int((out[0][3][:, 1].astype(np.int64) - out[0][3][:, 0]).max())
+    assert longest >= (n + 1) // 2, f"the scene must put most of its {n} Gaussians into one tile list (longest: {longest})"
+    o = util.oracle_forward(g, cam, [0, 0, 0], 0)
+    assert np.array_equal(out[0][1], o["point_list"]) and np.array_equal(out[0][3], o["ranges"])
