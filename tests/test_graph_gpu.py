@@ -585,3 +585,45 @@ def test_captured_iteration_is_bit_identical_with_and_without_sparse_gradients_a
     for k in res["new"][1]:
         assert torch.equal(res["new"][1][k], res["old"][1][k]), k
         assert torch.equal(res["new"][2][k][0], res["old"][2][k][0]) and torch.equal(res["new"][2][k][1], res["old"][2][k][1]), k
+
+
+@pytest.mark.parametrize("which", ["default_activations", "torch_activations"])
+def test_graph_with_separate_activation_operators_follows_the_fused_graph(which):
+    """MapperIterationGraph(activations=...): the activation getters as operators of their own (one fused launch, or the reference's torch ops) instead of inside
+    the rasteriser's preprocess kernels — the dense-gradient form of the captured iteration (no sparse rows: the activation backward reads every row), with the
+    step bump in the loss and the pre-zeroed forward still on.  Four replays over two views follow the fused-activation graph: same losses to 1e-5, parameters
+    within Adam's last-bits tolerance."""
+    import gs_icp_slam_amd.graph as graph_mod
+    from diff_gaussian_rasterization import GaussianRasterizer
+    P, W, H = 20000, 320, 200
+    res = {}
+    views = None
+    for mode in ("fused", which):
+        g, cam, params, opt = _mapper_setup(P, W, H, capturable=True)
+        if views is None:
+            views = []
+            for pose in (synth.DEFAULT_POSE_A, synth.se3((12.5, 27.0, 0.5), (-0.88, -0.22, -1.08))):
+                cam_k = synth.make_camera(W, H, cam["fx"], cam["fy"], pose)
+                rs_k = make_settings(cam_k, [0.0, 0.0, 0.0])
+                t2 = torch_inputs(synth.s_map(P, seed=5, perturb_seed=7))
+                with torch.no_grad():
+                    d, c, _, _ = GaussianRasterizer(rs_k)(means3D=t2["means3D"], means2D=torch.zeros_like(t2["means3D"]), shs=t2["shs"],
+                                                          opacities=t2["opacities"], scales=t2["scales"], rotations=t2["rotations"])
+                views.append((rs_k, c.clone(), d.clone()))
+        act = None if mode == "fused" else getattr(graph_mod, mode)
+        mg = graph_mod.MapperIterationGraph(params, opt, H, W, cam["tanfovx"], cam["tanfovy"], sh_degree=0, capacity=2_000_000, warmup=2, activations=act)
+        assert mg._sparse == (mode == "fused") and mg._bump_in_loss and mg._prezero
+        mg.set_view(views[0][0].viewmatrix, views[0][0].projmatrix, views[0][0].campos, views[0][1], views[0][2])
+        mg.capture()
+        losses = []
+        for k in (0, 1, 1, 0):
+            rs_k, gt_c, gt_d = views[k]
+            mg.set_view(rs_k.viewmatrix, rs_k.projmatrix, rs_k.campos, gt_c, gt_d)
+            losses.append(float(mg.step()))
+        torch.cuda.synchronize()
+        assert not mg.overflowed() and mg.skipped_steps() == 0 and int(opt.state[params["means3D"]]["step"].item()) == 4
+        res[mode] = (losses, {k: v.detach().clone() for k, v in params.items()})
+        mg.release()
+    np.testing.assert_allclose(res[which][0], res["fused"][0], rtol=1e-5)
+    for k in res["fused"][1]:
+        torch.testing.assert_close(res[which][1][k], res["fused"][1][k], rtol=1e-4, atol=1e-6, msg=lambda m, k=k: f"{k}: {m}")
